@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/ by RUNNING THE REFERENCE'S OWN PYTHON FILES.
+
+Run only in the build container (needs /root/reference; the GPU box has no copy):
+
+    python tests/golden/make_golden.py
+
+What is executed for real (imported from /root/reference, unmodified):
+  * arxiv_pyg/criterion.py   -> kd / fitnet / at / gpw / lpw / nce criteria
+  * ppi_pyg/criterion.py     -> multi-label kd_criterion
+  * arxiv_pyg/gnn.py         -> GCN, SAGE, ProjectionGCD, train(), test()
+  * arxiv_pyg/gnn_kd_and_aux.py -> train() (KD + aux combination rule)
+
+What is shimmed (third-party packages that are neither vendored by the reference nor installable
+here -- SURVEY.md 8c): ``torch_geometric`` (GCNConv, SAGEConv, utils.softmax, utils.subgraph,
+transforms.ToSparseTensor -> the oracle restatements), ``ogb`` (Evaluator -> SURVEY 9.10),
+``torch.utils.tensorboard`` (unused by the functions called).  The goldens therefore PIN the
+reference's own code (loss formulas, model structure, train/eval step) and leave the PyG operator
+semantics pinned only by tests/test_oracle_known_answers.py.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+import oracle.nn as onn  # noqa: E402
+import oracle.sparse as osp  # noqa: E402
+import oracle.utils as outils  # noqa: E402
+
+
+class _Evaluator:
+    def __init__(self, name=None):
+        self.name = name
+
+    def eval(self, d):
+        yt, yp = d["y_true"].cpu().numpy(), d["y_pred"].cpu().numpy()
+        return {"acc": float((yt == yp).mean())}
+
+
+def install_shims():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    utils = mod("torch_geometric.utils", softmax=outils.softmax, subgraph=outils.subgraph,
+                to_dense_adj=None, negative_sampling=None, add_self_loops=None)
+    nn_ = mod("torch_geometric.nn", GCNConv=onn.GCNConv, SAGEConv=onn.SAGEConv)
+    tr = mod("torch_geometric.transforms", ToSparseTensor=osp.ToSparseTensor)
+    mod("torch_geometric", utils=utils, nn=nn_, transforms=tr)
+    mod("torch_sparse", SparseTensor=osp.SparseTensor)
+    npp = mod("ogb.nodeproppred", PygNodePropPredDataset=None, Evaluator=_Evaluator)
+    mod("ogb", nodeproppred=npp)
+    mod("torch.utils.tensorboard", SummaryWriter=object)
+
+
+def load_ref(relpath, name):
+    path = os.path.join(REF, relpath)
+    d = os.path.dirname(path)
+    sys.path.insert(0, d)  # `from logger import Logger`, `from criterion import *`
+    try:
+        for stale in ("criterion", "logger"):
+            sys.modules.pop(stale, None)
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+    finally:
+        sys.path.remove(d)
+    return m
+
+
+def t2n(t):
+    return t.detach().cpu().numpy().copy()  # copy: parameters are later updated in place
+
+
+# ------------------------------------------------------------------------------------------------
+def criterion_inputs(seed=0, n=48, C=7, P=12, Ds=10, Dt=17, E=160):
+    g = torch.Generator().manual_seed(seed)
+    d = dict(
+        logits=torch.randn(n, C, generator=g) * 2,
+        labels=torch.randint(0, C, (n,), generator=g),
+        teacher_logits=torch.randn(n, C, generator=g) * 3,
+        feat_p=torch.randn(n, P, generator=g),
+        tfeat_p=torch.relu(torch.randn(n, P, generator=g)) + 0.01,
+        feat=torch.relu(torch.randn(n, Ds, generator=g)) * 0.7,
+        tfeat=torch.relu(torch.randn(n, Dt, generator=g)) * 0.5,
+    )
+    # directed edge list over the n nodes, CSR (row-major) order like adj_t.coo(); some nodes get
+    # no incoming edge, a few get many
+    src = torch.randint(0, n, (E,), generator=g)
+    dst = torch.cat([torch.randint(0, n // 2, (E - 30,), generator=g), torch.full((30,), 3)])
+    key = torch.unique(src * n + dst)
+    d["edge_index"] = torch.stack([key // n, key % n])
+    return d
+
+
+def run_criterion_case(fn, tensors_req, *args, np_seed=None, **kw):
+    """Call ``fn`` with grad-enabled clones; returns losses and grads of ``loss`` wrt inputs."""
+    leaves = {k: v.clone().requires_grad_(True) for k, v in tensors_req.items()}
+    if np_seed is not None:
+        np.random.seed(np_seed)
+    out = fn(leaves, *args, **kw)
+    loss, loss_cls, loss_aux = out
+    grads = torch.autograd.grad(loss, list(leaves.values()), allow_unused=True, retain_graph=True)
+    aux_grads = torch.autograd.grad(loss_aux, list(leaves.values()), allow_unused=True)
+    rec = {"loss": t2n(loss), "loss_cls": t2n(loss_cls), "loss_aux": t2n(loss_aux)}
+    for (k, _), g, ga in zip(leaves.items(), grads, aux_grads):
+        rec["grad_" + k] = t2n(g) if g is not None else np.zeros(0, np.float32)
+        rec["auxgrad_" + k] = t2n(ga) if ga is not None else np.zeros(0, np.float32)
+    return rec
+
+
+def make_criterion_goldens():
+    ref = load_ref("arxiv_pyg/criterion.py", "ref_arxiv_criterion")
+    refp = load_ref("ppi_pyg/criterion.py", "ref_ppi_criterion")
+    d = criterion_inputs()
+    out = {"in_" + k: t2n(v) for k, v in d.items()}
+    cases = {}
+
+    cases["kd"] = run_criterion_case(
+        lambda L: ref.kd_criterion(L["logits"], d["labels"], d["teacher_logits"], 0.9, 4.0),
+        {"logits": d["logits"]})
+    cases["kd_a05_T1"] = run_criterion_case(
+        lambda L: ref.kd_criterion(L["logits"], d["labels"], d["teacher_logits"], 0.5, 1.0),
+        {"logits": d["logits"]})
+    cases["fitnet"] = run_criterion_case(
+        lambda L: ref.fitnet_criterion(L["logits"], d["labels"], L["feat"], L["tfeat"], 1000),
+        {"logits": d["logits"], "feat": d["feat_p"], "tfeat": d["tfeat_p"]})
+    cases["at"] = run_criterion_case(
+        lambda L: ref.at_criterion(L["logits"], d["labels"], L["feat"], L["tfeat"], 1000),
+        {"logits": d["logits"], "feat": d["feat"], "tfeat": d["tfeat"]})
+    for kern in ("cosine", "poly", "l2", "rbf"):
+        # full (no subsampling) and subsampled (S=32 < n=48, np seed 123)
+        for tag, S, seed in (("full", 8192, None), ("sub", 32, 123)):
+            cases[f"gpw_{kern}_{tag}"] = run_criterion_case(
+                lambda L: ref.gpw_criterion(L["logits"], d["labels"], L["feat"], L["tfeat"], kern, 2.0, S),
+                {"logits": d["logits"], "feat": d["feat_p"], "tfeat": d["tfeat_p"]}, np_seed=seed)
+        for crit in ("kld", "mse"):
+            cases[f"lpw_{kern}_{crit}"] = run_criterion_case(
+                lambda L: ref.lpw_criterion(L["logits"], d["labels"], L["feat"], L["tfeat"], d["edge_index"],
+                                            kern, 100, crit),
+                {"logits": d["logits"], "feat": d["feat"], "tfeat": d["tfeat"]})
+    for tag, S, seed in (("full", 8192, None), ("sub", 32, 7)):
+        cases[f"nce_{tag}"] = run_criterion_case(
+            lambda L: ref.nce_criterion(L["logits"], d["labels"], L["feat"], L["tfeat"], 0.1, 0.075, S),
+            {"logits": d["logits"], "feat": d["feat_p"], "tfeat": d["tfeat_p"]}, np_seed=seed)
+
+    # PPI multi-label KD
+    g = torch.Generator().manual_seed(5)
+    pl = torch.randn(40, 11, generator=g)
+    py = (torch.rand(40, 11, generator=g) < 0.3).float()
+    pt = torch.randn(40, 11, generator=g) * 2
+    out["in_ppi_logits"], out["in_ppi_labels"], out["in_ppi_teacher"] = t2n(pl), t2n(py), t2n(pt)
+    cases["ppi_kd"] = run_criterion_case(lambda L: refp.kd_criterion(L["logits"], py, pt, 0.5, 1.0),
+                                         {"logits": pl})
+    for name, rec in cases.items():
+        for k, v in rec.items():
+            out[f"{name}__{k}"] = v
+    np.savez_compressed(os.path.join(HERE, "criterion.npz"), **out)
+    print("criterion.npz:", len(cases), "cases")
+
+
+# ------------------------------------------------------------------------------------------------
+def tiny_graph(seed=1, n=72, F_in=8, C=5, Dt=20, E=260):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n, (E,), generator=g)
+    dst = torch.cat([torch.randint(0, n, (E - 40,), generator=g), torch.full((40,), 5)])
+    keep = src != dst
+    edge_index = torch.stack([src[keep], dst[keep]])
+    perm = torch.randperm(n, generator=g)
+    return dict(
+        edge_index=edge_index, x=torch.randn(n, F_in, generator=g),
+        y=torch.randint(0, C, (n, 1), generator=g),
+        train_idx=perm[:40].clone(), valid_idx=perm[40:55].clone(), test_idx=perm[55:].clone(),
+        teacher_out_feat=torch.relu(torch.randn(n, Dt, generator=g)),
+        teacher_logits=torch.randn(n, C, generator=g) * 3,
+    )
+
+
+def make_train_goldens():
+    ref = load_ref("arxiv_pyg/gnn.py", "ref_arxiv_gnn")
+    ref2 = load_ref("arxiv_pyg/gnn_kd_and_aux.py", "ref_arxiv_gnn_kd_and_aux")
+    G = tiny_graph()
+    n, F_in = G["x"].shape
+    C, Dt, H, P, L = 5, G["teacher_out_feat"].shape[1], 16, 12, 3
+    out = {"in_" + k: t2n(v) for k, v in G.items()}
+    out["hp"] = np.array([H, P, L, C], dtype=np.int64)
+
+    data = types.SimpleNamespace(x=G["x"], y=G["y"], edge_index=G["edge_index"], num_nodes=n)
+    data = osp.ToSparseTensor()(data)
+    data.adj_t = data.adj_t.to_symmetric()
+    rowptr, col, _ = data.adj_t.csr()
+    out["adj_rowptr"], out["adj_col"] = t2n(rowptr), t2n(col)
+    split_idx = {"train": G["train_idx"], "valid": G["valid_idx"], "test": G["test_idx"]}
+    ei = torch.stack(data.adj_t.coo()[:2])
+    edge_index_tr = outils.subgraph(G["train_idx"], ei, relabel_nodes=True)[0]
+    out["train_subgraph_edge_index"] = t2n(edge_index_tr)
+
+    def args_for(mode, **kw):
+        a = dict(training=mode, alpha=0.9, kd_T=4.0, beta=0.5, nce_T=0.075, max_samples=24, proj_dim=P, kernel="rbf")
+        a.update(kw)
+        return argparse.Namespace(**a)
+
+    runs = [
+        ("gcn", "supervised", {}, ref), ("gcn", "kd", {}, ref),
+        ("gcn", "nce", dict(beta=0.1), ref), ("gcn", "nce", dict(beta=0.1, max_samples=8192), ref),
+        ("gcn", "gpw", dict(kernel="cosine", beta=100.0), ref), ("gcn", "gpw", dict(kernel="rbf", beta=10.0), ref),
+        ("gcn", "fitnet", dict(beta=10.0), ref), ("gcn", "at", dict(beta=10.0), ref),
+        ("gcn", "gcd", dict(beta=0.1), ref),
+        ("sage", "lpw", dict(kernel="rbf", beta=100.0), ref), ("sage", "lpw", dict(kernel="cosine", beta=100.0), ref),
+        ("sage", "kd", {}, ref), ("sage", "nce", dict(beta=0.1), ref),
+        ("gcn", "nce", dict(beta=0.01, nce_T=0.05), ref2), ("sage", "lpw", dict(kernel="l2", beta=1.0), ref2),
+    ]
+    names = []
+    for i, (gnn, mode, kw, R) in enumerate(runs):
+        tag = f"run{i:02d}"
+        names.append(f"{tag}:{gnn}:{mode}:{'kdaux' if R is ref2 else 'aux'}:" +
+                     ",".join(f"{k}={v}" for k, v in sorted(kw.items())))
+        a = args_for(mode, **kw)
+        torch.manual_seed(100 + i)
+        np.random.seed(100 + i)
+        Model = R.GCN if gnn == "gcn" else R.SAGE
+        model = Model(F_in, H, C, L, 0.0)  # dropout 0: no device-RNG coupling in the goldens
+        sp = tp = None
+        if mode in ("nce", "gpw", "fitnet"):
+            sp = torch.nn.Sequential(torch.nn.Linear(H, P), torch.nn.BatchNorm1d(P), torch.nn.ReLU())
+            tp = torch.nn.Sequential(torch.nn.Linear(Dt, P), torch.nn.BatchNorm1d(P), torch.nn.ReLU())
+        elif mode == "gcd":
+            sp, tp = R.ProjectionGCD(H, P), R.ProjectionGCD(Dt, P)
+        params = [{"params": model.parameters(), "lr": 0.01}]
+        if sp is not None:
+            params += [{"params": sp.parameters(), "lr": 0.01}, {"params": tp.parameters(), "lr": 0.01}]
+        opt = torch.optim.Adam(params)
+        for k, v in model.state_dict().items():
+            out[f"{tag}__init__model.{k}"] = t2n(v)
+        if sp is not None:
+            for k, v in sp.state_dict().items():
+                out[f"{tag}__init__sproj.{k}"] = t2n(v)
+            for k, v in tp.state_dict().items():
+                out[f"{tag}__init__tproj.{k}"] = t2n(v)
+        logits0, accs0 = R.test(model, data, split_idx, _Evaluator())  # eval at the initial state
+        out[f"{tag}__eval0_logits"] = t2n(logits0)
+        out[f"{tag}__eval0_accs"] = np.array(accs0, dtype=np.float64)
+        losses = []
+        for _ in range(3):
+            losses.append(R.train(model, data, G["train_idx"], opt, a, G["teacher_out_feat"], G["teacher_logits"],
+                                  sp, tp, edge_index_tr if mode == "lpw" else None))
+        # NOTE: biases that feed a BatchNorm have a mathematically zero gradient; under Adam their
+        # update is rounding noise / (|noise| + eps), so they (and running_mean, and therefore the
+        # post-training eval logits) are not reproducible across implementations.  Tests compare
+        # eval0_* tightly and exclude those entries from the final-state comparison.
+        logits, accs = R.test(model, data, split_idx, _Evaluator())
+        out[f"{tag}__losses"] = np.array(losses, dtype=np.float64)
+        out[f"{tag}__eval_logits"] = t2n(logits)
+        out[f"{tag}__eval_accs"] = np.array(accs, dtype=np.float64)
+        for k, v in model.state_dict().items():
+            out[f"{tag}__final__model.{k}"] = t2n(v)
+    out["run_names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "train_arxiv.npz"), **out)
+    print("train_arxiv.npz:", len(runs), "runs")
+
+
+if __name__ == "__main__":
+    assert os.path.isdir(REF), "needs /root/reference (build container only)"
+    torch.set_num_threads(1)  # reproducible reduction order in the recorded numbers
+    install_shims()
+    make_criterion_goldens()
+    make_train_goldens()

@@ -1,0 +1,160 @@
+"""Oracle vs the golden vectors produced by the reference's own files (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle.criterion as OC
+import oracle.models as OM
+import oracle.sparse as OS
+import oracle.utils as OU
+from conftest import as_t
+
+RT, AT = 1e-6, 1e-7
+
+
+def _check(rec, G, name):
+    for k, v in rec.items():
+        ref = G[f"{name}__{k}"]
+        np.testing.assert_allclose(v, ref, rtol=2e-5, atol=1e-7, err_msg=f"{name}:{k}")
+
+
+def _run(fn, leaves, np_seed=None):
+    L = {k: v.clone().requires_grad_(True) for k, v in leaves.items()}
+    if np_seed is not None:
+        np.random.seed(np_seed)
+    loss, loss_cls, loss_aux = fn(L)
+    g = torch.autograd.grad(loss, list(L.values()), allow_unused=True, retain_graph=True)
+    ga = torch.autograd.grad(loss_aux, list(L.values()), allow_unused=True)
+    rec = {"loss": loss.detach().numpy(), "loss_cls": loss_cls.detach().numpy(), "loss_aux": loss_aux.detach().numpy()}
+    for (k, _), a, b in zip(L.items(), g, ga):
+        rec["grad_" + k] = a.numpy() if a is not None else np.zeros(0, np.float32)
+        rec["auxgrad_" + k] = b.numpy() if b is not None else np.zeros(0, np.float32)
+    return rec
+
+
+def criterion_cases(G, C=OC, dev="cpu"):
+    """(name, fn(leaves)->triple, leaves, np_seed) for every golden criterion case."""
+    d = {k[3:]: as_t(G[k], dev) for k in G.files if k.startswith("in_")}
+    cases = [
+        ("kd", lambda L: C.kd_criterion(L["logits"], d["labels"], d["teacher_logits"], 0.9, 4.0), {"logits": d["logits"]}, None),
+        ("kd_a05_T1", lambda L: C.kd_criterion(L["logits"], d["labels"], d["teacher_logits"], 0.5, 1.0), {"logits": d["logits"]}, None),
+        ("fitnet", lambda L: C.fitnet_criterion(L["logits"], d["labels"], L["feat"], L["tfeat"], 1000),
+         {"logits": d["logits"], "feat": d["feat_p"], "tfeat": d["tfeat_p"]}, None),
+        ("at", lambda L: C.at_criterion(L["logits"], d["labels"], L["feat"], L["tfeat"], 1000),
+         {"logits": d["logits"], "feat": d["feat"], "tfeat": d["tfeat"]}, None),
+    ]
+    for kern in ("cosine", "poly", "l2", "rbf"):
+        for tag, S, seed in (("full", 8192, None), ("sub", 32, 123)):
+            cases.append((f"gpw_{kern}_{tag}",
+                          lambda L, kern=kern, S=S: C.gpw_criterion(L["logits"], d["labels"], L["feat"], L["tfeat"], kern, 2.0, S),
+                          {"logits": d["logits"], "feat": d["feat_p"], "tfeat": d["tfeat_p"]}, seed))
+        for crit in ("kld", "mse"):
+            cases.append((f"lpw_{kern}_{crit}",
+                          lambda L, kern=kern, crit=crit: C.lpw_criterion(L["logits"], d["labels"], L["feat"], L["tfeat"],
+                                                                         d["edge_index"], kern, 100, crit),
+                          {"logits": d["logits"], "feat": d["feat"], "tfeat": d["tfeat"]}, None))
+    for tag, S, seed in (("full", 8192, None), ("sub", 32, 7)):
+        cases.append((f"nce_{tag}", lambda L, S=S: C.nce_criterion(L["logits"], d["labels"], L["feat"], L["tfeat"], 0.1, 0.075, S),
+                      {"logits": d["logits"], "feat": d["feat_p"], "tfeat": d["tfeat_p"]}, seed))
+    return cases, d
+
+
+def test_criteria_match_reference(golden_criterion):
+    G = golden_criterion
+    cases, _ = criterion_cases(G)
+    assert len(cases) == 22
+    for name, fn, leaves, seed in cases:
+        _check(_run(fn, leaves, seed), G, name)
+
+
+def test_ppi_kd_matches_reference(golden_criterion):
+    G = golden_criterion
+    pl, py, pt = (as_t(G["in_ppi_" + k]) for k in ("logits", "labels", "teacher"))
+    _check(_run(lambda L: OC.ppi_kd_criterion(L["logits"], py, pt, 0.5, 1.0), {"logits": pl}), G, "ppi_kd")
+
+
+def test_loss_kd_only_alias(golden_criterion):
+    G = golden_criterion
+    d = {k[3:]: as_t(G[k]) for k in G.files if k.startswith("in_")}
+    v = OC.loss_kd_only(d["logits"], d["labels"], d["teacher_logits"], 0.9, 4.0)
+    np.testing.assert_allclose(v.numpy(), G["kd__loss_aux"], rtol=1e-6)
+
+
+def build_graph(G):
+    n = G["in_x"].shape[0]
+    adj = OS.to_sparse_tensor(as_t(G["in_edge_index"]), n).to_symmetric()
+    return adj
+
+
+def test_graph_structure_matches(golden_train):
+    G = golden_train
+    adj = build_graph(G)
+    rowptr, col, _ = adj.csr()
+    assert np.array_equal(rowptr.numpy(), G["adj_rowptr"]) and np.array_equal(col.numpy(), G["adj_col"])
+    ei = torch.stack(adj.coo()[:2])
+    sub = OU.subgraph(as_t(G["in_train_idx"]), ei, relabel_nodes=True)[0]
+    assert np.array_equal(sub.numpy(), G["train_subgraph_edge_index"])
+
+
+def parse_run(name):
+    tag, gnn, mode, flavour, kw = name.split(":")
+    hp = dict(alpha=0.9, kd_T=4.0, beta=0.5, nce_T=0.075, max_samples=24, kernel="rbf")
+    for item in filter(None, kw.split(",")):
+        k, v = item.split("=")
+        hp[k] = v if k == "kernel" else (int(v) if k == "max_samples" else float(v))
+    return tag, gnn, mode, flavour == "kdaux", hp
+
+
+def run_training(G, name, M, build_adj, dev="cpu", make_proj=None, subgraph_fn=None):
+    """Re-run one golden training run with module set ``M`` (oracle or product)."""
+    tag, gnn, mode, kdaux, hp = parse_run(name)
+    H, P, L, C = (int(v) for v in G["hp"])
+    x, y = as_t(G["in_x"], dev), as_t(G["in_y"], dev)
+    tr = as_t(G["in_train_idx"], dev)
+    split = {k: as_t(G[f"in_{k}_idx"], dev) for k in ("train", "valid", "test")}
+    tfeat, tlog = as_t(G["in_teacher_out_feat"], dev), as_t(G["in_teacher_logits"], dev)
+    adj = build_adj(G)
+    model = (M.GCN if gnn == "gcn" else M.SAGE)(x.shape[1], H, C, L, 0.0).to(dev)
+    model.load_state_dict({k.split("model.", 1)[1]: as_t(G[k], dev) for k in G.files if k.startswith(f"{tag}__init__model.")})
+    sp = tp = None
+    if mode in ("nce", "gpw", "fitnet"):
+        sp, tp = M.make_projection(H, P).to(dev), M.make_projection(tfeat.shape[1], P).to(dev)
+    elif mode == "gcd":
+        sp, tp = M.ProjectionGCD(H, P).to(dev), M.ProjectionGCD(tfeat.shape[1], P).to(dev)
+    if sp is not None:
+        sp.load_state_dict({k.split("sproj.", 1)[1]: as_t(G[k], dev) for k in G.files if k.startswith(f"{tag}__init__sproj.")})
+        tp.load_state_dict({k.split("tproj.", 1)[1]: as_t(G[k], dev) for k in G.files if k.startswith(f"{tag}__init__tproj.")})
+    groups = [{"params": model.parameters(), "lr": 0.01}]
+    if sp is not None:
+        groups += [{"params": sp.parameters(), "lr": 0.01}, {"params": tp.parameters(), "lr": 0.01}]
+    opt = torch.optim.Adam(groups)
+    ei = as_t(G["train_subgraph_edge_index"], dev) if mode == "lpw" else None
+    logits0, accs0 = M.evaluate(model, x, adj, y, split)
+    np.random.seed(100 + int(tag[3:]))
+    losses = [M.train_step(model, x, adj, y, tr, opt, mode, hp, tfeat, tlog, sp, tp, ei, kd_and_aux=kdaux) for _ in range(3)]
+    return model, np.array(losses), logits0, np.array(accs0)
+
+
+def noise_driven(key, n_layers):
+    """Pre-BatchNorm biases / running means: zero true gradient, Adam turns rounding noise into steps."""
+    if "running_mean" in key or "num_batches_tracked" in key:
+        return True
+    for i in range(n_layers - 1):
+        if key in (f"convs.{i}.bias", f"convs.{i}.lin_l.bias"):
+            return True
+    return False
+
+
+def test_train_and_eval_match_reference(golden_train):
+    G = golden_train
+    for name in G["run_names"]:
+        name = str(name)
+        tag = name.split(":")[0]
+        model, losses, logits0, accs0 = run_training(G, name, OM, build_graph)
+        np.testing.assert_allclose(logits0.numpy(), G[f"{tag}__eval0_logits"], rtol=1e-5, atol=1e-6, err_msg=name)
+        np.testing.assert_allclose(accs0, G[f"{tag}__eval0_accs"], err_msg=name)
+        np.testing.assert_allclose(losses, G[f"{tag}__losses"], rtol=1e-5, atol=1e-7, err_msg=name)
+        for k, v in model.state_dict().items():
+            if noise_driven(k, int(G["hp"][2])):
+                continue
+            np.testing.assert_allclose(v.numpy(), G[f"{tag}__final__model.{k}"], rtol=1e-4, atol=1e-6, err_msg=f"{name}:{k}")
