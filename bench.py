@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- training epochs/sec of the BASELINE.json workload on N MI355X GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+One "step" = one epoch of the reference loop /root/reference/arxiv_pyg/gnn.py:333-340: one full-graph
+``train()`` step (forward + G-CRD loss + backward + Adam + 3x .item()) PLUS one full-graph ``test()``
+(eval forward + argmax + 3 accuracies), on the synthetic ogbn-arxiv-shaped graph of SURVEY.md 8(d)
+(config 2: 3-layer GCN student, hidden 256, G-CRD with the run_gcn.sh:140-145 hyper-parameters
+beta=0.1, nce_T=0.075, max_samples=16384, proj_dim=256).  Inputs are resident in HBM before timing.
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying also
+  "roofline":     the SpMM aggregate kernel (K=256 GCN layer) timed with HIP events on its own stream
+                  inside the timed region; achieved = algorithmic bytes / avg launch time
+  "cpu_baseline": the CPU oracle (pure-PyTorch restatement of the reference path) timed on the host cores
+                  on the SAME synthetic inputs, a bounded sample of epochs (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+HP = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=16384, proj_dim=256, kernel="rbf")
+MODEL = dict(hidden=256, layers=3, dropout=0.5, lr=0.01)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scale", type=float, default=1.0, help="graph size multiplier (1.0 = ogbn-arxiv shape)")
+    ap.add_argument("--max-samples", type=int, default=HP["max_samples"])
+    ap.add_argument("--gnn", default="gcn", choices=["gcn", "sage"])
+    ap.add_argument("--training", default="nce", choices=["nce", "kd", "gpw", "lpw", "supervised"])
+    ap.add_argument("--cpu-epochs", type=int, default=3, help="CPU-oracle epochs timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def seed_all(seed):
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def build_problem(M, data, device, args, hp):
+    """Model + projection heads + Adam exactly as gnn.py:251-315 builds them."""
+    Net = M.GCN if args.gnn == "gcn" else M.SAGE
+    model = Net(data.num_features, MODEL["hidden"], data.num_classes, MODEL["layers"], MODEL["dropout"]).to(device)
+    sp = tp = None
+    groups = [{"params": model.parameters(), "lr": MODEL["lr"]}]
+    if args.training in ("nce", "gpw"):
+        sp = M.make_projection(MODEL["hidden"], hp["proj_dim"]).to(device)
+        tp = M.make_projection(data.teacher_out_feat.shape[1], hp["proj_dim"]).to(device)
+        groups += [{"params": sp.parameters(), "lr": MODEL["lr"]}, {"params": tp.parameters(), "lr": MODEL["lr"]}]
+    opt = torch.optim.Adam(groups)
+    return model, sp, tp, opt
+
+
+def to_device(data, device):
+    import types
+    d = types.SimpleNamespace(**vars(data))
+    d.x, d.y = data.x.to(device), data.y.to(device)
+    d.adj_t = data.adj_t.to(device)
+    d.split_idx = {k: v.to(device) for k, v in data.split_idx.items()}
+    d.teacher_out_feat = data.teacher_out_feat.to(device)
+    d.teacher_logits = data.teacher_logits.to(device)
+    return d
+
+
+def epoch(M, model, d, opt, args, hp, sp, tp, edge_index):
+    losses = M.train_step(model, d.x, d.adj_t, d.y, d.split_idx["train"], opt, args.training, hp,
+                          d.teacher_out_feat, d.teacher_logits, sp, tp, edge_index)
+    _, accs = M.evaluate(model, d.x, d.adj_t, d.y, d.split_idx)
+    return losses, accs
+
+
+class SpmmProbe:
+    """Brackets every egnn_spmm_csr_f32 launch of the timed region with HIP events on the launch stream."""
+
+    def __init__(self, ops):
+        self.ops, self.records, self.active = ops, [], False
+        self._orig = ops.spmm_raw
+
+    def __enter__(self):
+        def wrapped(adj, x, reduce="sum", src_scale=None, use_long_rows=True):
+            if not self.active:
+                return self._orig(adj, x, reduce, src_scale, use_long_rows)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = self._orig(adj, x, reduce, src_scale, use_long_rows)
+            b.record()
+            self.records.append((x.shape[1], adj.nnz(), adj.spmm_algorithmic_bytes(x.shape[1]), a, b))
+            return out
+        self.ops.spmm_raw = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.spmm_raw = self._orig
+
+    def summary(self, K):
+        ts = [(a.elapsed_time(b) * 1e-3, nbytes) for k, _, nbytes, a, b in self.records if k == K]
+        if not ts:
+            return None
+        avg = sum(t for t, _ in ts) / len(ts)
+        return dict(launches=len(ts), avg_s=avg, bytes=ts[0][1])
+
+
+def cpu_baseline(args, data, hp):
+    """The CPU oracle on the host cores: same inputs, same epoch definition, bounded number of epochs."""
+    import oracle.models as OM
+    import oracle.sparse as OS
+    import types
+    rowptr, col, _ = data.adj_t.csr()
+    d = types.SimpleNamespace(**vars(data))
+    d.adj_t = OS.SparseTensor(rowptr=rowptr, col=col, sparse_sizes=data.adj_t.sparse_sizes())
+    seed_all(args.seed)
+    model, sp, tp, opt = build_problem(OM, d, "cpu", args, hp)
+    times = []
+    for i in range(args.cpu_epochs + 1):
+        t0 = time.perf_counter()
+        OM.train_step(model, d.x, d.adj_t, d.y, d.split_idx["train"], opt, args.training, hp,
+                      d.teacher_out_feat, d.teacher_logits, sp, tp, None)
+        OM.evaluate(model, d.x, d.adj_t, d.y, d.split_idx)
+        times.append(time.perf_counter() - t0)
+    timed = times[1:]  # first epoch = warm-up (gcn_norm caching, allocator)
+    med = float(np.median(timed))
+    return dict(value=1.0 / med, unit="epochs/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{len(timed)} epochs after 1 warm-up, same synthetic graph/seeds, median {med:.3f} s/epoch "
+                       f"(pure-PyTorch CPU oracle; the reference's PyG stack is not installable)")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    hp = dict(HP, max_samples=args.max_samples)
+
+    import efficient_gnns_amd  # noqa: F401  (fails loudly if libegnn_hip.so is missing)
+    import efficient_gnns_amd.data as D
+    import efficient_gnns_amd.models as PM
+    import efficient_gnns_amd.ops as ops
+
+    if world > 1:
+        import efficient_gnns_amd.dist as dist_mod
+        return dist_mod.bench_main(args, hp, MODEL, rank, world, device)
+
+    seed_all(args.seed)
+    data = D.arxiv_like(args.scale, seed=args.seed)
+    d = to_device(data, device)
+    edge_index = None
+    if args.training == "lpw":
+        from efficient_gnns_amd.utils import subgraph
+        ei = torch.stack(d.adj_t.coo()[:2])
+        edge_index = subgraph(d.split_idx["train"], ei, relabel_nodes=True, num_nodes=d.num_nodes)[0]
+    model, sp, tp, opt = build_problem(PM, d, device, args, hp)
+
+    for _ in range(args.warmup):
+        epoch(PM, model, d, opt, args, hp, sp, tp, edge_index)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    train_ms = eval_ms = 0.0
+    with SpmmProbe(ops) as probe:
+        probe.active = True
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ev[0].record()
+            losses = PM.train_step(model, d.x, d.adj_t, d.y, d.split_idx["train"], opt, args.training, hp,
+                                   d.teacher_out_feat, d.teacher_logits, sp, tp, edge_index)
+            ev[1].record()
+            _, accs = PM.evaluate(model, d.x, d.adj_t, d.y, d.split_idx)
+            ev[2].record()
+            ev[2].synchronize()
+            train_ms += ev[0].elapsed_time(ev[1])
+            eval_ms += ev[1].elapsed_time(ev[2])
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        probe.active = False
+    K = MODEL["hidden"]
+    roof = probe.summary(K)
+    roofline = None
+    if roof:
+        gbs = roof["bytes"] / roof["avg_s"] / 1e9
+        traffic = os.environ.get("EGNN_SPMM_TRAFFIC_BYTES")
+        roofline = dict(bound="hbm", kernel=f"spmm_rows_kernel (egnn_spmm_csr_f32, K={K}, reduce=sum)",
+                        achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
+                        frac_of_measured_copy_peak=round(gbs / 6290.0, 4),
+                        algorithmic_bytes_per_launch=roof["bytes"], avg_launch_us=round(roof["avg_s"] * 1e6, 2),
+                        launches_timed=roof["launches"], traffic=float(traffic) if traffic else None)
+    cpu = cpu_baseline(args, data, hp) if args.cpu_epochs > 0 else None
+
+    out = dict(
+        metric="training epochs/sec, ogbn-arxiv 3-layer GCN student + G-CRD, 1/2/4/8 MI355X",
+        value=round(args.steps / elapsed, 3), unit="epochs/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
+        ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True, scaling="strong", vs_baseline=None,
+        dtype="f32", data="synthetic",
+        config=dict(workload=f"ogbn-arxiv-shaped synthetic graph (N={d.num_nodes}, nnz_sym={d.adj_t.nnz()}), "
+                             f"3-layer {args.gnn.upper()}-256 student + {args.training} (G-CRD) loss, full-graph "
+                             f"train step + eval per epoch",
+                    gnn=args.gnn, training=args.training, hidden=MODEL["hidden"], layers=MODEL["layers"],
+                    max_samples=hp["max_samples"], proj_dim=hp["proj_dim"], nce_T=hp["nce_T"], beta=hp["beta"],
+                    gemm_backend=ops.gemm_backend(), partitioning="single GPU"),
+        roofline=roofline, cpu_baseline=cpu,
+        phases_ms=dict(train_step=round(train_ms / args.steps, 3), eval=round(eval_ms / args.steps, 3)),
+        last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs],
+    )
+    if cpu:
+        out["speedup_vs_cpu_baseline"] = round(out["value"] / cpu["value"], 1)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""ctypes binding of libegnn_hip.so (the C ABI declared in include/egnn_hip.h).
+
+There is NO CPU fallback: if the shared object is missing or a tensor is not on a GPU the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libegnn_hip.so")
+
+_p, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/egnn_hip.h declares
+SIGNATURES = {
+    "egnn_abi_version": (_i32, []),
+    "egnn_error_string": (C.c_char_p, [_i32]),
+    "egnn_build_info": (_i32, [C.c_char_p, _sz]),
+    "egnn_spmm_csr_f32": (_i32, [_i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p, _i64, _i64, _p]),
+    "egnn_spmm_csr_max_bwd_f32": (_i32, [_i64, _i64, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p]),
+    "egnn_spmm_algorithmic_bytes": (_i64, [_i64, _i64, _i64, _i64, _i32, _i32]),
+    "egnn_rowptr_from_sorted_rows_i64": (_i32, [_p, _i64, _i64, _p, _p]),
+    "egnn_narrow_i64_to_i32": (_i32, [_p, _i64, _p, _p, _p]),
+    "egnn_gcn_norm_count_i64": (_i32, [_p, _p, _i64, _p, _p]),
+    "egnn_gcn_norm_fill_i64": (_i32, [_p, _p, _i64, _p, _p, _p, _p]),
+    "egnn_gcn_norm_values_i64": (_i32, [_p, _p, _i64, _p, _p, _p]),
+    "egnn_gemm_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _p]),
+    "egnn_ce_kd_ws_floats": (_sz, [_i64]),
+    "egnn_ce_kd_fwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _f32, _p, _p, _p]),
+    "egnn_ce_kd_bwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _f32, _p, _p, _p, _i64, _p]),
+    "egnn_gather_normalize_rows_f32": (_i32, [_p, _i64, _p, _i64, _i64, _f32, _p, _i64, _p, _p]),
+    "egnn_normalize_rows_bwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _f32, _p, _i64, _i32, _p]),
+    "egnn_nce_ws_floats": (_sz, [_i64]),
+    "egnn_nce_fwd_f32": (_i32, [_p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _p, _sz, _p]),
+    "egnn_nce_bwd_f32": (_i32, [_p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _p, _p, _p]),
+}
+
+_lib = None
+
+
+class HipExtensionError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the in-tree shared object (build it with ``python efficient-gnns_amd/build.py``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionError(
+            f"{LIB_PATH} is missing: build it with `python efficient-gnns_amd/build.py` "
+            "(__graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if lib.egnn_abi_version() != 1:
+        raise HipExtensionError("libegnn_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().egnn_error_string(rc).decode()
+        raise HipExtensionError(f"{what} failed: {msg} ({rc})")
+
+
+def ptr(t: "torch.Tensor | None") -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise HipExtensionError(
+                "efficient-gnns_amd kernels run on an MI355X only: got a CPU tensor (no CPU fallback exists; "
+                "move the tensor to the GPU)")
+
+
+def build_info() -> str:
+    buf = C.create_string_buffer(256)
+    check(load().egnn_build_info(buf, 256), "egnn_build_info")
+    return buf.value.decode()

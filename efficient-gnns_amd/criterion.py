@@ -1,0 +1,93 @@
+"""The reference's distillation criteria on the gfx950 kernels -- same names, signatures, defaults and
+3-tuple returns ``(loss, loss_cls, loss_aux)`` as /root/reference/arxiv_pyg/criterion.py:8,24,39,57,95,129,
+so ``from criterion import *`` in the reference's train loops resolves unchanged.
+
+Paper names: LSP = ``lpw_criterion``, GSP = ``gpw_criterion``, G-CRD = ``nce_criterion``.
+``loss_aux`` carries its own autograd graph (gnn_kd_and_aux.py:121-127 recombines it).
+Host-RNG coupling is preserved: one ``np.random.choice(n, S, replace=False)`` per gpw/nce call when S < n.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+
+__all__ = ["kd_criterion", "fitnet_criterion", "at_criterion", "gpw_criterion", "lpw_criterion", "nce_criterion",
+           "loss_kd_only", "ppi_kd_criterion"]
+
+
+def _sample_rows(n: int, max_samples: int, device):
+    """criterion.py:62-65,134-137: host NumPy global RNG, exactly one draw; None = keep every row."""
+    if max_samples < n:
+        pick = np.random.choice(n, max_samples, replace=False)
+        return torch.from_numpy(pick).to(device=device, dtype=torch.int64, non_blocking=True)
+    return None
+
+
+def kd_criterion(logits, labels, teacher_logits, alpha=0.9, T=4):
+    """Logit KD (criterion.py:8-21): CE + KL(softmax(teacher/T) || softmax(logits/T)) with reduction='mean'."""
+    loss_cls, loss_kd = ops.ce_and_kd(logits, labels, teacher_logits, T)
+    loss = loss_kd * (alpha * T * T) + loss_cls * (1 - alpha)
+    return loss, loss_cls, loss_kd
+
+
+def loss_kd_only(logits, labels, teacher_logits, alpha=0.9, T=4):
+    """north_star alias: the KD term alone (third return of ``kd_criterion``)."""
+    return kd_criterion(logits, labels, teacher_logits, alpha, T)[2]
+
+
+def fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000):
+    """FitNet (criterion.py:24-36): MSE between L2-normalised rows."""
+    loss_cls = ops.cross_entropy(logits, labels)
+    diff = ops.gather_normalize(feat) - ops.gather_normalize(teacher_feat)
+    loss_aux = (diff * diff).mean()
+    return loss_cls + beta * loss_aux, loss_cls, loss_aux
+
+
+def at_criterion(logits, labels, feat, teacher_feat, beta=1000):
+    """Attention transfer (criterion.py:39-54): per-node energies, L2-normalised ACROSS nodes."""
+    loss_cls = ops.cross_entropy(logits, labels)
+    e_s = (feat * feat).sum(-1)
+    e_t = (teacher_feat * teacher_feat).sum(-1)
+    d = e_s / e_s.norm().clamp_min(1e-12) - e_t / e_t.norm().clamp_min(1e-12)
+    loss_aux = (d * d).mean()
+    return loss_cls + beta * loss_aux, loss_cls, loss_aux
+
+
+def gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, max_samples=8192):
+    """GSP (criterion.py:57-92): MSE between all-pairs similarity matrices of student and teacher rows."""
+    from .ops_pairwise import gsp_loss
+    if kernel not in ("cosine", "poly", "l2", "rbf"):
+        raise NotImplementedError
+    loss_cls = ops.cross_entropy(logits, labels)
+    idx = _sample_rows(feat.shape[0], max_samples, feat.device)
+    loss_aux = gsp_loss(feat, teacher_feat, idx, kernel)
+    return loss_cls + beta * loss_aux, loss_cls, loss_aux
+
+
+def lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="cosine", beta=100, criterion="kld"):
+    """LSP (criterion.py:95-126): per-edge similarity, softmax over the edges sharing ``dst``, KL or MSE."""
+    from .ops_edge import lsp_loss
+    if kernel not in ("cosine", "poly", "l2", "rbf") or criterion not in ("kld", "mse"):
+        raise NotImplementedError
+    loss_cls = ops.cross_entropy(logits, labels)
+    loss_aux = lsp_loss(feat, teacher_feat, edge_index, kernel, criterion)
+    return loss_cls + beta * loss_aux, loss_cls, loss_aux
+
+
+def nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max_samples=8192):
+    """G-CRD (criterion.py:129-149): InfoNCE between unit student rows and unit teacher rows."""
+    loss_cls = ops.cross_entropy(logits, labels)
+    idx = _sample_rows(feat.shape[0], max_samples, feat.device)
+    fhat = ops.gather_normalize(feat, idx)
+    that = ops.gather_normalize(teacher_feat, idx)
+    loss_aux = ops.nce_unit(fhat, that, nce_T)
+    return loss_cls + beta * loss_aux, loss_cls, loss_aux
+
+
+def ppi_kd_criterion(logits, labels, teacher_logits, alpha=0.5, T=1):
+    """Multi-label KD of /root/reference/ppi_pyg/criterion.py:8-18 (BCE-with-logits twice)."""
+    from .ops_pairwise import bce_with_logits_pair
+    loss_cls, loss_kd = bce_with_logits_pair(logits, labels, teacher_logits)
+    return loss_kd * (alpha * T * T) + loss_cls * (1 - alpha), loss_cls, loss_kd

@@ -1,0 +1,123 @@
+// Dense fp32 GEMM entry point (K4): C = alpha * op(A) op(B) (+ bias), on the f32-input MFMA.
+// Replaces cuBLAS SGEMM under `x @ W` (GCNConv), nn.Linear (SAGEConv, projection heads) and their
+// backward GEMMs (/root/reference/arxiv_pyg/gnn.py:47,79,296-306,192).
+#include "gemm_core.h"
+
+using namespace egnn_gemm;
+
+namespace {
+
+struct GemmArgs {
+  int64_t M, N, K;
+  const float* A; int64_t lda;
+  const float* B; int64_t ldb;
+  const float* bias;
+  float* C; int64_t ldc;
+  float alpha;
+  const float* alpha_dev;  // optional device scalar multiplied into alpha
+  int split_k;
+  int64_t k_per_split;     // multiple of BK
+  float* ws;               // [split_k, M, N] when split_k > 1
+};
+
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+  using TS = TileShape<BM, BN>;
+  __shared__ __attribute__((aligned(16))) float smem[TS::SMEM_FLOATS];
+  const int64_t tiles_n = (g.N + BN - 1) / BN;
+  const int64_t m0 = (blockIdx.x / tiles_n) * BM;
+  const int64_t n0 = (blockIdx.x % tiles_n) * BN;
+  const int split = blockIdx.y;
+  const int64_t kbeg = split * g.k_per_split;
+  int64_t kend = kbeg + g.k_per_split;
+  if (kend > g.K) kend = g.K;
+
+  f32x16 acc[TS::TM][TS::TN];
+  zero_acc(acc);
+  IdentityXf id;
+  mainloop<BM, BN, AMAJ, BMAJ, VEC4>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kend, id, id, smem);
+
+  const int lane = egnn_lane();
+  const int wave = egnn_wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool partial = g.split_k > 1;
+  const float alpha = partial ? 1.f : g.alpha * (g.alpha_dev ? g.alpha_dev[0] : 1.f);
+  float* out = partial ? g.ws + (int64_t)split * g.M * g.N : g.C;
+  const int64_t ldo = partial ? g.N : g.ldc;
+#pragma unroll
+  for (int tn = 0; tn < TS::TN; ++tn) {
+    const int64_t c = n0 + acc_col<BM, BN>(wn, tn, lane);
+    if (c >= g.N) continue;
+    const float bv = (!partial && g.bias) ? g.bias[c] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TS::TM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + acc_row<BM, BN>(wm, tm, r, lane);
+        if (row < g.M) out[row * ldo + c] = alpha * acc[tm][tn][r] + bv;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
+  const int64_t total = g.M * g.N;
+  const float alpha = g.alpha * (g.alpha_dev ? g.alpha_dev[0] : 1.f);
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < g.split_k; ++k) s += g.ws[(int64_t)k * total + t];  // fixed order
+    const int64_t row = t / g.N, c = t % g.N;
+    g.C[row * g.ldc + c] = alpha * s + (g.bias ? g.bias[c] : 0.f);
+  }
+}
+
+template <int BM, int BN, int AMAJ, int BMAJ>
+int launch_tile(const GemmArgs& g, bool vec4, hipStream_t st) {
+  const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  if (tiles > 0x7fffffffLL) return EGNN_EINVAL;
+  dim3 grid((unsigned)tiles, (unsigned)g.split_k);
+  if (vec4) hipLaunchKernelGGL((gemm_kernel<BM, BN, AMAJ, BMAJ, true>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gemm_kernel<BM, BN, AMAJ, BMAJ, false>), grid, dim3(256), 0, st, g);
+  return EGNN_OK;
+}
+
+template <int AMAJ, int BMAJ>
+int launch_major(const GemmArgs& g, bool vec4, hipStream_t st) {
+  // narrow outputs (N <= 64, e.g. the 40-class layer) take the 128x64 tile
+  if (g.N <= 64) return launch_tile<128, 64, AMAJ, BMAJ>(g, vec4, st);
+  return launch_tile<128, 128, AMAJ, BMAJ>(g, vec4, st);
+}
+
+}  // namespace
+
+extern "C" int egnn_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                             int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
+                             int split_k, float* ws, size_t ws_bytes, void* stream) {
+  EGNN_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
+  if (M == 0 || N == 0) return EGNN_OK;
+  EGNN_CHECK_ARG(A && B && C && ldc >= N);
+  EGNN_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N));
+  if (split_k < 1) split_k = 1;
+  int64_t ksteps = (K + BK - 1) / BK;
+  if (split_k > ksteps) split_k = (int)(ksteps > 0 ? ksteps : 1);
+  if (split_k > 1) {
+    if (!ws || ws_bytes < (size_t)split_k * M * N * sizeof(float)) return EGNN_EWORKSPACE;
+  }
+  GemmArgs g{M, N, K, A, lda, B, ldb, bias, C, ldc, alpha, nullptr, split_k,
+             ((ksteps + split_k - 1) / split_k) * BK, ws};
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec4 = (lda % 4 == 0) && (ldb % 4 == 0) && egnn_aligned16(A) && egnn_aligned16(B);
+  const int amaj = trans_a ? MNMAJOR : KMAJOR;   // A stored [K,M] when transposed
+  const int bmaj = trans_b ? KMAJOR : MNMAJOR;   // B stored [N,K] when transposed, else [K,N]
+  int rc;
+  if (amaj == KMAJOR && bmaj == KMAJOR) rc = launch_major<KMAJOR, KMAJOR>(g, vec4, st);
+  else if (amaj == KMAJOR) rc = launch_major<KMAJOR, MNMAJOR>(g, vec4, st);
+  else if (bmaj == KMAJOR) rc = launch_major<MNMAJOR, KMAJOR>(g, vec4, st);
+  else rc = launch_major<MNMAJOR, MNMAJOR>(g, vec4, st);
+  if (rc != EGNN_OK) return rc;
+  if (split_k > 1) {
+    const int64_t blocks = (M * N + 255) / 256;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, g);
+  }
+  return egnn_launch_status();
+}

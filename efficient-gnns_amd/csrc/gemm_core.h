@@ -1,0 +1,172 @@
+// fp32 MFMA GEMM building blocks for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, == an fmaf chain).
+//
+// Block tile BM x BN, 256 threads = 4 waves in a 2 x 2 arrangement, each wave owning
+// (BM/2) x (BN/2) as TM x TN MFMA tiles of 32 x 32.  K is consumed in steps of BK = 16 through two
+// LDS buffers; global loads for step k+1 are issued before the MFMAs of step k and written to the
+// other LDS buffer after them (one barrier per step).  Both operands live in LDS k-contiguous
+// ([rows][BK+4]) whatever their global layout, so the inner loop is one ds_read_b128 per operand tile
+// per 4 MFMAs: lane l reads k = {4h .. 4h+3}, h = l >> 5, and MFMA #m of the group consumes element m
+// of both fragments -- a permutation of the k order that A and B share, so the sum is unchanged.
+// At 64 cycles per MFMA per SIMD the LDS and the staging VALU have an order of magnitude of slack;
+// the kernel is paced by the matrix pipe.
+#pragma once
+#include "common.h"
+
+namespace egnn_gemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 16;
+constexpr int LDS_LD = BK + 4;  // floats per LDS row: 80 B keeps every row 16-byte aligned
+
+constexpr int KMAJOR = 0;   // operand stored [rows, K] (k contiguous)
+constexpr int MNMAJOR = 1;  // operand stored [K, rows] (row index contiguous)
+
+struct IdentityXf {
+  __device__ __forceinline__ float operator()(float v, int64_t, int64_t) const { return v; }
+};
+
+// Stages one operand tile of R rows x BK through registers into LDS.  XF transforms in-range elements
+// (value, global row, global k) on the way; out-of-range elements are exact zeros.
+template <int R, int MAJOR, bool VEC4, class XF>
+struct Stager {
+  static constexpr int NV = R / 64;
+  float v[NV][4];
+
+  __device__ __forceinline__ void load(const float* __restrict__ p, int64_t ld, int64_t r0, int64_t rmax, int64_t k0,
+                                       int64_t kmax, const XF& xf) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if constexpr (MAJOR == KMAJOR) {
+        const int64_t r = r0 + (t >> 2) + 64 * i;
+        const int64_t k = k0 + (t & 3) * 4;
+        const float* q = p + r * ld + k;
+        if (r < rmax && VEC4 && k + 3 < kmax) {
+          const float4 x = *reinterpret_cast<const float4*>(q);
+          v[i][0] = xf(x.x, r, k); v[i][1] = xf(x.y, r, k + 1); v[i][2] = xf(x.z, r, k + 2); v[i][3] = xf(x.w, r, k + 3);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[i][j] = (r < rmax && k + j < kmax) ? xf(q[j], r, k + j) : 0.f;
+        }
+      } else {
+        constexpr int TPR = R / 4;          // threads per k-row
+        constexpr int KPP = 256 / TPR;      // k-rows per pass
+        const int64_t k = k0 + t / TPR + KPP * i;
+        const int64_t r = r0 + (t % TPR) * 4;
+        const float* q = p + k * ld + r;
+        if (k < kmax && VEC4 && r + 3 < rmax) {
+          const float4 x = *reinterpret_cast<const float4*>(q);
+          v[i][0] = xf(x.x, r, k); v[i][1] = xf(x.y, r + 1, k); v[i][2] = xf(x.z, r + 2, k); v[i][3] = xf(x.w, r + 3, k);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[i][j] = (k < kmax && r + j < rmax) ? xf(q[j], r + j, k) : 0.f;
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(float (*lds)[LDS_LD]) const {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if constexpr (MAJOR == KMAJOR) {
+        f32x4v x = {v[i][0], v[i][1], v[i][2], v[i][3]};
+        *reinterpret_cast<f32x4v*>(&lds[(t >> 2) + 64 * i][(t & 3) * 4]) = x;
+      } else {
+        constexpr int TPR = R / 4;
+        constexpr int KPP = 256 / TPR;
+        const int k = t / TPR + KPP * i;
+        const int r = (t % TPR) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[r + j][k] = v[i][j];
+      }
+    }
+  }
+};
+
+template <int BM, int BN>
+struct TileShape {
+  static constexpr int WM = BM / 2, WN = BN / 2;
+  static constexpr int TM = WM / 32, TN = WN / 32;
+  static constexpr int SMEM_FLOATS = 2 * (BM + BN) * LDS_LD;
+  static_assert(TM >= 1 && TN >= 1, "tile too small for the 2x2 wave arrangement");
+};
+
+// row / column of accumulator register `reg` of MFMA tile (tm, tn) inside the block tile
+template <int BM, int BN>
+__device__ __forceinline__ int acc_row(int wm, int tm, int reg, int lane) {
+  return wm * TileShape<BM, BN>::WM + tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+}
+template <int BM, int BN>
+__device__ __forceinline__ int acc_col(int wn, int tn, int lane) {
+  return wn * TileShape<BM, BN>::WN + tn * 32 + (lane & 31);
+}
+
+// acc += A[m0:m0+BM, kbeg:kend] * B[kbeg:kend, n0:n0+BN]   (all 256 threads must call with equal bounds)
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, class XFA, class XFB, int TM_, int TN_>
+__device__ __forceinline__ void mainloop(f32x16 (&acc)[TM_][TN_],
+                                         const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
+                                         const float* __restrict__ B, int64_t ldb, int64_t n0, int64_t N,
+                                         int64_t kbeg, int64_t kend, const XFA& xfa, const XFB& xfb, float* smem) {
+  using TS = TileShape<BM, BN>;
+  static_assert(TM_ == TS::TM && TN_ == TS::TN, "accumulator shape does not match the block tile");
+  float (*As)[BM][LDS_LD] = reinterpret_cast<float (*)[BM][LDS_LD]>(smem);
+  float (*Bs)[BN][LDS_LD] = reinterpret_cast<float (*)[BN][LDS_LD]>(smem + 2 * BM * LDS_LD);
+  Stager<BM, AMAJ, VEC4, XFA> sa;
+  Stager<BN, BMAJ, VEC4, XFB> sb;
+  const int nk = (int)((kend - kbeg + BK - 1) / BK);
+  if (nk <= 0) return;
+  const int lane = egnn_lane();
+  const int wave = egnn_wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+
+  sa.load(A, lda, m0, M, kbeg, kend, xfa);
+  sb.load(B, ldb, n0, N, kbeg, kend, xfb);
+  sa.store(As[0]);
+  sb.store(Bs[0]);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) {
+      sa.load(A, lda, m0, M, kbeg + (int64_t)(kt + 1) * BK, kend, xfa);
+      sb.load(B, ldb, n0, N, kbeg + (int64_t)(kt + 1) * BK, kend, xfb);
+    }
+    const float* ab = &As[cur][wm * TS::WM + (lane & 31)][(lane >> 5) * 4];
+    const float* bb = &Bs[cur][wn * TS::WN + (lane & 31)][(lane >> 5) * 4];
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      f32x4v a[TS::TM], b[TS::TN];
+#pragma unroll
+      for (int tm = 0; tm < TS::TM; ++tm) a[tm] = *reinterpret_cast<const f32x4v*>(ab + tm * 32 * LDS_LD + kb * 8);
+#pragma unroll
+      for (int tn = 0; tn < TS::TN; ++tn) b[tn] = *reinterpret_cast<const f32x4v*>(bb + tn * 32 * LDS_LD + kb * 8);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int tm = 0; tm < TS::TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TS::TN; ++tn)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][m], b[tn][m], acc[tm][tn], 0, 0, 0);
+    }
+    if (more) {
+      sa.store(As[cur ^ 1]);
+      sb.store(Bs[cur ^ 1]);
+    }
+    __syncthreads();
+  }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+}
+
+}  // namespace egnn_gemm

@@ -1,0 +1,195 @@
+// Row-wise fused losses for gfx950 (HBM/latency-bound; wave64 per row, fixed-order two-stage reductions).
+//   cross entropy + logit KD     /root/reference/arxiv_pyg/criterion.py:8-21 (and the CE first line of
+//                                every criterion)
+//   gather + L2 row normalise    F.normalize after `feat[sampled_inds]`, criterion.py:64-72,136-140
+#include "common.h"
+
+namespace {
+
+constexpr int kRowsPerBlock = 4;     // one wave per row
+constexpr int kMaxBlocks = 1024;     // partial sums per launch (fixed => deterministic finalize)
+
+// log-sum-exp of (x * s) over a row distributed lane-strided; returns lse, every lane gets it
+__device__ __forceinline__ float row_lse(const float* p, int64_t C, float s, int lane) {
+  float m = -INFINITY;
+  for (int64_t c = lane; c < C; c += 64) m = fmaxf(m, p[c] * s);
+  m = egnn_wave_max(m);
+  float z = 0.f;
+  for (int64_t c = lane; c < C; c += 64) z += expf(p[c] * s - m);
+  z = egnn_wave_sum(z);
+  return m + logf(z);
+}
+
+__global__ __launch_bounds__(256) void ce_kd_fwd_kernel(const float* __restrict__ logits, int64_t ldl,
+                                                        const float* __restrict__ teacher, int64_t ldt,
+                                                        const int64_t* __restrict__ labels, int64_t n, int64_t C,
+                                                        float T, float* __restrict__ partials) {
+  __shared__ float s_ce[kRowsPerBlock], s_kd[kRowsPerBlock];
+  const int lane = egnn_lane();
+  const int wave = egnn_wave_id();
+  const float invT = 1.f / T;
+  float ce = 0.f, kd = 0.f;  // lane 0 of each wave carries the wave's running sums
+  for (int64_t row = blockIdx.x * (int64_t)kRowsPerBlock + wave; row < n; row += (int64_t)gridDim.x * kRowsPerBlock) {
+    const float* lp = logits + row * ldl;
+    const float lse1 = row_lse(lp, C, 1.f, lane);
+    const int64_t y = labels[row];
+    if (lane == 0) ce += lse1 - lp[y];
+    if (teacher != nullptr) {
+      const float* tp = teacher + row * ldt;
+      const float lseq = row_lse(lp, C, invT, lane);
+      const float lsep = row_lse(tp, C, invT, lane);
+      float acc = 0.f;
+      for (int64_t c = lane; c < C; c += 64) {
+        const float logp = tp[c] * invT - lsep;
+        const float logq = lp[c] * invT - lseq;
+        const float p = expf(logp);
+        acc += p > 0.f ? p * (logp - logq) : 0.f;  // F.kl_div: 0 where target == 0
+      }
+      acc = egnn_wave_sum(acc);
+      if (lane == 0) kd += acc;
+    }
+  }
+  if (lane == 0) { s_ce[wave] = ce; s_kd[wave] = kd; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < kRowsPerBlock; ++w) { a += s_ce[w]; b += s_kd[w]; }
+    partials[blockIdx.x] = a;
+    partials[kMaxBlocks + blockIdx.x] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_kd_finalize_kernel(const float* __restrict__ partials, int nblocks, int64_t n,
+                                                             int64_t C, int has_teacher, float* __restrict__ out2) {
+  __shared__ float s[2][256];
+  float a = 0.f, b = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) { a += partials[i]; b += partials[kMaxBlocks + i]; }
+  s[0][threadIdx.x] = a; s[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { s[0][threadIdx.x] += s[0][threadIdx.x + o]; s[1][threadIdx.x] += s[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out2[0] = s[0][0] / (float)n;
+    if (has_teacher) out2[1] = s[1][0] / ((float)n * (float)C);
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_kd_bwd_kernel(const float* __restrict__ logits, int64_t ldl,
+                                                        const float* __restrict__ teacher, int64_t ldt,
+                                                        const int64_t* __restrict__ labels, int64_t n, int64_t C, float T,
+                                                        const float* __restrict__ g_cls, const float* __restrict__ g_kd,
+                                                        float* __restrict__ dl, int64_t ldd) {
+  const int lane = egnn_lane();
+  const int wave = egnn_wave_id();
+  const float invT = 1.f / T;
+  const float gc = g_cls ? g_cls[0] / (float)n : 0.f;
+  const float gk = (g_kd && teacher) ? g_kd[0] * invT / ((float)n * (float)C) : 0.f;
+  for (int64_t row = blockIdx.x * (int64_t)kRowsPerBlock + wave; row < n; row += (int64_t)gridDim.x * kRowsPerBlock) {
+    const float* lp = logits + row * ldl;
+    const float lse1 = row_lse(lp, C, 1.f, lane);
+    const int64_t y = labels[row];
+    float lseq = 0.f, lsep = 0.f;
+    const float* tp = nullptr;
+    if (gk != 0.f) {
+      tp = teacher + row * ldt;
+      lseq = row_lse(lp, C, invT, lane);
+      lsep = row_lse(tp, C, invT, lane);
+    }
+    for (int64_t c = lane; c < C; c += 64) {
+      float g = gc * (expf(lp[c] - lse1) - (c == y ? 1.f : 0.f));
+      if (gk != 0.f) g += gk * (expf(lp[c] * invT - lseq) - expf(tp[c] * invT - lsep));
+      dl[row * ldd + c] = g;
+    }
+  }
+}
+
+// ---- gather + L2 normalise ----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_normalize_kernel(const float* __restrict__ x, int64_t ldx,
+                                                               const int64_t* __restrict__ idx, int64_t n, int64_t D,
+                                                               float eps, float* __restrict__ out, int64_t ldo,
+                                                               float* __restrict__ inv_norm) {
+  const int lane = egnn_lane();
+  const int64_t row = blockIdx.x * 4LL + egnn_wave_id();
+  if (row >= n) return;
+  const float* xp = x + (idx ? idx[row] : row) * ldx;
+  float ss = 0.f;
+  for (int64_t d = lane; d < D; d += 64) { const float v = xp[d]; ss = fmaf(v, v, ss); }
+  ss = egnn_wave_sum(ss);
+  const float inv = 1.f / fmaxf(sqrtf(ss), eps);
+  for (int64_t d = lane; d < D; d += 64) out[row * ldo + d] = xp[d] * inv;
+  if (lane == 0 && inv_norm) inv_norm[row] = inv;
+}
+
+__global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* __restrict__ xhat, int64_t ldh,
+                                                            const float* __restrict__ dout, int64_t ldd,
+                                                            const float* __restrict__ inv_norm,
+                                                            const int64_t* __restrict__ idx, int64_t n, int64_t D, float eps,
+                                                            float* __restrict__ dx, int64_t ldx, int accumulate) {
+  const int lane = egnn_lane();
+  const int64_t row = blockIdx.x * 4LL + egnn_wave_id();
+  if (row >= n) return;
+  const float* hp = xhat + row * ldh;
+  const float* gp = dout + row * ldd;
+  const float inv = inv_norm[row];
+  float dot = 0.f;
+  for (int64_t d = lane; d < D; d += 64) dot = fmaf(gp[d], hp[d], dot);
+  dot = egnn_wave_sum(dot);
+  // y = x / max(||x||, eps): when the clamp is active (||x|| < eps) the denominator is constant
+  const bool clamped = inv >= 1.f / eps;
+  if (clamped) dot = 0.f;
+  float* xp = dx + (idx ? idx[row] : row) * ldx;
+  for (int64_t d = lane; d < D; d += 64) {
+    const float g = inv * (gp[d] - hp[d] * dot);
+    xp[d] = accumulate ? xp[d] + g : g;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t egnn_ce_kd_ws_floats(int64_t) { return 2 * (size_t)kMaxBlocks; }
+
+extern "C" int egnn_ce_kd_fwd_f32(const float* logits, int64_t ld_logits, const float* teacher, int64_t ld_teacher,
+                                  const int64_t* labels, int64_t n, int64_t C, float T, float* out2, float* partials,
+                                  void* stream) {
+  EGNN_CHECK_ARG(n > 0 && C > 0 && logits && labels && out2 && partials && ld_logits >= C && T > 0.f);
+  EGNN_CHECK_ARG(teacher == nullptr || ld_teacher >= C);
+  const int64_t want = (n + kRowsPerBlock - 1) / kRowsPerBlock;
+  const int nblocks = (int)(want < kMaxBlocks ? want : kMaxBlocks);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_kd_fwd_kernel, dim3(nblocks), dim3(256), 0, st, logits, ld_logits, teacher, ld_teacher, labels, n, C, T, partials);
+  hipLaunchKernelGGL(ce_kd_finalize_kernel, dim3(1), dim3(256), 0, st, partials, nblocks, n, C, teacher != nullptr, out2);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_ce_kd_bwd_f32(const float* logits, int64_t ld_logits, const float* teacher, int64_t ld_teacher,
+                                  const int64_t* labels, int64_t n, int64_t C, float T, const float* g_cls,
+                                  const float* g_kd, float* dlogits, int64_t ld_dlogits, void* stream) {
+  EGNN_CHECK_ARG(n > 0 && C > 0 && logits && labels && dlogits && ld_logits >= C && ld_dlogits >= C && T > 0.f);
+  const int64_t want = (n + kRowsPerBlock - 1) / kRowsPerBlock;
+  const int nblocks = (int)(want < 4096 ? want : 4096);
+  hipLaunchKernelGGL(ce_kd_bwd_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, logits, ld_logits, teacher, ld_teacher,
+                     labels, n, C, T, g_cls, g_kd, dlogits, ld_dlogits);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_gather_normalize_rows_f32(const float* x, int64_t ldx, const int64_t* idx, int64_t n, int64_t D, float eps,
+                                              float* out, int64_t ldo, float* inv_norm, void* stream) {
+  EGNN_CHECK_ARG(n >= 0 && D > 0 && ldx >= D && ldo >= D);
+  if (n == 0) return EGNN_OK;
+  EGNN_CHECK_ARG(x && out);
+  hipLaunchKernelGGL(gather_normalize_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, idx, n, D, eps, out, ldo, inv_norm);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_normalize_rows_bwd_f32(const float* xhat, int64_t ldh, const float* dout, int64_t ldd, const float* inv_norm,
+                                           const int64_t* idx, int64_t n, int64_t D, float eps, float* dx, int64_t ldx,
+                                           int accumulate, void* stream) {
+  EGNN_CHECK_ARG(n >= 0 && D > 0 && ldh >= D && ldd >= D && ldx >= D);
+  if (n == 0) return EGNN_OK;
+  EGNN_CHECK_ARG(xhat && dout && inv_norm && dx);
+  hipLaunchKernelGGL(normalize_bwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, xhat, ldh, dout, ldd,
+                     inv_norm, idx, n, D, eps, dx, ldx, accumulate);
+  return egnn_launch_status();
+}

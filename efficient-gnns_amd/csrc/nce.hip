@@ -1,0 +1,241 @@
+// G-CRD / InfoNCE loss (/root/reference/arxiv_pyg/criterion.py:139-145) on the f32-input MFMA.
+//
+//   Z = fhat that^T / tau  [S,S] ;  loss = mean_i ( logsumexp_j Z_ij - Z_ii )
+//
+// Forward: one workgroup owns 128 rows and walks a contiguous range of 128-column blocks; every lane
+// keeps an ONLINE (max, sum-exp) pair for each of its 32 accumulator rows, so the soft-max statistics
+// never leave registers until the block is done; lanes / waves / column splits are then merged in a
+// fixed order.  Z is written once (fp32) for the backward: with the fp32 MFMA at 1/16 of the bf16 rate
+// a stored Z (HBM has room for it and the traffic hides under the matrix pipe) is cheaper than the
+// flash-style recompute (3 GEMM passes instead of 4).
+// Backward: dfhat = c (P - I) that, dthat = c (P - I)^T fhat with P = exp(Z - lse): two GEMMs whose A
+// operand is transformed from Z while it is staged into LDS.
+#include "gemm_core.h"
+
+using namespace egnn_gemm;
+
+namespace {
+
+constexpr int kMaxSplit = 8;
+constexpr int FB = 128;  // forward block tile (rows and columns)
+
+__device__ __forceinline__ void lse_merge(float& m, float& s, float om, float os) {
+  const float mn = fmaxf(m, om);
+  if (mn == -INFINITY) return;  // both empty
+  s = s * expf(m - mn) + os * expf(om - mn);  // exp(-inf - finite) == 0
+  m = mn;
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ fhat, const float* __restrict__ that,
+                                                      int64_t S, int64_t P, int64_t ld, float inv_tau,
+                                                      float* __restrict__ Z, float* __restrict__ zdiag,
+                                                      float* __restrict__ pm, float* __restrict__ ps, int nsplit,
+                                                      int cb_per_split) {
+  using TS = TileShape<FB, FB>;
+  __shared__ __attribute__((aligned(16))) float smem[TS::SMEM_FLOATS];
+  const int lane = egnn_lane();
+  const int wave = egnn_wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t i0 = (int64_t)blockIdx.x * FB;
+  const int split = blockIdx.y;
+  const int64_t ncb = (S + FB - 1) / FB;
+  const int64_t cb0 = (int64_t)split * cb_per_split;
+  int64_t cb1 = cb0 + cb_per_split;
+  if (cb1 > ncb) cb1 = ncb;
+
+  float rm[TS::TM][16], rs[TS::TM][16];
+#pragma unroll
+  for (int tm = 0; tm < TS::TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { rm[tm][r] = -INFINITY; rs[tm][r] = 0.f; }
+
+  IdentityXf id;
+  for (int64_t cb = cb0; cb < cb1; ++cb) {
+    const int64_t j0 = cb * FB;
+    f32x16 acc[TS::TM][TS::TN];
+    zero_acc(acc);
+    mainloop<FB, FB, KMAJOR, KMAJOR, VEC4>(acc, fhat, ld, i0, S, that, ld, j0, S, 0, P, id, id, smem);
+#pragma unroll
+    for (int tm = 0; tm < TS::TM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = i0 + acc_row<FB, FB>(wm, tm, r, lane);
+        float zt[TS::TN];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int tn = 0; tn < TS::TN; ++tn) {
+          const int64_t c = j0 + acc_col<FB, FB>(wn, tn, lane);
+          const float z = acc[tm][tn][r] * inv_tau;
+          const bool ok = row < S && c < S;
+          if (ok) {
+            if (Z) Z[row * S + c] = z;
+            if (row == c) zdiag[row] = z;
+          }
+          zt[tn] = ok ? z : -INFINITY;
+          mt = fmaxf(mt, zt[tn]);
+        }
+        if (mt > -INFINITY) {
+          const float mn = fmaxf(rm[tm][r], mt);
+          float s = rs[tm][r] * expf(rm[tm][r] - mn);
+#pragma unroll
+          for (int tn = 0; tn < TS::TN; ++tn) s += expf(zt[tn] - mn);  // exp(-inf) == 0 for masked columns
+          rs[tm][r] = s;
+          rm[tm][r] = mn;
+        }
+      }
+    }
+  }
+
+  // merge the 32 lanes that share a row (same lane >> 5), then the two column-waves through LDS
+  float* lm = smem;            // [2][FB]
+  float* lsum = smem + 2 * FB; // [2][FB]
+#pragma unroll
+  for (int tm = 0; tm < TS::TM; ++tm) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float m = rm[tm][r], s = rs[tm][r];
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        const float om = __shfl_xor(m, o);
+        const float os = __shfl_xor(s, o);
+        lse_merge(m, s, om, os);
+      }
+      if ((lane & 31) == 0) {
+        const int lr = acc_row<FB, FB>(wm, tm, r, lane);
+        lm[wn * FB + lr] = m;
+        lsum[wn * FB + lr] = s;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < FB) {
+    const int64_t row = i0 + threadIdx.x;
+    if (row < S) {
+      float m = lm[threadIdx.x], s = lsum[threadIdx.x];
+      lse_merge(m, s, lm[FB + threadIdx.x], lsum[FB + threadIdx.x]);
+      pm[row * nsplit + split] = m;
+      ps[row * nsplit + split] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void nce_finalize_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
+                                                            const float* __restrict__ zdiag, int64_t S, int nsplit,
+                                                            float* __restrict__ lse, float* __restrict__ loss) {
+  __shared__ float red[1024];
+  float local = 0.f;
+  for (int64_t row = threadIdx.x; row < S; row += 1024) {
+    float m = -INFINITY, s = 0.f;
+    for (int k = 0; k < nsplit; ++k) lse_merge(m, s, pm[row * nsplit + k], ps[row * nsplit + k]);
+    const float l = m + logf(s);
+    lse[row] = l;
+    local += l - zdiag[row];
+  }
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0] / (float)S;
+}
+
+// A-operand transform of the backward GEMMs: z -> exp(z - lse[i]) - [i == j]
+struct NceGradXf {
+  const float* lse;
+  int lse_by_k;  // 0: i = gemm row (A = Z, k-major);  1: i = gemm k (A = Z^T, stored [k][m])
+  __device__ __forceinline__ float operator()(float v, int64_t r, int64_t k) const {
+    const int64_t i = lse_by_k ? k : r;
+    return expf(v - lse[i]) - (r == k ? 1.f : 0.f);
+  }
+};
+
+// C[M=S, N=P] = scale * xf(Z or Z^T) [S,S] * B[S,P]   (B row-major, n contiguous)
+template <int BM, int AMAJ, bool VEC4>
+__global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ Z, int64_t S, const float* __restrict__ lse,
+                                                      const float* __restrict__ Bm, int64_t P, int64_t ldb,
+                                                      float coef, const float* __restrict__ g, float* __restrict__ C,
+                                                      int64_t ldc) {
+  constexpr int BN = 128;
+  using TS = TileShape<BM, BN>;
+  __shared__ __attribute__((aligned(16))) float smem[TS::SMEM_FLOATS];
+  const int64_t tiles_n = (P + BN - 1) / BN;
+  const int64_t m0 = (blockIdx.x / tiles_n) * BM;
+  const int64_t n0 = (blockIdx.x % tiles_n) * BN;
+  f32x16 acc[TS::TM][TS::TN];
+  zero_acc(acc);
+  NceGradXf xf{lse, AMAJ == MNMAJOR};
+  IdentityXf id;
+  mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, S, m0, S, Bm, ldb, n0, P, 0, S, xf, id, smem);
+  const int lane = egnn_lane();
+  const int wave = egnn_wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  const float scale = coef * (g ? g[0] : 1.f);
+#pragma unroll
+  for (int tn = 0; tn < TS::TN; ++tn) {
+    const int64_t c = n0 + acc_col<BM, BN>(wn, tn, lane);
+    if (c >= P) continue;
+#pragma unroll
+    for (int tm = 0; tm < TS::TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + acc_row<BM, BN>(wm, tm, r, lane);
+        if (row < S) C[row * ldc + c] = scale * acc[tm][tn][r];
+      }
+  }
+}
+
+template <int AMAJ>
+void launch_bwd(const float* Z, int64_t S, const float* lse, const float* Bm, int64_t P, int64_t ld, float coef,
+                const float* g, float* C, bool vec4, hipStream_t st) {
+  const int64_t tiles_n = (P + 127) / 128;
+  const int64_t t128 = ((S + 127) / 128) * tiles_n;
+  if (t128 >= 200) {
+    if (vec4) hipLaunchKernelGGL((nce_bwd_kernel<128, AMAJ, true>), dim3((unsigned)t128), dim3(256), 0, st, Z, S, lse, Bm, P, ld, coef, g, C, ld);
+    else hipLaunchKernelGGL((nce_bwd_kernel<128, AMAJ, false>), dim3((unsigned)t128), dim3(256), 0, st, Z, S, lse, Bm, P, ld, coef, g, C, ld);
+  } else {  // fewer than ~one block per CU: halve the row tile
+    const int64_t t64 = ((S + 63) / 64) * tiles_n;
+    if (vec4) hipLaunchKernelGGL((nce_bwd_kernel<64, AMAJ, true>), dim3((unsigned)t64), dim3(256), 0, st, Z, S, lse, Bm, P, ld, coef, g, C, ld);
+    else hipLaunchKernelGGL((nce_bwd_kernel<64, AMAJ, false>), dim3((unsigned)t64), dim3(256), 0, st, Z, S, lse, Bm, P, ld, coef, g, C, ld);
+  }
+}
+
+}  // namespace
+
+extern "C" size_t egnn_nce_ws_floats(int64_t S) { return (size_t)S * (1 + 2 * kMaxSplit); }
+
+extern "C" int egnn_nce_fwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,
+                                float* Z, float* lse, float* loss, float* ws, size_t ws_floats, void* stream) {
+  EGNN_CHECK_ARG(S > 0 && P > 0 && ld >= P && tau > 0.f && fhat && that && lse && loss && ws);
+  if (ws_floats < egnn_nce_ws_floats(S)) return EGNN_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rb = (S + FB - 1) / FB;
+  int nsplit = (int)((512 + rb - 1) / rb);
+  if (nsplit > kMaxSplit) nsplit = kMaxSplit;
+  if (nsplit > rb) nsplit = (int)rb;
+  if (nsplit < 1) nsplit = 1;
+  const int cb_per_split = (int)((rb + nsplit - 1) / nsplit);
+  nsplit = (int)((rb + cb_per_split - 1) / cb_per_split);  // no empty splits
+  float* zdiag = ws;
+  float* pm = ws + S;
+  float* ps = pm + S * kMaxSplit;
+  const bool vec4 = (ld % 4 == 0) && egnn_aligned16(fhat) && egnn_aligned16(that);
+  dim3 grid((unsigned)rb, (unsigned)nsplit);
+  if (vec4) hipLaunchKernelGGL(nce_fwd_kernel<true>, grid, dim3(256), 0, st, fhat, that, S, P, ld, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split);
+  else hipLaunchKernelGGL(nce_fwd_kernel<false>, grid, dim3(256), 0, st, fhat, that, S, P, ld, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split);
+  hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(1024), 0, st, pm, ps, zdiag, S, nsplit, lse, loss);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_nce_bwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,
+                                const float* Z, const float* lse, const float* g, float* dfhat, float* dthat,
+                                void* stream) {
+  EGNN_CHECK_ARG(S > 0 && P > 0 && ld >= P && tau > 0.f && fhat && that && Z && lse);
+  hipStream_t st = (hipStream_t)stream;
+  const float coef = 1.f / ((float)S * tau);
+  const bool vec4 = (ld % 4 == 0) && (S % 4 == 0) && egnn_aligned16(fhat) && egnn_aligned16(that) && egnn_aligned16(Z);
+  if (dfhat) launch_bwd<KMAJOR>(Z, S, lse, that, P, ld, coef, g, dfhat, vec4, st);
+  if (dthat) launch_bwd<MNMAJOR>(Z, S, lse, fhat, P, ld, coef, g, dthat, vec4, st);
+  return egnn_launch_status();
+}

@@ -1,0 +1,365 @@
+// CSR neighbour aggregation for gfx950:  Y[i,:] = REDUCE_e val[e] * src_scale[col[e]] * X[col[e],:]
+//
+// Replaces torch_sparse::spmm (forward and, on the transposed CSR, backward) reached from
+// GCNConv / SAGEConv (/root/reference/arxiv_pyg/gnn.py:47,52,79,84,192) and
+// adj_t.matmul(reduce='mean') (/root/reference/mag_pyg/gnn.py:162).
+//
+// Design (HBM/L2-bound gather; no MFMA):
+//   * the feature dimension is cut into NS column slices of G lanes x VEC floats (128 B for the
+//     K%32==0 cases) and slice s is pinned to XCD (blockIdx % 8): every XCD's private 4 MiB L2 then
+//     caches ONE 128-byte line per source node instead of the whole K*4-byte row, i.e. 8x more
+//     distinct neighbours stay L2-resident (observed dispatch: block b -> XCD b % 8; speed only);
+//   * one wave64 per (row, slice): the wave reads up to 64 (col,val) pairs with ONE coalesced load,
+//     then broadcasts them lane-to-lane (ds_bpermute, no LDS storage) while 64/G neighbours are
+//     gathered per load instruction and 4 such loads are kept in flight;
+//   * rows longer than `long_threshold` are reduced by a whole 1024-thread workgroup whose 16 waves
+//     each own a contiguous chunk and are combined through LDS in a fixed order (bit-stable);
+//   * fp32 accumulation order is fixed (lane-strided, then an xor tree), no atomics.
+#include "common.h"
+
+namespace {
+
+template <typename IdxT>
+struct SpmmArgs {
+  int64_t n_rows, K;
+  const IdxT* rowptr;
+  const IdxT* col;
+  const float* val;
+  const float* src_scale;
+  const float* X;
+  int64_t ldx;
+  float* Y;
+  int64_t ldy;
+  int mean;
+  int64_t* argmax;
+  const int64_t* long_rows;
+  int64_t n_long;
+  int64_t long_threshold;
+  int logG;      // lanes per neighbour = 1 << logG
+  int NS;        // number of column slices
+  int map_mode;  // 0: slice = b % NS ; 1: NS divides 8 ; 2: NS multiple of 8
+};
+
+constexpr int kUnroll = 4;
+
+// Accumulate entries [start, end) of one row into acc (and arg for max).  All 64 lanes take part in
+// the broadcasts; lanes whose column is out of range (colok == false) only skip the loads.
+template <typename IdxT, int VEC, bool IS_MAX>
+__device__ __forceinline__ void accumulate_range(const SpmmArgs<IdxT>& a, int64_t start, int64_t end, int64_t col0,
+                                                 bool colok, int lane, int sub, float (&acc)[VEC],
+                                                 int64_t (&arg)[VEC]) {
+  const int npw = 64 >> a.logG;
+  for (int64_t base = start; base < end; base += 64) {
+    const int64_t rem = end - base;
+    const int n = rem < 64 ? (int)rem : 64;
+    long long c_l = 0;
+    float v_l = 1.f;
+    if (lane < n) {
+      c_l = (long long)a.col[base + lane];
+      if (a.val) v_l = a.val[base + lane];
+      if (a.src_scale) v_l *= a.src_scale[c_l];
+    }
+    for (int j0 = 0; j0 < n; j0 += npw * kUnroll) {
+      float xv[kUnroll][VEC];
+      float vv[kUnroll];
+      bool ok[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        ok[u] = false;
+        vv[u] = 0.f;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) xv[u][q] = 0.f;
+        if (j0 + u * npw < n) {  // wave-uniform
+          const int j = j0 + u * npw + sub;
+          ok[u] = j < n;
+          const int jj = ok[u] ? j : n - 1;  // clamp: same cache line as a live lane, never out of bounds
+          const long long c = __shfl(c_l, jj);
+          vv[u] = __shfl(v_l, jj);
+          if (colok) {
+            const float* xp = a.X + c * a.ldx + col0;
+            if constexpr (VEC == 4) {
+              const float4 t = *reinterpret_cast<const float4*>(xp);
+              xv[u][0] = t.x; xv[u][1] = t.y; xv[u][2] = t.z; xv[u][3] = t.w;
+            } else {
+              xv[u][0] = *xp;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        if (j0 + u * npw < n) {
+          if constexpr (IS_MAX) {
+            const int64_t e = base + j0 + u * npw + sub;
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+              const float cand = vv[u] * xv[u][q];
+              // entries arrive in increasing e per lane, so strict > keeps the first maximal entry
+              const bool take = ok[u] && (arg[q] < 0 || cand > acc[q]);
+              acc[q] = take ? cand : acc[q];
+              arg[q] = take ? e : arg[q];
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) acc[q] = ok[u] ? fmaf(vv[u], xv[u][q], acc[q]) : acc[q];
+          }
+        }
+      }
+    }
+  }
+}
+
+// (value, first-entry) max-merge used by the cross-lane / cross-wave combines
+__device__ __forceinline__ void max_merge(float& v, int64_t& e, float ov, int64_t oe) {
+  const bool take = (oe >= 0) && (e < 0 || ov > v || (ov == v && oe < e));
+  v = take ? ov : v;
+  e = take ? oe : e;
+}
+
+template <int VEC, bool IS_MAX>
+__device__ __forceinline__ void cross_sub_reduce(int logG, float (&acc)[VEC], int64_t (&arg)[VEC]) {
+  for (int off = 1 << logG; off < 64; off <<= 1) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      const float ov = __shfl_xor(acc[q], off);
+      if constexpr (IS_MAX) {
+        const long long oe = __shfl_xor((long long)arg[q], off);
+        max_merge(acc[q], arg[q], ov, (int64_t)oe);
+      } else {
+        acc[q] += ov;
+      }
+    }
+  }
+}
+
+template <typename IdxT, int VEC, bool IS_MAX>
+__device__ __forceinline__ void store_row(const SpmmArgs<IdxT>& a, int64_t row, int64_t col0, float inv,
+                                          const float (&acc)[VEC], const int64_t (&arg)[VEC]) {
+  float* yp = a.Y + row * a.ldy + col0;
+  if constexpr (IS_MAX) {
+    int64_t* ap = a.argmax + row * a.K + col0;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      yp[q] = arg[q] < 0 ? 0.f : acc[q];
+      ap[q] = arg[q];
+    }
+  } else if constexpr (VEC == 4) {
+    *reinterpret_cast<float4*>(yp) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+  } else {
+    yp[0] = acc[0] * inv;
+  }
+}
+
+// ---- wave-per-(row, slice) kernel ---------------------------------------------------------------
+template <typename IdxT, int VEC, bool IS_MAX>
+__global__ __launch_bounds__(256) void spmm_rows_kernel(const SpmmArgs<IdxT> a) {
+  const int lane = egnn_lane();
+  const int wave = egnn_wave_id();
+  const int64_t b = blockIdx.x;
+  int64_t slice, rg;
+  if (a.map_mode == 1) {  // NS in {1,2,4,8}: XCD x = b % 8 owns slice x % NS
+    const int x = (int)(b & 7);
+    const int r = 8 / a.NS;
+    slice = x % a.NS;
+    rg = (b >> 3) * r + x / a.NS;
+  } else if (a.map_mode == 2) {  // NS multiple of 8: XCD x owns slices x, x+8, ...
+    const int x = (int)(b & 7);
+    const int64_t q = b >> 3;
+    const int per = a.NS >> 3;
+    slice = x + 8 * (q % per);
+    rg = q / per;
+  } else {
+    slice = b % a.NS;
+    rg = b / a.NS;
+  }
+  const int64_t row = rg * 4 + wave;
+  if (row >= a.n_rows) return;
+  const int64_t start = (int64_t)a.rowptr[row];
+  const int64_t end = (int64_t)a.rowptr[row + 1];
+  if (a.long_rows != nullptr && end - start > a.long_threshold) return;  // workgroup-per-row kernel
+
+  const int G = 1 << a.logG;
+  const int sub = lane >> a.logG;
+  const int li = lane & (G - 1);
+  const int64_t col0 = (slice * G + li) * VEC;
+  const bool colok = col0 < a.K;
+
+  float acc[VEC];
+  int64_t arg[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) { acc[q] = 0.f; arg[q] = -1; }
+  accumulate_range<IdxT, VEC, IS_MAX>(a, start, end, col0, colok, lane, sub, acc, arg);
+  cross_sub_reduce<VEC, IS_MAX>(a.logG, acc, arg);
+  if (sub == 0 && colok) {
+    const int64_t cnt = end - start;
+    const float inv = a.mean ? 1.f / (float)(cnt > 0 ? cnt : 1) : 1.f;
+    store_row<IdxT, VEC, IS_MAX>(a, row, col0, inv, acc, arg);
+  }
+}
+
+// ---- workgroup-per-(long row, slice) kernel -------------------------------------------------------
+constexpr int kLongWaves = 16;
+
+template <typename IdxT, int VEC, bool IS_MAX>
+__global__ __launch_bounds__(kLongWaves * 64) void spmm_long_rows_kernel(const SpmmArgs<IdxT> a) {
+  __shared__ float s_val[kLongWaves][64 * VEC];
+  __shared__ long long s_arg[IS_MAX ? kLongWaves : 1][IS_MAX ? 64 * VEC : 1];
+  const int lane = egnn_lane();
+  const int wave = egnn_wave_id();
+  const int64_t b = blockIdx.x;
+  const int64_t slice = b % a.NS;
+  const int64_t row = a.long_rows[b / a.NS];
+  const int64_t start = (int64_t)a.rowptr[row];
+  const int64_t end = (int64_t)a.rowptr[row + 1];
+  // contiguous chunk per wave, multiple of 64 entries so index loads stay aligned/coalesced
+  int64_t chunk = (end - start + kLongWaves - 1) / kLongWaves;
+  chunk = (chunk + 63) / 64 * 64;
+  int64_t ws = start + wave * chunk;
+  int64_t we = ws + chunk;
+  if (ws > end) ws = end;
+  if (we > end) we = end;
+
+  const int G = 1 << a.logG;
+  const int sub = lane >> a.logG;
+  const int li = lane & (G - 1);
+  const int64_t col0 = (slice * G + li) * VEC;
+  const bool colok = col0 < a.K;
+
+  float acc[VEC];
+  int64_t arg[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) { acc[q] = 0.f; arg[q] = -1; }
+  accumulate_range<IdxT, VEC, IS_MAX>(a, ws, we, col0, colok, lane, sub, acc, arg);
+  cross_sub_reduce<VEC, IS_MAX>(a.logG, acc, arg);
+  if (sub == 0) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      s_val[wave][li * VEC + q] = acc[q];
+      if constexpr (IS_MAX) s_arg[wave][li * VEC + q] = arg[q];
+    }
+  }
+  __syncthreads();
+  if (wave == 0 && sub == 0 && colok) {
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      float v = s_val[0][li * VEC + q];
+      int64_t e = IS_MAX ? (int64_t)s_arg[0][li * VEC + q] : -1;
+      for (int w = 1; w < kLongWaves; ++w) {  // fixed order
+        if constexpr (IS_MAX) max_merge(v, e, s_val[w][li * VEC + q], (int64_t)s_arg[w][li * VEC + q]);
+        else v += s_val[w][li * VEC + q];
+      }
+      acc[q] = v;
+      arg[q] = e;
+    }
+    const int64_t cnt = end - start;
+    const float inv = a.mean ? 1.f / (float)(cnt > 0 ? cnt : 1) : 1.f;
+    store_row<IdxT, VEC, IS_MAX>(a, row, col0, inv, acc, arg);
+  }
+}
+
+int ilog2_ceil(int64_t v) {
+  int l = 0;
+  while ((1LL << l) < v) ++l;
+  return l;
+}
+
+template <typename IdxT, int VEC, bool IS_MAX>
+int launch(SpmmArgs<IdxT> a, hipStream_t st) {
+  // slice geometry: 128-byte slices (G = 8 float4 lanes) whenever K allows, else one slice per <=64 lanes
+  const int64_t kv = (a.K + VEC - 1) / VEC;  // columns in VEC units
+  if (VEC == 4 && kv % 8 == 0) {
+    a.logG = 3;
+    a.NS = (int)(kv / 8);
+  } else {
+    a.logG = ilog2_ceil(kv < 64 ? kv : 64);
+    a.NS = (int)((kv + (1 << a.logG) - 1) >> a.logG);
+  }
+  int64_t rgroups = (a.n_rows + 3) / 4;
+  int64_t grid;
+  if (a.NS <= 8 && 8 % a.NS == 0) {
+    a.map_mode = 1;
+    const int r = 8 / a.NS;
+    grid = ((rgroups + r - 1) / r) * 8;
+  } else if (a.NS % 8 == 0) {
+    a.map_mode = 2;
+    grid = rgroups * a.NS;
+  } else {
+    a.map_mode = 0;
+    grid = rgroups * a.NS;
+  }
+  if (grid > 0x7fffffffLL) return EGNN_EINVAL;
+  if (a.n_rows > 0) hipLaunchKernelGGL((spmm_rows_kernel<IdxT, VEC, IS_MAX>), dim3((unsigned)grid), dim3(256), 0, st, a);
+  if (a.long_rows != nullptr && a.n_long > 0) {
+    const int64_t g2 = a.n_long * a.NS;
+    if (g2 > 0x7fffffffLL) return EGNN_EINVAL;
+    hipLaunchKernelGGL((spmm_long_rows_kernel<IdxT, VEC, IS_MAX>), dim3((unsigned)g2), dim3(kLongWaves * 64), 0, st, a);
+  }
+  return egnn_launch_status();
+}
+
+template <typename IdxT>
+int dispatch(SpmmArgs<IdxT> a, int reduce, hipStream_t st) {
+  const bool vec4 = (a.K % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) && egnn_aligned16(a.X) && egnn_aligned16(a.Y);
+  if (reduce == EGNN_MAX) return vec4 ? launch<IdxT, 4, true>(a, st) : launch<IdxT, 1, true>(a, st);
+  return vec4 ? launch<IdxT, 4, false>(a, st) : launch<IdxT, 1, false>(a, st);
+}
+
+template <typename IdxT>
+__global__ void spmm_max_bwd_kernel(int64_t total, int64_t K, const IdxT* col, const float* val, const int64_t* argmax,
+                                    const float* dY, int64_t ldy, float* dX, int64_t ldx) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / K, k = t % K;
+    const int64_t e = argmax[t];
+    if (e < 0) continue;
+    float g = dY[i * ldy + k];
+    if (val) g *= val[e];
+    atomicAdd(dX + (int64_t)col[e] * ldx + k, g);
+  }
+}
+
+}  // namespace
+
+extern "C" int egnn_spmm_csr_f32(int64_t n_rows, int64_t n_src, int64_t K, const void* rowptr, const void* col,
+                                 int index_bits, const float* val, const float* src_scale, const float* X, int64_t ldx,
+                                 float* Y, int64_t ldy, int reduce, int64_t* argmax, const int64_t* long_rows,
+                                 int64_t n_long, int64_t long_threshold, void* stream) {
+  EGNN_CHECK_ARG(n_rows >= 0 && n_src >= 0 && K >= 0 && ldx >= K && ldy >= K);
+  EGNN_CHECK_ARG(index_bits == 32 || index_bits == 64);
+  EGNN_CHECK_ARG(reduce == EGNN_SUM || reduce == EGNN_MEAN || reduce == EGNN_MAX);
+  if (n_rows == 0 || K == 0) return EGNN_OK;
+  EGNN_CHECK_ARG(rowptr && col && X && Y);
+  EGNN_CHECK_ARG(reduce != EGNN_MAX || argmax != nullptr);
+  EGNN_CHECK_ARG(n_long >= 0 && (n_long == 0 || long_rows != nullptr));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (index_bits == 32) {
+    SpmmArgs<int32_t> a{n_rows, K, (const int32_t*)rowptr, (const int32_t*)col, val, src_scale, X, ldx, Y, ldy,
+                        reduce == EGNN_MEAN, argmax, n_long > 0 ? long_rows : nullptr, n_long, long_threshold, 0, 0, 0};
+    return dispatch(a, reduce, st);
+  }
+  SpmmArgs<int64_t> a{n_rows, K, (const int64_t*)rowptr, (const int64_t*)col, val, src_scale, X, ldx, Y, ldy,
+                      reduce == EGNN_MEAN, argmax, n_long > 0 ? long_rows : nullptr, n_long, long_threshold, 0, 0, 0};
+  return dispatch(a, reduce, st);
+}
+
+extern "C" int egnn_spmm_csr_max_bwd_f32(int64_t n_rows, int64_t K, const void* col, int index_bits, const float* val,
+                                         const int64_t* argmax, const float* dY, int64_t ldy, float* dX, int64_t ldx,
+                                         void* stream) {
+  EGNN_CHECK_ARG(n_rows >= 0 && K >= 0 && (index_bits == 32 || index_bits == 64));
+  if (n_rows == 0 || K == 0) return EGNN_OK;
+  EGNN_CHECK_ARG(col && argmax && dY && dX);
+  const int64_t total = n_rows * K;
+  const int64_t blocks = (total + 255) / 256;
+  const unsigned grid = (unsigned)(blocks < 8192 ? blocks : 8192);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (index_bits == 32)
+    hipLaunchKernelGGL(spmm_max_bwd_kernel<int32_t>, dim3(grid), dim3(256), 0, st, total, K, (const int32_t*)col, val, argmax, dY, ldy, dX, ldx);
+  else
+    hipLaunchKernelGGL(spmm_max_bwd_kernel<int64_t>, dim3(grid), dim3(256), 0, st, total, K, (const int64_t*)col, val, argmax, dY, ldy, dX, ldx);
+  return egnn_launch_status();
+}
+
+extern "C" int64_t egnn_spmm_algorithmic_bytes(int64_t n_rows, int64_t n_src, int64_t K, int64_t nnz, int index_bits,
+                                               int has_val) {
+  const int64_t ib = index_bits / 8;
+  return 4 * n_src * K + 4 * n_rows * K + nnz * (ib + (has_val ? 4 : 0)) + (n_rows + 1) * ib;
+}

@@ -1,0 +1,121 @@
+"""Seeded synthetic datasets with the shapes of the reference's datasets (none is on disk and there is no
+network).  Integer / host-side generation only -- tensors are moved to the GPU by the caller.
+
+  * ``arxiv_like``  ogbn-arxiv: N=169 343, 1 166 243 directed power-law edges (no self loops, no
+                    multi-edges), x [N,128], 40 classes, split 90 941 / 29 799 / 48 603, GAT-teacher
+                    artefacts [N,750] (non-negative, post-ReLU) and [N,40]
+                    (/root/reference/arxiv_pyg/gnn.py:236-279)
+  * ``ppi_like``    PPI: 20+2+2 graphs, x [n,50], 121 labels (/root/reference/ppi_pyg/gnn.py:301-310)
+  * ``mag_like``    ogbn-mag grouped homogeneous graph (/root/reference/mag_pyg/gnn.py:322-346)
+"""
+from __future__ import annotations
+
+import types
+
+import numpy as np
+import torch
+
+ARXIV = dict(num_nodes=169_343, num_edges=1_166_243, num_features=128, num_classes=40,
+             split=(90_941, 29_799, 48_603), teacher_dim=750, max_degree=13_000)
+
+
+def powerlaw_edges(n: int, e: int, gamma: float = 2.2, max_degree: int | None = None, seed: int = 0) -> np.ndarray:
+    """Directed edge list [2, e] (source, target): power-law in-degree (Chung-Lu weights w_i ~ (i+i0)^-1/(gamma-1)),
+    near-uniform out-degree, no self loops, no duplicate edges, node ids randomly permuted."""
+    rng = np.random.default_rng(seed)
+    alpha = 1.0 / (gamma - 1.0)
+    ranks = np.arange(n, dtype=np.float64)
+
+    def probs(i0):
+        w = (ranks + i0) ** (-alpha)
+        return w / w.sum()
+
+    i0 = 1.0
+    if max_degree is not None:  # bisect the offset so that the expected hub in-degree ~ max_degree
+        lo, hi = 1e-3, 1e4
+        for _ in range(60):
+            mid = (lo * hi) ** 0.5
+            if probs(mid)[0] * e > max_degree:
+                lo = mid
+            else:
+                hi = mid
+        i0 = hi
+    p = probs(i0)
+    perm = rng.permutation(n)
+    keys = np.empty(0, dtype=np.int64)
+    need = e
+    while need > 0:
+        m = int(need * 1.1) + 16
+        dst = perm[rng.choice(n, size=m, p=p)]
+        src = rng.integers(0, n, size=m)
+        ok = src != dst
+        k = src[ok].astype(np.int64) * n + dst[ok]
+        keys = np.unique(np.concatenate([keys, k]))
+        need = e - keys.size
+    if keys.size > e:
+        keys = np.sort(rng.choice(keys, size=e, replace=False))
+    return np.stack([keys // n, keys % n])
+
+
+def arxiv_like(scale: float = 1.0, seed: int = 0, with_teacher: bool = True):
+    """Synthetic ogbn-arxiv-shaped node-classification problem (CPU tensors).  ``scale`` < 1 shrinks N and E
+    proportionally (test sizes); scale=1 is the BASELINE.json workload."""
+    from .transforms import to_sparse_tensor
+    n = max(64, int(round(ARXIV["num_nodes"] * scale)))
+    e = max(128, int(round(ARXIV["num_edges"] * scale)))
+    md = max(8, int(ARXIV["max_degree"] * min(1.0, scale * 4)))
+    ei = torch.from_numpy(powerlaw_edges(n, e, max_degree=md, seed=seed))
+    g = torch.Generator().manual_seed(seed)
+    d = types.SimpleNamespace()
+    d.num_nodes, d.num_features, d.num_classes = n, ARXIV["num_features"], ARXIV["num_classes"]
+    d.edge_index = ei
+    d.x = torch.randn(n, d.num_features, generator=g)
+    d.y = torch.randint(0, d.num_classes, (n, 1), generator=g)
+    tr, va, te = ARXIV["split"]
+    n_tr = int(round(n * tr / ARXIV["num_nodes"]))
+    n_va = int(round(n * va / ARXIV["num_nodes"]))
+    perm = torch.randperm(n, generator=g)
+    d.split_idx = {"train": perm[:n_tr].clone(), "valid": perm[n_tr:n_tr + n_va].clone(), "test": perm[n_tr + n_va:].clone()}
+    d.adj_t = to_sparse_tensor(ei, n).to_symmetric()  # gnn.py:237-240
+    d.edge_index = None
+    if with_teacher:
+        d.teacher_out_feat = torch.relu(torch.randn(n, ARXIV["teacher_dim"], generator=g))
+        d.teacher_logits = torch.randn(n, d.num_classes, generator=g) * 3.0
+    return d
+
+
+def ppi_like(seed: int = 0, n_train: int = 20, total_train_nodes: int = 44_906, feats: int = 50, labels: int = 121):
+    """List of per-graph namespaces (x, y, edge_index symmetric LongTensor[2,E], teacher_logits)."""
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(600, 3500, size=n_train).astype(np.float64)
+    sizes = np.maximum(64, np.round(sizes * total_train_nodes / sizes.sum())).astype(np.int64)
+    sizes = list(sizes) + [3257, 3257, 2762, 2762]  # 2 validation (6 514) + 2 test (5 524) graphs
+    graphs = []
+    for gi, n in enumerate(sizes):
+        n = int(n)
+        e = int(n * 13.5)
+        ei = powerlaw_edges(n, e, gamma=2.6, max_degree=max(8, n // 8), seed=seed * 1000 + gi)
+        both = np.unique(np.concatenate([ei[0] * n + ei[1], ei[1] * n + ei[0]]))
+        g = torch.Generator().manual_seed(seed * 1000 + gi)
+        d = types.SimpleNamespace()
+        d.edge_index = torch.from_numpy(np.stack([both // n, both % n]))
+        d.x = torch.randn(n, feats, generator=g)
+        d.y = (torch.rand(n, labels, generator=g) < 0.3).float()
+        d.teacher_logits = torch.randn(n, labels, generator=g) * 2.0
+        d.num_nodes = n
+        graphs.append(d)
+    return graphs[:n_train], graphs[n_train:n_train + 2], graphs[n_train + 2:]
+
+
+def mag_like(scale: float = 1.0, seed: int = 0, feats: int = 128):
+    """Homogeneous MAG-shaped graph: N=1 939 743, 42 182 144 directed edges after reverse edges."""
+    from .transforms import to_sparse_tensor
+    n = max(256, int(round(1_939_743 * scale)))
+    e = max(512, int(round(21_091_072 * scale)))
+    ei = torch.from_numpy(powerlaw_edges(n, e, gamma=2.3, max_degree=max(16, int(30_000 * min(1.0, scale * 4))), seed=seed))
+    g = torch.Generator().manual_seed(seed)
+    d = types.SimpleNamespace()
+    d.num_nodes, d.num_features, d.num_classes = n, feats, 349
+    d.x = torch.randn(n, feats, generator=g)
+    d.adj_t = to_sparse_tensor(ei, n).to_symmetric()
+    return d

@@ -1,0 +1,128 @@
+"""Student models and the train / eval step, mirroring the reference's L1/L2 code on the new operators.
+
+``GCN`` / ``SAGE`` / ``ProjectionGCD`` follow /root/reference/arxiv_pyg/gnn.py:23-99 (same constructor
+signatures, ``convs`` / ``bns`` state_dict keys, ``.out_feat`` side channel); ``train_step`` follows
+``train()`` (:102-195) and the KD+aux rule of gnn_kd_and_aux.py:114-181; ``evaluate`` follows ``test()``
+(:198-218).  The reference's own ``gnn.py`` also runs unchanged on top of ``efficient-gnns_amd/dropin``.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import criterion as C
+from .nn import GCNConv, SAGEConv
+
+
+class _Student(nn.Module):
+    def __init__(self, make_conv, in_channels, hidden_channels, out_channels, num_layers, dropout):
+        super().__init__()
+        dims = [in_channels] + [hidden_channels] * (num_layers - 1) + [out_channels]
+        self.convs = nn.ModuleList(make_conv(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.bns = nn.ModuleList(nn.BatchNorm1d(hidden_channels) for _ in range(num_layers - 1))
+        self.dropout = dropout
+        self.out_feat = None
+
+    def reset_parameters(self):
+        for m in list(self.convs) + list(self.bns):
+            m.reset_parameters()
+
+    def forward(self, x, adj_t):
+        for conv, bn in zip(self.convs[:-1], self.bns):
+            x = F.dropout(F.relu(bn(conv(x, adj_t))), p=self.dropout, training=self.training)
+            self.out_feat = x
+        return self.convs[-1](x, adj_t)
+
+
+class GCN(_Student):
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout, cached=True):
+        super().__init__(lambda a, b: GCNConv(a, b, cached=cached), in_channels, hidden_channels, out_channels,
+                         num_layers, dropout)
+
+
+class SAGE(_Student):
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout, aggr="mean"):
+        super().__init__(lambda a, b: SAGEConv(a, b, aggr=aggr), in_channels, hidden_channels, out_channels,
+                         num_layers, dropout)
+
+
+class ProjectionGCD(nn.Module):
+    def __init__(self, hidden_channels, proj_dim):
+        super().__init__()
+        self.lin = nn.Linear(hidden_channels, proj_dim)
+        self.conv = GCNConv(hidden_channels, proj_dim)
+        self.bn = nn.BatchNorm1d(proj_dim)
+
+    def forward(self, x, adj_t):
+        return F.relu(self.bn(self.lin(x) + self.conv(x, adj_t)))
+
+
+def make_projection(in_dim, proj_dim):
+    return nn.Sequential(nn.Linear(in_dim, proj_dim), nn.BatchNorm1d(proj_dim), nn.ReLU())
+
+
+def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_logits, hp,
+                 student_proj=None, teacher_proj=None, edge_index=None, adj_t=None, kd_and_aux=False):
+    if mode == "supervised":
+        from . import ops
+        loss = ops.cross_entropy(out, labels)
+        return loss, loss, loss * 0
+    if mode == "kd":
+        return C.kd_criterion(out, labels, teacher_logits[train_idx], hp["alpha"], hp["kd_T"])
+    if mode in ("fitnet", "gpw", "nce"):
+        f = student_proj(model.out_feat[train_idx])
+        t = teacher_proj(teacher_out_feat[train_idx])
+    elif mode in ("at", "lpw"):
+        f, t = model.out_feat[train_idx], teacher_out_feat[train_idx]
+    elif mode == "gcd":
+        f = student_proj(model.out_feat, adj_t)[train_idx]
+        t = teacher_proj(teacher_out_feat, adj_t)[train_idx]
+    else:
+        raise NotImplementedError(mode)
+    if mode == "fitnet":
+        res = C.fitnet_criterion(out, labels, f, t, hp["beta"])
+    elif mode == "at":
+        res = C.at_criterion(out, labels, f, t, hp["beta"])
+    elif mode == "gpw":
+        res = C.gpw_criterion(out, labels, f, t, hp["kernel"], hp["beta"], hp["max_samples"])
+    elif mode == "lpw":
+        res = C.lpw_criterion(out, labels, f, t, edge_index, hp["kernel"], hp["beta"])
+    else:
+        res = C.nce_criterion(out, labels, f, t, hp["beta"], hp["nce_T"], hp["max_samples"])
+    if not kd_and_aux:
+        return res
+    loss_aux = res[2]
+    loss, loss_cls, _ = C.kd_criterion(out, labels, teacher_logits[train_idx], hp["alpha"], hp["kd_T"])
+    return loss + hp["beta"] * loss_aux, loss_cls, loss_aux
+
+
+def train_step(model, x, adj_t, y, train_idx, optimizer, mode, hp, teacher_out_feat=None, teacher_logits=None,
+               student_proj=None, teacher_proj=None, edge_index=None, kd_and_aux=False):
+    """One full-graph optimisation step (= one training epoch of the reference)."""
+    model.train()
+    for p in (student_proj, teacher_proj):
+        if p is not None:
+            p.train()
+    out = model(x, adj_t)[train_idx]
+    labels = y.squeeze(1)[train_idx]
+    loss, loss_cls, loss_aux = distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_logits, hp,
+                                            student_proj, teacher_proj, edge_index, adj_t, kd_and_aux)
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss.item(), loss_cls.item(), loss_aux.item()
+
+
+def accuracy(y_true, y_pred) -> float:
+    """``ogb`` Evaluator('ogbn-arxiv')['acc'] = mean(y_true == y_pred); compared on the device, one scalar read."""
+    return float((y_true == y_pred).float().mean())
+
+
+@torch.no_grad()
+def evaluate(model, x, adj_t, y, split_idx):
+    model.eval()
+    out = model(x, adj_t)
+    y_pred = out.argmax(dim=-1, keepdim=True)
+    accs = tuple(accuracy(y[split_idx[k]], y_pred[split_idx[k]]) for k in ("train", "valid", "test"))
+    return out, accs

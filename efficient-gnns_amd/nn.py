@@ -1,0 +1,102 @@
+"""``torch_geometric.nn.{GCNConv, SAGEConv}`` stand-ins on the gfx950 kernels.
+
+Same constructor / forward signatures, parameter names and layouts as PyG <=1.7, which is what the
+reference's ``state_dict`` files hold (/root/reference/arxiv_pyg/gnn.py:13,28-35,61-67,92;
+/root/reference/ppi_pyg/gnn.py:125-132,158-164).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import Tensor, nn
+
+from . import ops
+from .sparse import SparseTensor, _ind2ptr, gcn_norm
+
+
+def _adj_from_edge_index(edge_index: Tensor, n: int, value: Tensor | None = None) -> SparseTensor:
+    """edge_index = (source, target) -> CSR with rows = targets, stable in edge order (PPI path)."""
+    src, dst = edge_index[0], edge_index[1]
+    perm = torch.argsort(dst, stable=True)
+    return SparseTensor(rowptr=_ind2ptr(dst[perm].contiguous(), n), col=src[perm],
+                        value=None if value is None else value[perm], sparse_sizes=(n, n))
+
+
+def _gcn_norm_edge_index(edge_index: Tensor, n: int) -> SparseTensor:
+    """PyG <=1.7 ``gcn_norm`` on an edge_index (ppi_pyg/gnn.py:125-132): add_remaining_self_loops, then
+    D^-1/2 A D^-1/2 with in-degrees by target.  Every loop carries weight 1, so the result equals the
+    SparseTensor branch applied to the target-major CSR with duplicates kept."""
+    src, dst = edge_index[0], edge_index[1]
+    keep = src != dst
+    loops = torch.arange(n, dtype=torch.int64, device=edge_index.device)
+    src2, dst2 = torch.cat([src[keep], loops]), torch.cat([dst[keep], loops])
+    w = torch.ones(src2.numel(), dtype=torch.float32, device=edge_index.device)
+    deg = torch.zeros(n, dtype=torch.float32, device=edge_index.device).index_add_(0, dst2, w)
+    dinv = deg.pow(-0.5)
+    dinv.masked_fill_(dinv == float("inf"), 0.0)
+    val = dinv[src2] * w * dinv[dst2]
+    return _adj_from_edge_index(torch.stack([src2, dst2]), n, val)
+
+
+class GCNConv(nn.Module):
+    """out = A^ (x W) + b;  W [in,out] glorot, b zeros;  ``cached=True`` keeps A^ until reset_parameters()."""
+
+    def __init__(self, in_channels: int, out_channels: int, cached: bool = False, bias: bool = True, **_):
+        super().__init__()
+        self.in_channels, self.out_channels, self.cached = in_channels, out_channels, cached
+        self.weight = nn.Parameter(torch.empty(in_channels, out_channels))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        self._cached_adj_t = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        a = math.sqrt(6.0 / (self.in_channels + self.out_channels))
+        with torch.no_grad():
+            self.weight.uniform_(-a, a)
+            if self.bias is not None:
+                self.bias.zero_()
+        self._cached_adj_t = None
+
+    def forward(self, x: Tensor, edge_index) -> Tensor:
+        norm = self._cached_adj_t
+        if norm is None:
+            if isinstance(edge_index, SparseTensor):
+                norm = gcn_norm(edge_index)
+            else:
+                norm = _gcn_norm_edge_index(edge_index, x.shape[0])
+            if self.cached:
+                self._cached_adj_t = norm
+        out = ops.spmm(norm, ops.matmul(x, self.weight), "sum")
+        if self.bias is not None:
+            out = out + self.bias
+        return out
+
+    def __repr__(self):
+        return f"GCNConv({self.in_channels}, {self.out_channels})"
+
+
+class SAGEConv(nn.Module):
+    """out = lin_l(aggr_{j in N(i)} x_j) + lin_r(x_i); ``aggr`` in {mean (reference), sum, max}."""
+
+    def __init__(self, in_channels: int, out_channels: int, aggr: str = "mean", **_):
+        super().__init__()
+        if aggr == "add":
+            aggr = "sum"
+        if aggr not in ("mean", "sum", "max"):
+            raise ValueError(f"unsupported aggregation '{aggr}'")
+        self.in_channels, self.out_channels, self.aggr = in_channels, out_channels, aggr
+        self.lin_l = nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_r = nn.Linear(in_channels, out_channels, bias=False)
+
+    def reset_parameters(self):
+        self.lin_l.reset_parameters()
+        self.lin_r.reset_parameters()
+
+    def forward(self, x: Tensor, edge_index) -> Tensor:
+        adj = edge_index if isinstance(edge_index, SparseTensor) else _adj_from_edge_index(edge_index, x.shape[0])
+        agg = ops.spmm(adj.set_value(None), x, self.aggr)
+        return ops.linear(agg, self.lin_l.weight, self.lin_l.bias) + ops.linear(x, self.lin_r.weight, None)
+
+    def __repr__(self):
+        return f"SAGEConv({self.in_channels}, {self.out_channels}, aggr={self.aggr})"

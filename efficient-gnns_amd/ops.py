@@ -1,0 +1,281 @@
+"""autograd.Function wrappers around the C ABI (include/egnn_hip.h).  GPU only; no CPU fallback."""
+from __future__ import annotations
+
+import os
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+_REDUCE = {"sum": 0, "add": 0, "mean": 1, "max": 2}
+
+
+def _rowmajor(x: Tensor) -> Tensor:
+    """fp32, unit inner stride (the kernels take an explicit leading dimension)."""
+    if x.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {x.dtype}")
+    if x.dim() != 2:
+        raise ValueError("expected a 2-D tensor")
+    if x.stride(1) != 1 or x.stride(0) < x.shape[1]:
+        x = x.contiguous()
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# SpMM
+# ------------------------------------------------------------------------------------------------
+def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = None, use_long_rows: bool = True):
+    """Y = REDUCE(adj, X) on the GPU (egnn_spmm_csr_f32).  Returns (Y, argmax | None)."""
+    _lib.require_gpu(x, adj._col)
+    x = _rowmajor(x)
+    n_rows, n_src = adj.sparse_sizes()
+    if x.shape[0] != n_src:
+        raise ValueError(f"matmul: adjacency has {n_src} columns, x has {x.shape[0]} rows")
+    K = x.shape[1]
+    red = _REDUCE[reduce]
+    y = torch.empty(n_rows, K, dtype=torch.float32, device=x.device)
+    arg = torch.empty(n_rows, K, dtype=torch.int64, device=x.device) if red == 2 else None
+    rowptr, col, bits = adj._index_arrays()
+    long_rows = adj._long_rows() if use_long_rows else None
+    n_long = 0 if long_rows is None else long_rows.numel()
+    from .sparse import LONG_ROW_THRESHOLD
+    rc = _lib.load().egnn_spmm_csr_f32(
+        n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), bits, _lib.ptr(adj._value), _lib.ptr(src_scale),
+        _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), red, _lib.ptr(arg),
+        _lib.ptr(long_rows) if n_long else None, n_long, LONG_ROW_THRESHOLD, _lib.stream())
+    _lib.check(rc, "egnn_spmm_csr_f32")
+    return y, arg
+
+
+class _SpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, adj, reduce):
+        y, arg = spmm_raw(adj, x, reduce)
+        ctx.adj, ctx.reduce = adj, reduce
+        if arg is not None:
+            ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        adj, reduce = ctx.adj, ctx.reduce
+        gy = _rowmajor(gy)
+        if reduce in ("sum", "add"):
+            gx, _ = spmm_raw(adj.t(), gy, "sum")
+        elif reduce == "mean":
+            # dX = A^T (dY / cnt): per-source-row scale of the transposed aggregation
+            gx, _ = spmm_raw(adj.t(), gy, "sum", src_scale=adj._inv_rowcount())
+        else:
+            (arg,) = ctx.saved_tensors
+            n_rows, n_src = adj.sparse_sizes()
+            K = gy.shape[1]
+            gx = torch.zeros(n_src, K, dtype=torch.float32, device=gy.device)
+            _, col, bits = adj._index_arrays()
+            rc = _lib.load().egnn_spmm_csr_max_bwd_f32(n_rows, K, _lib.ptr(col), bits, _lib.ptr(adj._value), _lib.ptr(arg),
+                                                       _lib.ptr(gy), gy.stride(0), _lib.ptr(gx), gx.stride(0), _lib.stream())
+            _lib.check(rc, "egnn_spmm_csr_max_bwd_f32")
+        return gx, None, None
+
+
+def spmm(adj, x: Tensor, reduce: str = "sum") -> Tensor:
+    if reduce not in _REDUCE:
+        raise ValueError(f"unknown reduce '{reduce}'")
+    return _SpMM.apply(x, adj, reduce)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense GEMM (fp32 MFMA)
+# ------------------------------------------------------------------------------------------------
+def gemm_backend() -> str:
+    """'hip' = hand-written fp32-MFMA kernel (default); 'blas' = torch.matmul (rocBLAS/hipBLASLt)."""
+    return os.environ.get("EGNN_GEMM", "hip")
+
+
+def gemm_raw(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False, bias: Tensor | None = None,
+             alpha: float = 1.0, split_k: int | None = None) -> Tensor:
+    """C = alpha * op(a) @ op(b) (+ bias) via egnn_gemm_f32."""
+    _lib.require_gpu(a, b)
+    a, b = _rowmajor(a), _rowmajor(b)
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    Kb, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    if K != Kb:
+        raise ValueError(f"gemm: inner dimensions differ ({K} vs {Kb})")
+    c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if split_k is None:
+        # reductions over many rows into a small output (dW = X^T dY): spread K over the chip
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        split_k = 1 if tiles >= 128 or K < 4096 else max(1, min(64, 512 // max(tiles, 1), K // 1024))
+    ws = None
+    if split_k > 1:
+        ws = torch.empty(split_k * M * N, dtype=torch.float32, device=a.device)
+    rc = _lib.load().egnn_gemm_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.ptr(a), a.stride(0), _lib.ptr(b),
+                                   b.stride(0), _lib.ptr(bias), _lib.ptr(c), c.stride(0), split_k, _lib.ptr(ws),
+                                   0 if ws is None else ws.numel() * 4, _lib.stream())
+    _lib.check(rc, "egnn_gemm_f32")
+    return c
+
+
+class _MatMul(torch.autograd.Function):
+    """y = x @ w (+ bias); w stored [K,N] (``transposed=False``, GCNConv) or [N,K] (nn.Linear layout)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, transposed):
+        ctx.save_for_backward(x, w)
+        ctx.transposed, ctx.has_bias = transposed, bias is not None
+        return gemm_raw(x, w, False, transposed, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _rowmajor(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_raw(gy, w, False, not ctx.transposed)           # dX = dY W^T  (or dY W)
+        if ctx.needs_input_grad[1]:
+            gw = gemm_raw(gy, x, True, False) if ctx.transposed else gemm_raw(x, gy, True, False)  # dW = dY^T X | X^T dY
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb, None
+
+
+def matmul(x: Tensor, w: Tensor) -> Tensor:
+    """x [M,K] @ w [K,N]."""
+    if gemm_backend() == "blas":
+        return x @ w
+    return _MatMul.apply(x, w, None, False)
+
+
+def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None) -> Tensor:
+    """x @ weight^T + bias with ``weight`` in nn.Linear layout [out, in]."""
+    if gemm_backend() == "blas":
+        return torch.nn.functional.linear(x, weight, bias)
+    return _MatMul.apply(x, weight, bias, True)
+
+
+# ------------------------------------------------------------------------------------------------
+# cross entropy (+ logit KD)
+# ------------------------------------------------------------------------------------------------
+class _CeKd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, teacher, T):
+        _lib.require_gpu(logits, labels, teacher)
+        logits = _rowmajor(logits)
+        teacher = None if teacher is None else _rowmajor(teacher)
+        labels = labels.contiguous()
+        n, C = logits.shape
+        lib = _lib.load()
+        out = torch.zeros(2, dtype=torch.float32, device=logits.device)
+        ws = torch.empty(lib.egnn_ce_kd_ws_floats(n), dtype=torch.float32, device=logits.device)
+        rc = lib.egnn_ce_kd_fwd_f32(_lib.ptr(logits), logits.stride(0), _lib.ptr(teacher), 0 if teacher is None else teacher.stride(0),
+                                    _lib.ptr(labels), n, C, float(T), _lib.ptr(out), _lib.ptr(ws), _lib.stream())
+        _lib.check(rc, "egnn_ce_kd_fwd_f32")
+        ctx.save_for_backward(logits, labels, *([] if teacher is None else [teacher]))
+        ctx.T = float(T)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_kd):
+        saved = ctx.saved_tensors
+        logits, labels = saved[0], saved[1]
+        teacher = saved[2] if len(saved) > 2 else None
+        n, C = logits.shape
+        dl = torch.empty_like(logits)
+        g_cls = None if g_cls is None else g_cls.contiguous().to(torch.float32)
+        g_kd = None if g_kd is None else g_kd.contiguous().to(torch.float32)
+        rc = _lib.load().egnn_ce_kd_bwd_f32(_lib.ptr(logits), logits.stride(0), _lib.ptr(teacher),
+                                            0 if teacher is None else teacher.stride(0), _lib.ptr(labels), n, C, ctx.T,
+                                            _lib.ptr(g_cls), _lib.ptr(g_kd), _lib.ptr(dl), dl.stride(0), _lib.stream())
+        _lib.check(rc, "egnn_ce_kd_bwd_f32")
+        return dl, None, None, None
+
+
+def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
+    """mean CE (F.cross_entropy) on the fused kernel."""
+    return _CeKd.apply(logits, labels, None, 1.0)[0]
+
+
+def ce_and_kd(logits: Tensor, labels: Tensor, teacher_logits: Tensor, T: float):
+    """(mean CE, F.kl_div(log_softmax(logits/T), softmax(teacher/T)) with reduction='mean')."""
+    return _CeKd.apply(logits, labels, teacher_logits, T)
+
+
+# ------------------------------------------------------------------------------------------------
+# gather + L2 normalise
+# ------------------------------------------------------------------------------------------------
+class _GatherNormalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, eps):
+        _lib.require_gpu(x, idx)
+        x = _rowmajor(x)
+        n = x.shape[0] if idx is None else idx.numel()
+        D = x.shape[1]
+        out = torch.empty(n, D, dtype=torch.float32, device=x.device)
+        inv = torch.empty(n, dtype=torch.float32, device=x.device)
+        rc = _lib.load().egnn_gather_normalize_rows_f32(_lib.ptr(x), x.stride(0), _lib.ptr(idx), n, D, float(eps), _lib.ptr(out),
+                                                        out.stride(0), _lib.ptr(inv), _lib.stream())
+        _lib.check(rc, "egnn_gather_normalize_rows_f32")
+        ctx.save_for_backward(out, inv, *([] if idx is None else [idx]))
+        ctx.eps, ctx.n_in = float(eps), x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        saved = ctx.saved_tensors
+        out, inv = saved[0], saved[1]
+        idx = saved[2] if len(saved) > 2 else None
+        gout = _rowmajor(gout)
+        n, D = out.shape
+        dx = torch.zeros(ctx.n_in, D, dtype=torch.float32, device=out.device) if idx is not None else torch.empty_like(out)
+        rc = _lib.load().egnn_normalize_rows_bwd_f32(_lib.ptr(out), out.stride(0), _lib.ptr(gout), gout.stride(0), _lib.ptr(inv),
+                                                     _lib.ptr(idx), n, D, ctx.eps, _lib.ptr(dx), dx.stride(0), 0, _lib.stream())
+        _lib.check(rc, "egnn_normalize_rows_bwd_f32")
+        return dx, None, None
+
+
+def gather_normalize(x: Tensor, idx: Tensor | None = None, eps: float = 1e-12) -> Tensor:
+    """F.normalize(x[idx], p=2, dim=-1) fused (rows of ``idx`` must be unique, as np.random.choice(replace=False) gives)."""
+    return _GatherNormalize.apply(x, idx, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# G-CRD / InfoNCE on unit rows
+# ------------------------------------------------------------------------------------------------
+class _NCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fhat, that, tau):
+        _lib.require_gpu(fhat, that)
+        fhat, that = fhat.contiguous(), that.contiguous()
+        S, P = fhat.shape
+        if that.shape != fhat.shape:
+            raise ValueError("nce: student and teacher features must have the same shape")
+        lib = _lib.load()
+        dev = fhat.device
+        Z = torch.empty(S, S, dtype=torch.float32, device=dev)
+        lse = torch.empty(S, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        nws = lib.egnn_nce_ws_floats(S)
+        ws = torch.empty(nws, dtype=torch.float32, device=dev)
+        rc = lib.egnn_nce_fwd_f32(_lib.ptr(fhat), _lib.ptr(that), S, P, fhat.stride(0), float(tau), _lib.ptr(Z), _lib.ptr(lse),
+                                  _lib.ptr(loss), _lib.ptr(ws), nws, _lib.stream())
+        _lib.check(rc, "egnn_nce_fwd_f32")
+        ctx.save_for_backward(fhat, that, Z, lse)
+        ctx.tau = float(tau)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        fhat, that, Z, lse = ctx.saved_tensors
+        S, P = fhat.shape
+        g = g.contiguous().to(torch.float32)
+        df = torch.empty_like(fhat) if ctx.needs_input_grad[0] else None
+        dt = torch.empty_like(that) if ctx.needs_input_grad[1] else None
+        rc = _lib.load().egnn_nce_bwd_f32(_lib.ptr(fhat), _lib.ptr(that), S, P, fhat.stride(0), ctx.tau, _lib.ptr(Z), _lib.ptr(lse),
+                                          _lib.ptr(g), _lib.ptr(df), _lib.ptr(dt), _lib.stream())
+        _lib.check(rc, "egnn_nce_bwd_f32")
+        return df, dt, None
+
+
+def nce_unit(fhat: Tensor, that: Tensor, tau: float) -> Tensor:
+    """mean_i(logsumexp_j(fhat_i . that_j / tau) - fhat_i . that_i / tau) for unit-norm rows."""
+    return _NCE.apply(fhat, that, tau)

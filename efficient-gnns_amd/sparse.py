@@ -1,0 +1,252 @@
+"""``torch_sparse.SparseTensor`` stand-in backed by the gfx950 kernels.
+
+Mirrors the subset of the torch-sparse interface the reference calls
+(/root/reference/arxiv_pyg/gnn.py:240-241,248; /root/reference/mag_pyg/gnn.py:13,151,162):
+``SparseTensor(row=, col=, value=, sparse_sizes=)``, ``.to_symmetric()``, ``.to(device)``, ``.coo()``,
+``.matmul(x, reduce=)``, ``.storage.rowptr()/col()/value()``, ``.set_value()``, ``.sparse_sizes()``, ``.t()``.
+
+Data layout in HBM: CSR, rows sorted, columns ascending within a row; the exported index arrays are
+int64 (torch-sparse convention, bit-exact vs the oracle).  For the kernels an int32 copy of
+``rowptr``/``col`` is cached when nnz and N fit (halves index traffic), together with the transposed
+CSR (the ``csr2csc`` route of the backward pass) and the list of "long" rows the SpMM hands to whole
+workgroups.  Structure building (sort / unique) is one-off integer preprocessing done with torch ops
+on whatever device the indices live on; ``matmul`` and ``gcn_norm`` require the GPU.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import _lib
+
+LONG_ROW_THRESHOLD = 512  # entries; rows above it are reduced by a 16-wave workgroup
+
+
+def _ind2ptr(row: Tensor, n_rows: int) -> Tensor:
+    rowptr = torch.empty(n_rows + 1, dtype=torch.int64, device=row.device)
+    if row.is_cuda:
+        row = row.contiguous()
+        _lib.check(_lib.load().egnn_rowptr_from_sorted_rows_i64(_lib.ptr(row), row.numel(), n_rows, _lib.ptr(rowptr),
+                                                                _lib.stream()), "egnn_rowptr_from_sorted_rows_i64")
+        return rowptr
+    rowptr[0] = 0
+    torch.cumsum(torch.bincount(row, minlength=n_rows), 0, out=rowptr[1:])
+    return rowptr
+
+
+def _ptr2ind(rowptr: Tensor, nnz: int) -> Tensor:
+    n = rowptr.numel() - 1
+    return torch.repeat_interleave(torch.arange(n, dtype=torch.int64, device=rowptr.device),
+                                   rowptr[1:] - rowptr[:-1], output_size=nnz)
+
+
+class _Storage:
+    def __init__(self, owner: "SparseTensor"):
+        self._o = owner
+
+    def rowptr(self):
+        return self._o._rowptr
+
+    def row(self):
+        return self._o._row()
+
+    def col(self):
+        return self._o._col
+
+    def value(self):
+        return self._o._value
+
+    def csr2csc(self):
+        return self._o._transpose_meta()[1]
+
+    def colptr(self):
+        return self._o._transpose_meta()[0]
+
+    def rowcount(self):
+        return self._o._rowptr[1:] - self._o._rowptr[:-1]
+
+
+class SparseTensor:
+    def __init__(self, row: Tensor | None = None, rowptr: Tensor | None = None, col: Tensor | None = None,
+                 value: Tensor | None = None, sparse_sizes=None, is_sorted: bool = False):
+        if col is None or (row is None and rowptr is None):
+            raise ValueError("SparseTensor needs col and one of row / rowptr")
+        if sparse_sizes is None or sparse_sizes[0] is None or sparse_sizes[1] is None:
+            m = (int(row.max()) + 1 if row.numel() else 0) if row is not None else rowptr.numel() - 1
+            n = int(col.max()) + 1 if col.numel() else 0
+            sparse_sizes = (m, n)
+        self._sizes = (int(sparse_sizes[0]), int(sparse_sizes[1]))
+        if row is not None and not is_sorted:
+            perm = torch.argsort(row * self._sizes[1] + col, stable=True)
+            row, col = row[perm], col[perm]
+            value = None if value is None else value[perm]
+        self._rowptr = rowptr if rowptr is not None else _ind2ptr(row, self._sizes[0])
+        self._row_cache = row
+        self._col = col.contiguous()
+        self._value = None if value is None else value.contiguous()
+        self._struct = {}  # caches that depend on structure only (shared by set_value copies)
+        self.storage = _Storage(self)
+
+    # ---- accessors ---------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self._col.device
+
+    def _row(self) -> Tensor:
+        if self._row_cache is None:
+            self._row_cache = _ptr2ind(self._rowptr, self._col.numel())
+        return self._row_cache
+
+    def sparse_sizes(self):
+        return self._sizes
+
+    def sparse_size(self, dim: int) -> int:
+        return self._sizes[dim]
+
+    def size(self, dim: int) -> int:
+        return self._sizes[dim]
+
+    def sizes(self):
+        return list(self._sizes)
+
+    def nnz(self) -> int:
+        return self._col.numel()
+
+    def has_value(self) -> bool:
+        return self._value is not None
+
+    def coo(self):
+        return self._row(), self._col, self._value
+
+    def csr(self):
+        return self._rowptr, self._col, self._value
+
+    def set_value(self, value, layout=None) -> "SparseTensor":
+        out = SparseTensor(rowptr=self._rowptr, col=self._col, value=value, sparse_sizes=self._sizes)
+        out._row_cache = self._row_cache
+        out._struct = self._struct
+        return out
+
+    def fill_value(self, fill: float, dtype=torch.float32) -> "SparseTensor":
+        return self.set_value(torch.full((self.nnz(),), fill, dtype=dtype, device=self.device))
+
+    def to(self, device, *_, **__) -> "SparseTensor":
+        device = torch.device(device)
+        if device == self.device:
+            return self
+        out = SparseTensor(rowptr=self._rowptr.to(device), col=self._col.to(device),
+                           value=None if self._value is None else self._value.to(device), sparse_sizes=self._sizes)
+        return out
+
+    def cuda(self):
+        return self.to("cuda")
+
+    def is_cuda(self) -> bool:
+        return self._col.is_cuda
+
+    # ---- structure ---------------------------------------------------------------------------
+    def to_symmetric(self) -> "SparseTensor":
+        """Union of (r,c) and (c,r), sorted, deduplicated (torch-sparse ``to_symmetric``, value-less)."""
+        if self._value is not None:
+            raise NotImplementedError("to_symmetric with values is not used by the reference")
+        n = max(self._sizes)
+        row, col = self._row(), self._col
+        key = torch.unique(torch.cat([row * n + col, col * n + row]))
+        return SparseTensor(row=torch.div(key, n, rounding_mode="floor"), col=key % n, sparse_sizes=(n, n), is_sorted=True)
+
+    def _transpose_meta(self):
+        """(colptr, csr2csc): stable sort of the entries by column (rows stay ascending per column)."""
+        if "tmeta" not in self._struct:
+            perm = torch.argsort(self._col, stable=True)
+            colptr = _ind2ptr(self._col[perm], self._sizes[1])
+            self._struct["tmeta"] = (colptr, perm)
+        return self._struct["tmeta"]
+
+    def t(self) -> "SparseTensor":
+        """Transposed CSR (= the CSC view torch-sparse caches as ``csr2csc``); cached."""
+        if self._value is None and "t_obj" in self._struct:
+            return self._struct["t_obj"]
+        if getattr(self, "_t_obj", None) is not None:
+            return self._t_obj
+        colptr, perm = self._transpose_meta()
+        if "t_col" not in self._struct:
+            self._struct["t_col"] = self._row()[perm].contiguous()
+        out = SparseTensor(rowptr=colptr, col=self._struct["t_col"],
+                           value=None if self._value is None else self._value[perm],
+                           sparse_sizes=(self._sizes[1], self._sizes[0]))
+        out._struct = self._struct.setdefault("t_struct", {})
+        if self._value is None:
+            self._struct["t_obj"] = out
+        else:
+            self._t_obj = out
+        return out
+
+    # ---- kernel-side views ----------------------------------------------------------------------
+    def _index_arrays(self):
+        """(rowptr, col, bits): int32 narrowing when every index fits, else the int64 originals."""
+        if "idx" not in self._struct:
+            fits = self.nnz() < 2 ** 31 and max(self._sizes) < 2 ** 31
+            if fits and self._col.is_cuda:
+                lib = _lib.load()
+                rp32 = torch.empty(self._rowptr.numel(), dtype=torch.int32, device=self.device)
+                c32 = torch.empty(self.nnz(), dtype=torch.int32, device=self.device)
+                _lib.check(lib.egnn_narrow_i64_to_i32(_lib.ptr(self._rowptr), self._rowptr.numel(), _lib.ptr(rp32), None,
+                                                      _lib.stream()), "egnn_narrow_i64_to_i32")
+                _lib.check(lib.egnn_narrow_i64_to_i32(_lib.ptr(self._col), self.nnz(), _lib.ptr(c32), None,
+                                                      _lib.stream()), "egnn_narrow_i64_to_i32")
+                self._struct["idx"] = (rp32, c32, 32)
+            else:
+                self._struct["idx"] = (self._rowptr, self._col, 64)
+        return self._struct["idx"]
+
+    def _long_rows(self):
+        if "long" not in self._struct:
+            cnt = self._rowptr[1:] - self._rowptr[:-1]
+            self._struct["long"] = torch.nonzero(cnt > LONG_ROW_THRESHOLD).view(-1).contiguous()
+        return self._struct["long"]
+
+    def _inv_rowcount(self) -> Tensor:
+        if "invcnt" not in self._struct:
+            cnt = (self._rowptr[1:] - self._rowptr[:-1]).clamp(min=1)
+            self._struct["invcnt"] = (1.0 / cnt.to(torch.float32)).contiguous()
+        return self._struct["invcnt"]
+
+    # ---- matmul --------------------------------------------------------------------------------
+    def matmul(self, x: Tensor, reduce: str = "sum") -> Tensor:
+        from .ops import spmm
+        return spmm(self, x, reduce)
+
+    def __matmul__(self, x: Tensor) -> Tensor:
+        return self.matmul(x, "sum")
+
+    def spmm_algorithmic_bytes(self, K: int) -> int:
+        _, _, bits = self._index_arrays()
+        return int(_lib.load().egnn_spmm_algorithmic_bytes(self._sizes[0], self._sizes[1], K, self.nnz(), bits,
+                                                           int(self._value is not None)))
+
+
+def gcn_norm(adj_t: SparseTensor) -> SparseTensor:
+    """A^ = D^-1/2 (A + I) D^-1/2 with ``fill_diag(1)`` (PyG ``gcn_norm``, SparseTensor branch) on the GPU."""
+    if adj_t.has_value():
+        raise NotImplementedError("gcn_norm on a valued adjacency is not used by the reference")
+    rowptr, col, _ = adj_t.csr()
+    _lib.require_gpu(rowptr, col)
+    n = adj_t.sparse_size(0)
+    if adj_t.sparse_size(1) != n:
+        raise ValueError("gcn_norm needs a square adjacency")
+    lib, st = _lib.load(), _lib.stream()
+    dev = col.device
+    counts = torch.empty(n, dtype=torch.int64, device=dev)
+    _lib.check(lib.egnn_gcn_norm_count_i64(_lib.ptr(rowptr), _lib.ptr(col), n, _lib.ptr(counts), st), "egnn_gcn_norm_count_i64")
+    rowptr_out = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=rowptr_out[1:])
+    nnz_out = adj_t.nnz() + n  # upper bound; exact count below (one host read, once per run)
+    nnz_out = int(rowptr_out[-1])
+    col_out = torch.empty(nnz_out, dtype=torch.int64, device=dev)
+    dinv = torch.empty(n, dtype=torch.float32, device=dev)
+    val = torch.empty(nnz_out, dtype=torch.float32, device=dev)
+    _lib.check(lib.egnn_gcn_norm_fill_i64(_lib.ptr(rowptr), _lib.ptr(col), n, _lib.ptr(rowptr_out), _lib.ptr(col_out),
+                                          _lib.ptr(dinv), st), "egnn_gcn_norm_fill_i64")
+    _lib.check(lib.egnn_gcn_norm_values_i64(_lib.ptr(rowptr_out), _lib.ptr(col_out), n, _lib.ptr(dinv), _lib.ptr(val), st),
+               "egnn_gcn_norm_values_i64")
+    return SparseTensor(rowptr=rowptr_out, col=col_out, value=val, sparse_sizes=(n, n))

@@ -1,0 +1,23 @@
+"""``torch_geometric.transforms.ToSparseTensor`` stand-in (/root/reference/arxiv_pyg/gnn.py:237)."""
+from __future__ import annotations
+
+import torch
+
+from .sparse import SparseTensor
+
+
+def to_sparse_tensor(edge_index: torch.Tensor, num_nodes: int) -> SparseTensor:
+    """(source, target) edge list -> ``adj_t``: row i lists the sources j of edges j->i, ascending; no dedupe."""
+    src, dst = edge_index[0], edge_index[1]
+    perm = torch.argsort(dst * num_nodes + src, stable=True)
+    return SparseTensor(row=dst[perm], col=src[perm], value=None, sparse_sizes=(num_nodes, num_nodes), is_sorted=True)
+
+
+class ToSparseTensor:
+    def __call__(self, data):
+        n = getattr(data, "num_nodes", None)
+        if n is None:
+            n = data.x.shape[0]
+        data.adj_t = to_sparse_tensor(data.edge_index, int(n))
+        data.edge_index = None
+        return data

@@ -1,0 +1,175 @@
+/*
+ * egnn_hip.h -- C ABI of libegnn_hip.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * GNN-distillation hot path of chaitjo/efficient-gnns.
+ *
+ * The reference has no FFI of its own: its hot path calls the PyG / torch-sparse / torch-scatter
+ * Python operator API, whose native kernels live in un-vendored wheels.  Each entry
+ * point below therefore cites the reference call site whose third-party kernel it replaces.  The
+ * Python host side (efficient-gnns_amd/) binds these with ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator); no entry
+ *     point allocates, frees, synchronises or keeps global state: all are re-entrant;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *   - dense matrices are row-major fp32 with an explicit leading dimension in ELEMENTS;
+ *   - sparse structure is CSR; index arrays are int32 or int64, selected by `index_bits` (32|64).
+ *     The exported structure is always int64 (torch-sparse convention); int32 is an internal
+ *     narrowing the host performs when nnz and N fit;
+ *   - return value: 0 on success, a negative EGNN_E* code otherwise (nothing enqueued on error,
+ *     except EGNN_ELAUNCH which reports hipGetLastError() after a launch).
+ */
+#ifndef EGNN_HIP_H
+#define EGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGNN_OK 0
+#define EGNN_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported enum) */
+#define EGNN_ELAUNCH (-2)  /* the HIP runtime reported a launch error */
+#define EGNN_EWORKSPACE (-3) /* caller-provided workspace too small */
+#define EGNN_EALIGN (-4)   /* pointer / leading dimension not aligned as the entry point requires */
+
+#define EGNN_ABI_VERSION 1
+int egnn_abi_version(void);
+const char* egnn_error_string(int code);
+/* Number of distinct kernels-families compiled in; used by the loader's self check. */
+int egnn_build_info(char* buf, size_t buf_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Neighbour aggregation: Y[i,:] = REDUCE_{e in row i} val[e] * src_scale[col[e]] * X[col[e],:]
+ *
+ * Replaces torch_sparse::spmm (K1/K2 in SURVEY.md 2.2), reached from
+ *   GCNConv.forward      /root/reference/arxiv_pyg/gnn.py:47,52   (reduce=sum, val = gcn_norm)
+ *   SAGEConv.forward     /root/reference/arxiv_pyg/gnn.py:79,84   (reduce=mean, val = NULL)
+ *   adj_t.matmul(mean)   /root/reference/mag_pyg/gnn.py:162
+ *   loss.backward()      /root/reference/arxiv_pyg/gnn.py:192     (same kernel on the transposed CSR)
+ *
+ * reduce: EGNN_SUM, EGNN_MEAN (sum / max(stored entries of the row, 1)), EGNN_MAX (argmax = index of
+ * the FIRST maximal stored entry in CSR order, -1 and 0.0 for an empty row).
+ * val        [nnz]    nullable (= 1.0)
+ * src_scale  [n_src]  nullable; per-source-row factor, used for the backward of mean
+ *                     (dX = A^T (dY / cnt)) without materialising a per-entry value array
+ * argmax     [n_rows, K] int64, required for EGNN_MAX, ignored otherwise
+ * long_rows  [n_long] int64 ids of rows with more than `long_threshold` entries (nullable: then every
+ *                     row is handled by the wave-per-row kernel).  Rows listed here are reduced by a
+ *                     whole workgroup with a fixed-order LDS combine, so results are run-to-run
+ *                     bit-stable for every degree distribution.
+ * ---------------------------------------------------------------------------------------------- */
+#define EGNN_SUM 0
+#define EGNN_MEAN 1
+#define EGNN_MAX 2
+
+int egnn_spmm_csr_f32(int64_t n_rows, int64_t n_src, int64_t K,
+                      const void* rowptr, const void* col, int index_bits,
+                      const float* val, const float* src_scale,
+                      const float* X, int64_t ldx, float* Y, int64_t ldy,
+                      int reduce, int64_t* argmax,
+                      const int64_t* long_rows, int64_t n_long, int64_t long_threshold,
+                      void* stream);
+
+/* Backward of EGNN_MAX: dX[col[argmax[i,k]], k] += val * dY[i,k].  dX must be zero-filled by the
+ * caller.  Uses float atomics (the only entry point that does); max-aggregation is never exercised
+ * by the reference and is provided because north_star names it. */
+int egnn_spmm_csr_max_bwd_f32(int64_t n_rows, int64_t K, const void* col, int index_bits, const float* val,
+                              const int64_t* argmax, const float* dY, int64_t ldy, float* dX, int64_t ldx,
+                              void* stream);
+
+/* Algorithmic (compulsory) HBM bytes of one egnn_spmm_csr_f32 call, SURVEY.md 8(d):
+ * 4*n_src*K (read X) + 4*n_rows*K (write Y) + nnz*(index bytes + value bytes) + rowptr. */
+int64_t egnn_spmm_algorithmic_bytes(int64_t n_rows, int64_t n_src, int64_t K, int64_t nnz, int index_bits,
+                                    int has_val);
+
+/* ------------------------------------------------------------------------------------------------
+ * Graph structure (integer work is bit-exact vs torch-sparse semantics)
+ * ---------------------------------------------------------------------------------------------- */
+/* rowptr[i] = #entries with row < i, for i in [0, n_rows]; `row` sorted ascending.
+ * Replaces torch_sparse ind2ptr inside T.ToSparseTensor()  /root/reference/arxiv_pyg/gnn.py:237. */
+int egnn_rowptr_from_sorted_rows_i64(const int64_t* row, int64_t nnz, int64_t n_rows, int64_t* rowptr, void* stream);
+
+/* int64 -> int32 narrowing of an index array; *overflow (device int32, caller-zeroed) is set to 1
+ * if any element does not fit. */
+int egnn_narrow_i64_to_i32(const int64_t* src, int64_t n, int32_t* dst, int32_t* overflow, void* stream);
+
+/* gcn_norm on a value-less, row-sorted CSR (GCNConv first forward, /root/reference/arxiv_pyg/gnn.py:28-35;
+ * SURVEY 9.3): A^ = D^-1/2 (A + I) D^-1/2 with fill_diag(1) replacing any stored diagonal.
+ *  step 1: out_count[i] = #off-diagonal entries of row i + 1                 (caller scans -> rowptr_out)
+ *  step 2: writes col_out (diagonal inserted at its sorted slot) and dinv[i] = deg^-1/2 (inf -> 0)
+ *  step 3: val_out[e] = (1 * dinv[row(e)]) * dinv[col_out[e]]
+ */
+int egnn_gcn_norm_count_i64(const int64_t* rowptr, const int64_t* col, int64_t n, int64_t* out_count, void* stream);
+int egnn_gcn_norm_fill_i64(const int64_t* rowptr, const int64_t* col, int64_t n, const int64_t* rowptr_out,
+                           int64_t* col_out, float* dinv, void* stream);
+int egnn_gcn_norm_values_i64(const int64_t* rowptr_out, const int64_t* col_out, int64_t n, const float* dinv,
+                             float* val_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense fp32 GEMM on the f32-input MFMA (v_mfma_f32_32x32x2_f32, exact fp32 == fmaf chain).
+ * C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] (+ bias[N]) ; op = identity or transpose.
+ *   trans_a = 0: A is [M,K] row-major (lda >= K);  trans_a = 1: A is stored [K,M] (lda >= M)
+ *   trans_b = 0: B is [K,N] row-major (ldb >= N);  trans_b = 1: B is stored [N,K] (ldb >= K)
+ * Replaces cuBLAS SGEMM under torch.matmul / nn.Linear (K4): GCNConv `x @ W`
+ * (/root/reference/arxiv_pyg/gnn.py:47), SAGEConv lin_l/lin_r (:79), projection heads (:296-306) and
+ * their backward (dX = dY W^T, dW = X^T dY).
+ * split_k > 1 writes split_k partial products into `ws` ([split_k, M, N] floats) and reduces them in
+ * a fixed order (deterministic); ws may be NULL when split_k <= 1.
+ * ---------------------------------------------------------------------------------------------- */
+int egnn_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha,
+                  const float* A, int64_t lda, const float* B, int64_t ldb,
+                  const float* bias, float* C, int64_t ldc,
+                  int split_k, float* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused losses (K5-K7).  Every loss entry point comes as fwd (scalars out) + bwd (input grads out);
+ * upstream gradients are passed as DEVICE scalars so that no host sync is needed.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Row-wise cross entropy + logit-KD, /root/reference/arxiv_pyg/criterion.py:8-21 (and the
+ * `loss_cls = F.cross_entropy(logits, labels)` first line of every criterion, :26,41,60,98,132).
+ *   out[0] = mean_i CE(logits_i, labels_i)
+ *   out[1] = sum_{i,c} p_t (log p_t - log q) / (n*C)   (F.kl_div default reduction='mean'), q = softmax(logits/T),
+ *            p_t = softmax(teacher/T); written only when teacher != NULL
+ * partials: workspace of egnn_ce_kd_ws_floats(n) floats. */
+size_t egnn_ce_kd_ws_floats(int64_t n);
+int egnn_ce_kd_fwd_f32(const float* logits, int64_t ld_logits, const float* teacher, int64_t ld_teacher,
+                       const int64_t* labels, int64_t n, int64_t C, float T,
+                       float* out2, float* partials, void* stream);
+/* dlogits[i,c] = g_cls * (softmax(logits_i)_c - [c == label_i]) / n  +  g_kd * (q_ic - p_t,ic) / (T * n * C)
+ * g_cls / g_kd: device scalars (nullable = 0). */
+int egnn_ce_kd_bwd_f32(const float* logits, int64_t ld_logits, const float* teacher, int64_t ld_teacher,
+                       const int64_t* labels, int64_t n, int64_t C, float T,
+                       const float* g_cls, const float* g_kd, float* dlogits, int64_t ld_dlogits, void* stream);
+
+/* Gather + L2 row normalisation:  out[i,:] = x[idx[i],:] / max(||x[idx[i],:]||_2, eps), inv_norm[i] = 1/max(..).
+ * idx nullable (identity).  F.normalize in criterion.py:29-30,71-72,139-140 fused with the
+ * `feat[sampled_inds]` gather (:64-65,136-137). */
+int egnn_gather_normalize_rows_f32(const float* x, int64_t ldx, const int64_t* idx, int64_t n, int64_t D, float eps,
+                                   float* out, int64_t ldo, float* inv_norm, void* stream);
+/* Backward of the above: dx[idx[i],:] (+)= inv_norm[i] * (dout[i,:] - xhat[i,:] * <dout[i,:], xhat[i,:]>)
+ * (zero where the eps clamp was active).  `accumulate` != 0 adds into dx (rows of idx are unique). */
+int egnn_normalize_rows_bwd_f32(const float* xhat, int64_t ldh, const float* dout, int64_t ldd, const float* inv_norm,
+                                const int64_t* idx, int64_t n, int64_t D, float eps,
+                                float* dx, int64_t ldx, int accumulate, void* stream);
+
+/* G-CRD / InfoNCE, /root/reference/arxiv_pyg/criterion.py:139-145:
+ *   Z = fhat that^T / tau  ([S,S]);  loss = mean_i( logsumexp_j Z_ij - Z_ii ).
+ * fwd: Z tiles are produced on the fp32 MFMA, the row log-sum-exp is accumulated online per lane and
+ *      merged in a fixed order; Z is written to `Z` ([S,S], ld = S) for the backward when Z != NULL.
+ *      lse [S] and the scalar loss are outputs.  ws: egnn_nce_ws_floats(S) floats.
+ * bwd: dfhat = g/(S tau) (P - I) that ; dthat = g/(S tau) (P - I)^T fhat, P = exp(Z - lse); g device scalar.
+ *      Requires the Z written by fwd. */
+size_t egnn_nce_ws_floats(int64_t S);
+int egnn_nce_fwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,
+                     float* Z, float* lse, float* loss, float* ws, size_t ws_floats, void* stream);
+int egnn_nce_bwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,
+                     const float* Z, const float* lse, const float* g,
+                     float* dfhat, float* dthat, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGNN_HIP_H */

@@ -1,0 +1,453 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the C ABI via the
+product package, against the CPU oracle and the golden vectors.
+
+Bars: integer / index results bit-exact; fp32 layer outputs rtol 1e-5 with
+atol = 1e-5 * max|ref|; scalar losses rtol 1e-5 (NCE 2e-5); gradients rtol 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+import efficient_gnns_amd as E
+import efficient_gnns_amd.data as D
+import efficient_gnns_amd.criterion as PC
+import efficient_gnns_amd.models as PM
+import efficient_gnns_amd.ops as ops
+import oracle.criterion as OC
+import oracle.models as OM
+import oracle.nn as ON
+import oracle.sparse as OS
+import oracle.utils as OU
+from conftest import as_t
+from test_oracle_golden import criterion_cases, run_training, noise_driven
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def close(actual, ref, rtol=1e-5, atol_scale=1e-5, msg=""):
+    a = actual.detach().cpu().double().numpy() if torch.is_tensor(actual) else np.asarray(actual, dtype=np.float64)
+    r = ref.detach().cpu().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, dtype=np.float64)
+    atol = atol_scale * (np.abs(r).max() if r.size else 0.0) + 1e-30
+    np.testing.assert_allclose(a, r, rtol=rtol, atol=atol, err_msg=msg)
+
+
+def random_csr(n_rows, n_cols, avg_deg, seed, hubs=(), empty_frac=0.1, dup=False):
+    """COO (row, col) with empty rows, optional hub rows (very long) and optional duplicate entries."""
+    g = torch.Generator().manual_seed(seed)
+    e = int(n_rows * avg_deg)
+    row = torch.randint(0, n_rows, (e,), generator=g)
+    col = torch.randint(0, n_cols, (e,), generator=g)
+    for h, deg in hubs:
+        row = torch.cat([row, torch.full((deg,), h)])
+        col = torch.cat([col, torch.randint(0, n_cols, (deg,), generator=g)])
+    keep = torch.rand(n_rows, generator=g) >= empty_frac
+    for h, _ in hubs:
+        keep[h] = True
+    m = keep[row]
+    row, col = row[m], col[m]
+    if not dup:
+        key = torch.unique(row * n_cols + col)
+        row, col = key // n_cols, key % n_cols
+    return row, col
+
+
+def make_pair(row, col, val, sizes):
+    o = OS.SparseTensor(row=row, col=col, value=val, sparse_sizes=sizes)
+    p = E.SparseTensor(row=row.to(DEV), col=col.to(DEV), value=None if val is None else val.to(DEV), sparse_sizes=sizes)
+    return o, p
+
+
+# ------------------------------------------------------------------------------------------------
+# structure (bit-exact)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,e,seed", [(1, 0, 0), (9, 0, 1), (40, 300, 2), (3000, 40000, 3)])
+def test_structure_on_device_bit_exact(n, e, seed):
+    g = torch.Generator().manual_seed(seed)
+    ei = torch.stack([torch.randint(0, n, (e,), generator=g), torch.randint(0, n, (e,), generator=g)])
+    o = OS.to_sparse_tensor(ei, n)
+    p = E.to_sparse_tensor(ei.to(DEV), n)
+    for a, b in zip(p.csr()[:2], o.csr()[:2]):
+        assert torch.equal(a.cpu(), b)
+    so, sp = o.to_symmetric(), p.to_symmetric()
+    for a, b in zip(sp.csr()[:2], so.csr()[:2]):
+        assert torch.equal(a.cpu(), b)
+    assert torch.equal(sp.storage.colptr().cpu(), so._colptr())
+    assert torch.equal(sp.storage.csr2csc().cpu(), so._csr2csc())
+    # host-built tensor moved to the GPU gives the same arrays
+    moved = E.to_sparse_tensor(ei, n).to_symmetric().to(DEV)
+    assert torch.equal(moved.csr()[1], sp.csr()[1]) and torch.equal(moved.csr()[0], sp.csr()[0])
+    # gcn_norm: structure bit-exact (diagonal inserted in sorted position), values fp32-close
+    go, gp = OS.gcn_norm_sparse(so), E.gcn_norm(sp)
+    assert torch.equal(gp.csr()[0].cpu(), go.csr()[0]) and torch.equal(gp.csr()[1].cpu(), go.csr()[1])
+    close(gp.csr()[2], go.csr()[2], rtol=2e-6, atol_scale=0)
+    # int32 narrowing round-trips
+    rp32, c32, bits = sp._index_arrays()
+    assert bits == 32 and torch.equal(rp32.long(), sp.csr()[0]) and torch.equal(c32.long(), sp.csr()[1])
+
+
+def test_gcn_norm_replaces_existing_diagonal_and_duplicates():
+    row = torch.tensor([0, 0, 0, 1, 1, 2, 2, 2, 3])
+    col = torch.tensor([0, 0, 2, 0, 1, 1, 2, 3, 0])  # duplicate diagonal in row 0
+    o, p = make_pair(row, col, None, (4, 4))
+    go, gp = OS.gcn_norm_sparse(o), E.gcn_norm(p)
+    assert torch.equal(gp.csr()[0].cpu(), go.csr()[0]) and torch.equal(gp.csr()[1].cpu(), go.csr()[1])
+    close(gp.csr()[2], go.csr()[2], rtol=2e-6, atol_scale=0)
+
+
+def test_subgraph_and_edge_index_norm_on_device():
+    n = 500
+    g = torch.Generator().manual_seed(0)
+    ei = torch.stack([torch.randint(0, n, (4000,), generator=g), torch.randint(0, n, (4000,), generator=g)])
+    subset = torch.randperm(n, generator=g)[:200]
+    a = E.subgraph(subset.to(DEV), ei.to(DEV), relabel_nodes=True, num_nodes=n)[0]
+    b = OU.subgraph(subset, ei, relabel_nodes=True, num_nodes=n)[0]
+    assert torch.equal(a.cpu(), b)
+
+
+# ------------------------------------------------------------------------------------------------
+# SpMM
+# ------------------------------------------------------------------------------------------------
+SPMM_K = [1, 3, 4, 40, 50, 64, 121, 128, 256, 300]
+
+
+@pytest.mark.parametrize("K", SPMM_K)
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
+def test_spmm_forward_backward_vs_oracle(K, reduce):
+    n_rows, n_cols = 700, 650
+    row, col = random_csr(n_rows, n_cols, 9, seed=K, hubs=((5, 1400), (699, 600)), dup=(K % 2 == 0))
+    g = torch.Generator().manual_seed(K + 1)
+    val = torch.rand(row.numel(), generator=g) + 0.1 if reduce != "mean" and K % 3 != 0 else None
+    o, p = make_pair(row, col, val, (n_rows, n_cols))
+    x = torch.randn(n_cols, K, generator=g)
+    gy = torch.randn(n_rows, K, generator=g)
+    xo = x.clone().requires_grad_(True)
+    xp = x.to(DEV).requires_grad_(True)
+    yo = o.matmul(xo, reduce)
+    yp = p.matmul(xp, reduce)
+    close(yp, yo, msg=f"fwd K={K} {reduce}")
+    yo.backward(gy)
+    yp.backward(gy.to(DEV))
+    close(xp.grad, xo.grad, rtol=1e-4, msg=f"bwd K={K} {reduce}")
+
+
+@pytest.mark.parametrize("K", [4, 33, 128])
+def test_spmm_max_argmax_bit_exact_with_ties(K):
+    n_rows, n_cols = 300, 280
+    row, col = random_csr(n_rows, n_cols, 12, seed=11, hubs=((7, 900),), dup=True)
+    o, p = make_pair(row, col, None, (n_rows, n_cols))
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-3, 4, (n_cols, K), generator=g).float()  # small integers => many exact ties
+    yo, ao = OS.matmul_max_with_arg(o, x)
+    yp, ap = ops.spmm_raw(p, x.to(DEV), "max")
+    assert torch.equal(yp.cpu(), yo)
+    assert torch.equal(ap.cpu(), ao), "argmax must be the first maximal stored entry"
+
+
+def test_spmm_int64_path_and_no_long_row_list_agree():
+    n = 400
+    row, col = random_csr(n, n, 10, seed=5, hubs=((3, 1500),))
+    o, p = make_pair(row, col, None, (n, n))
+    x = torch.randn(n, 96)
+    ref = o.matmul(x, "sum")
+    p._struct["idx"] = (p._rowptr, p._col, 64)  # force the int64 kernels
+    y64, _ = ops.spmm_raw(p, x.to(DEV), "sum")
+    close(y64, ref)
+    y_nolong, _ = ops.spmm_raw(p, x.to(DEV), "sum", use_long_rows=False)
+    close(y_nolong, ref)
+
+
+def test_spmm_deterministic_and_strided_input():
+    n = 2000
+    row, col = random_csr(n, n, 14, seed=8, hubs=((0, 3000),))
+    o, p = make_pair(row, col, torch.rand(row.numel()), (n, n))
+    big = torch.randn(n, 320, device=DEV)
+    x = big[:, 32:288]  # ld = 320, 16-byte aligned view
+    y1, _ = ops.spmm_raw(p, x, "sum")
+    y2, _ = ops.spmm_raw(p, x, "sum")
+    assert torch.equal(y1, y2), "fixed summation order => run-to-run bit-stable"
+    close(y1, o.matmul(x.cpu().contiguous(), "sum"))
+    x_odd = big[:, 1:257]  # misaligned view must take the scalar path and still be right
+    y3, _ = ops.spmm_raw(p, x_odd, "sum")
+    close(y3, o.matmul(x_odd.cpu().contiguous(), "sum"))
+
+
+def test_spmm_rectangular_mag_style_mean():
+    n_dst, n_src = 900, 400
+    row, col = random_csr(n_dst, n_src, 6, seed=21)
+    o, p = make_pair(row, col, None, (n_dst, n_src))
+    x = torch.randn(n_src, 128)
+    close(p.matmul(x.to(DEV), reduce="mean"), o.matmul(x, reduce="mean"))
+
+
+def test_spmm_full_size_properties():
+    """BASELINE.json size (N=169 343, ~2.3 M nnz): size-independent properties instead of the oracle."""
+    d = D.arxiv_like(1.0, seed=0, with_teacher=False)
+    adj = d.adj_t.to(DEV)
+    n = d.num_nodes
+    cnt = (adj.csr()[0][1:] - adj.csr()[0][:-1]).float()
+    ones = torch.ones(n, 8, device=DEV)
+    deg, _ = ops.spmm_raw(adj, ones, "sum")
+    assert torch.equal(deg[:, 0], cnt), "A * 1 = row counts, exactly (integers < 2^24)"
+    x = torch.randn(n, 256, device=DEV)
+    y, _ = ops.spmm_raw(adj, x, "sum")
+    ym, _ = ops.spmm_raw(adj, x, "mean")
+    close(ym * cnt.clamp(min=1).unsqueeze(1), y, rtol=1e-5)
+    # linearity and symmetry: <A x, z> == <x, A^T z> with A symmetric
+    z = torch.randn(n, 256, device=DEV)
+    yz, _ = ops.spmm_raw(adj.t(), z, "sum")
+    lhs, rhs = (y.double() * z.double()).sum(), (x.double() * yz.double()).sum()
+    assert abs(lhs - rhs) <= 1e-6 * abs(lhs)
+    # spot rows against a gather-sum done with torch on the device (incl. the hub row)
+    rowptr, col, _ = adj.csr()
+    hub = int(torch.argmax(cnt))
+    for r in [0, 1, hub, n - 1]:
+        s, e = int(rowptr[r]), int(rowptr[r + 1])
+        ref = x[col[s:e]].double().sum(0)
+        close(y[r], ref, rtol=1e-5)
+    gn = E.gcn_norm(adj)
+    rs, _ = ops.spmm_raw(gn, torch.ones(n, 4, device=DEV), "sum")
+    dinv = (cnt + 1).pow(-0.5)
+    rs_ref, _ = ops.spmm_raw(adj, dinv.unsqueeze(1).expand(n, 4).contiguous(), "sum")
+    close(rs[:, 0], dinv * (rs_ref[:, 0] + dinv), rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense GEMM
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (130, 70, 33), (256, 256, 256), (1000, 40, 256), (515, 256, 750), (64, 300, 17)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_all_layouts(M, N, K, ta, tb):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = (a.t() if ta else a).double() @ (b.t() if tb else b).double() * 0.5 + bias.double()
+    out = ops.gemm_raw(a.to(DEV), b.to(DEV), ta, tb, bias.to(DEV), alpha=0.5)
+    close(out, ref, rtol=1e-5, atol_scale=2e-6, msg=f"{M}x{N}x{K} ta={ta} tb={tb}")
+
+
+def test_gemm_split_k_and_asymmetric_operand():
+    # A = I with an asymmetric B catches row/column transposes of the MFMA fragment layout
+    n = 160
+    b = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 7.0
+    out = ops.gemm_raw(torch.eye(n, device=DEV), b.to(DEV))
+    assert torch.equal(out.cpu(), b)
+    g = torch.Generator().manual_seed(0)
+    x, gy = torch.randn(20000, 96, generator=g), torch.randn(20000, 72, generator=g)
+    ref = x.double().t() @ gy.double()
+    for sk in (1, 7, 32):
+        close(ops.gemm_raw(x.to(DEV), gy.to(DEV), True, False, split_k=sk), ref, rtol=1e-5, atol_scale=2e-6, msg=f"split_k={sk}")
+    o1 = ops.gemm_raw(x.to(DEV), gy.to(DEV), True, False, split_k=32)
+    o2 = ops.gemm_raw(x.to(DEV), gy.to(DEV), True, False, split_k=32)
+    assert torch.equal(o1, o2)
+
+
+def test_linear_and_matmul_autograd():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(777, 128, generator=g)
+    w = torch.randn(128, 40, generator=g)
+    wl = torch.randn(256, 128, generator=g)
+    bl = torch.randn(256, generator=g)
+    for kind in ("matmul", "linear"):
+        xr = x.clone().requires_grad_(True)
+        xg = x.to(DEV).requires_grad_(True)
+        if kind == "matmul":
+            wr, wg = w.clone().requires_grad_(True), w.to(DEV).requires_grad_(True)
+            yr, yg = xr @ wr, ops.matmul(xg, wg)
+            params = [(wr, wg)]
+        else:
+            wr, wg = wl.clone().requires_grad_(True), wl.to(DEV).requires_grad_(True)
+            br, bg = bl.clone().requires_grad_(True), bl.to(DEV).requires_grad_(True)
+            yr, yg = torch.nn.functional.linear(xr, wr, br), ops.linear(xg, wg, bg)
+            params = [(wr, wg), (br, bg)]
+        close(yg, yr, rtol=1e-5, atol_scale=2e-6)
+        gy = torch.randn(yr.shape, generator=g)
+        yr.backward(gy)
+        yg.backward(gy.to(DEV))
+        close(xg.grad, xr.grad, rtol=1e-4, atol_scale=1e-5)
+        for r, q in params:
+            close(q.grad, r.grad, rtol=1e-4, atol_scale=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# convs
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["gcn", "sage_mean", "sage_max", "sage_sum"])
+def test_conv_layers_vs_oracle(kind):
+    n, fin, fout = 600, 50, 121
+    row, col = random_csr(n, n, 8, seed=2, hubs=((1, 700),))
+    o, p = make_pair(row, col, None, (n, n))
+    o, p = o.to_symmetric(), p.to_symmetric()
+    torch.manual_seed(0)
+    if kind == "gcn":
+        co, cp = ON.GCNConv(fin, fout, cached=True), E.GCNConv(fin, fout, cached=True).to(DEV)
+    else:
+        aggr = kind.split("_")[1]
+        co, cp = ON.SAGEConv(fin, fout, aggr=aggr), E.SAGEConv(fin, fout, aggr=aggr).to(DEV)
+    cp.load_state_dict(co.state_dict())
+    x = torch.randn(n, fin)
+    xo, xp = x.clone().requires_grad_(True), x.to(DEV).requires_grad_(True)
+    yo, yp = co(xo, o), cp(xp, p)
+    close(yp, yo, msg=kind)
+    gy = torch.randn(n, fout)
+    yo.backward(gy)
+    yp.backward(gy.to(DEV))
+    close(xp.grad, xo.grad, rtol=1e-4, msg=kind)
+    for (k, a), (_, b) in zip(cp.named_parameters(), co.named_parameters()):
+        close(a.grad, b.grad, rtol=1e-4, msg=f"{kind}:{k}")
+
+
+def test_gcnconv_edge_index_input_ppi_path():
+    n = 300
+    g = torch.Generator().manual_seed(4)
+    ei = torch.stack([torch.randint(0, n, (2500,), generator=g), torch.randint(0, n, (2500,), generator=g)])
+    ei = torch.cat([ei, ei.flip(0)], dim=1)  # symmetric like PPI, with a few self loops and duplicates
+    torch.manual_seed(0)
+    co, cp = ON.GCNConv(50, 64, cached=False), E.GCNConv(50, 64, cached=False).to(DEV)
+    cp.load_state_dict(co.state_dict())
+    x = torch.randn(n, 50)
+    close(cp(x.to(DEV), ei.to(DEV)), co(x, ei))
+    so, sp = ON.SAGEConv(50, 64), E.SAGEConv(50, 64).to(DEV)
+    sp.load_state_dict(so.state_dict())
+    close(sp(x.to(DEV), ei.to(DEV)), so(x, ei))
+
+
+# ------------------------------------------------------------------------------------------------
+# criteria: golden vectors produced by the reference's own criterion.py
+# ------------------------------------------------------------------------------------------------
+def _run_case(fn, leaves, seed):
+    L = {k: v.clone().requires_grad_(True) for k, v in leaves.items()}
+    if seed is not None:
+        np.random.seed(seed)
+    loss, loss_cls, loss_aux = fn(L)
+    g = torch.autograd.grad(loss, list(L.values()), allow_unused=True, retain_graph=True)
+    ga = torch.autograd.grad(loss_aux, list(L.values()), allow_unused=True)
+    rec = {"loss": loss, "loss_cls": loss_cls, "loss_aux": loss_aux}
+    for (k, _), a, b in zip(L.items(), g, ga):
+        rec["grad_" + k] = a
+        rec["auxgrad_" + k] = b
+    return rec
+
+
+def test_criteria_match_reference_goldens(golden_criterion):
+    G = golden_criterion
+    cases, _ = criterion_cases(G, PC, DEV)
+    failures = []
+    for name, fn, leaves, seed in cases:
+        try:
+            rec = _run_case(fn, leaves, seed)
+            for k, v in rec.items():
+                ref = G[f"{name}__{k}"]
+                if v is None:
+                    assert ref.size == 0 or np.abs(ref).max() == 0, f"{name}:{k} missing grad"
+                    continue
+                rtol = 2e-5 if k.startswith("loss") else 1e-4
+                close(v, ref, rtol=rtol, atol_scale=1e-5 if not k.startswith("loss") else 0, msg=f"{name}:{k}")
+        except NotImplementedError as ex:  # pragma: no cover
+            failures.append(f"{name}: not implemented {ex}")
+        except AssertionError as ex:
+            failures.append(f"{name}: {str(ex)[:300]}")
+    assert not failures, "\n".join(failures)
+
+
+def test_ppi_kd_matches_reference_golden(golden_criterion):
+    G = golden_criterion
+    pl, py, pt = (as_t(G["in_ppi_" + k], DEV) for k in ("logits", "labels", "teacher"))
+    rec = _run_case(lambda L: E.ppi_kd_criterion(L["logits"], py, pt, 0.5, 1.0), {"logits": pl}, None)
+    for k, v in rec.items():
+        close(v, G[f"ppi_kd__{k}"], rtol=2e-5 if k.startswith("loss") else 1e-4, atol_scale=1e-5)
+
+
+@pytest.mark.parametrize("n,C,T", [(1, 2, 1.0), (257, 40, 4.0), (1000, 121, 2.0), (5000, 7, 4.0)])
+def test_ce_kd_kernel_vs_oracle(n, C, T):
+    g = torch.Generator().manual_seed(n)
+    logits = (torch.randn(n, C, generator=g) * 3).requires_grad_(True)
+    labels = torch.randint(0, C, (n,), generator=g)
+    teacher = torch.randn(n, C, generator=g) * 4
+    ref = OC.kd_criterion(logits, labels, teacher, 0.9, T)
+    lg = logits.detach().to(DEV).requires_grad_(True)
+    out = E.kd_criterion(lg, labels.to(DEV), teacher.to(DEV), 0.9, T)
+    for a, b in zip(out, ref):
+        close(a, b, rtol=1e-5, atol_scale=0)
+    ref[0].backward()
+    out[0].backward()
+    close(lg.grad, logits.grad, rtol=1e-4)
+
+
+@pytest.mark.parametrize("S,P,n,tau", [(64, 16, 64, 0.075), (300, 72, 500, 0.075), (1000, 256, 1000, 0.05), (2048, 256, 3000, 0.075)])
+def test_nce_vs_oracle(S, P, n, tau):
+    g = torch.Generator().manual_seed(S)
+    logits = torch.randn(n, 5, generator=g)
+    labels = torch.randint(0, 5, (n,), generator=g)
+    f = torch.relu(torch.randn(n, P, generator=g))
+    t = torch.relu(torch.randn(n, P, generator=g) + 0.3 * f)
+    fo, to_ = f.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    fp, tp = f.to(DEV).requires_grad_(True), t.to(DEV).requires_grad_(True)
+    np.random.seed(S)
+    ref = OC.nce_criterion(logits, labels, fo, to_, 0.1, tau, S)
+    np.random.seed(S)
+    out = E.nce_criterion(logits.to(DEV), labels.to(DEV), fp, tp, 0.1, tau, S)
+    close(out[2], ref[2], rtol=2e-5, atol_scale=0, msg="loss_nce")
+    close(out[0], ref[0], rtol=2e-5, atol_scale=0)
+    ref[0].backward()
+    out[0].backward()
+    close(fp.grad, fo.grad, rtol=1e-4, atol_scale=2e-5)
+    close(tp.grad, to_.grad, rtol=1e-4, atol_scale=2e-5)
+
+
+def test_nce_full_size_properties():
+    """S = 16384, P = 256 (run_gcn.sh:140-145): properties that need no S x S oracle."""
+    S, P = 16384, 256
+    g = torch.Generator(device=DEV).manual_seed(0)
+    f = torch.nn.functional.normalize(torch.randn(S, P, device=DEV, generator=g), dim=-1)
+    # identical student and teacher with tiny tau: the positive dominates, loss -> ~0
+    l0 = ops.nce_unit(f, f.clone(), 0.01)
+    assert float(l0) < 1e-3
+    # orthogonal-ish random teacher: loss ~ log(S) + small; and invariance to a row permutation applied to both
+    t = torch.nn.functional.normalize(torch.randn(S, P, device=DEV, generator=g), dim=-1)
+    l1 = ops.nce_unit(f, t, 0.075)
+    perm = torch.randperm(S, device=DEV)
+    l2 = ops.nce_unit(f[perm].contiguous(), t[perm].contiguous(), 0.075)
+    assert abs(float(l1) - float(l2)) <= 2e-5 * abs(float(l1))
+    assert abs(float(l1) - np.log(S)) < 1.0
+    # gradient rows are orthogonal to nothing in particular, but sum_i dL/df_i . f_i relation: check against
+    # a row-block evaluated with torch on the device
+    fr = f.clone().requires_grad_(True)
+    tr = t.clone().requires_grad_(True)
+    ops.nce_unit(fr, tr, 0.075).backward()
+    rows = torch.arange(0, S, 997, device=DEV)
+    z = (f[rows] @ t.t()) / 0.075
+    p = torch.softmax(z.double(), dim=1)
+    p[torch.arange(rows.numel(), device=DEV), rows] -= 1.0
+    ref = (p @ t.double()) / (S * 0.075)
+    close(fr.grad[rows], ref, rtol=1e-4, atol_scale=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# whole train / eval step vs goldens produced by the reference's own gnn.py
+# ------------------------------------------------------------------------------------------------
+def _build_adj_dev(G):
+    n = G["in_x"].shape[0]
+    return E.to_sparse_tensor(as_t(G["in_edge_index"], DEV), n).to_symmetric()
+
+
+def test_train_and_eval_match_reference_goldens(golden_train):
+    G = golden_train
+    failures = []
+    for name in G["run_names"]:
+        name = str(name)
+        tag = name.split(":")[0]
+        try:
+            model, losses, logits0, accs0 = run_training(G, name, PM, _build_adj_dev, DEV)
+            close(logits0, G[f"{tag}__eval0_logits"], rtol=1e-4, atol_scale=1e-5, msg=name)
+            close(losses, G[f"{tag}__losses"], rtol=2e-4, atol_scale=0, msg=name)
+            for k, v in model.state_dict().items():
+                if noise_driven(k, int(G["hp"][2])):
+                    continue
+                close(v, G[f"{tag}__final__model.{k}"], rtol=2e-3, atol_scale=2e-3, msg=f"{name}:{k}")
+        except NotImplementedError as ex:  # pragma: no cover
+            failures.append(f"{name}: not implemented {ex}")
+        except AssertionError as ex:
+            failures.append(f"{name}: {str(ex)[:400]}")
+    assert not failures, "\n".join(failures)
