@@ -101,12 +101,12 @@ class SpmmProbe:
         self._orig = ops.spmm_raw
 
     def __enter__(self):
-        def wrapped(adj, x, reduce="sum", src_scale=None, use_long_rows=True):
+        def wrapped(adj, x, reduce="sum", src_scale=None, use_plan=True):
             if not self.active:
-                return self._orig(adj, x, reduce, src_scale, use_long_rows)
+                return self._orig(adj, x, reduce, src_scale, use_plan)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            out = self._orig(adj, x, reduce, src_scale, use_long_rows)
+            out = self._orig(adj, x, reduce, src_scale, use_plan)
             b.record()
             self.records.append((x.shape[1], adj.nnz(), adj.spmm_algorithmic_bytes(x.shape[1]), a, b))
             return out

@@ -19,7 +19,7 @@ SIGNATURES = {
     "egnn_abi_version": (_i32, []),
     "egnn_error_string": (C.c_char_p, [_i32]),
     "egnn_build_info": (_i32, [C.c_char_p, _sz]),
-    "egnn_spmm_csr_f32": (_i32, [_i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p, _i64, _i64, _p]),
+    "egnn_spmm_csr_f32": (_i32, [_i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p, _i64, _p, _i64, _p, _i64, _p]),
     "egnn_spmm_csr_max_bwd_f32": (_i32, [_i64, _i64, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p]),
     "egnn_spmm_algorithmic_bytes": (_i64, [_i64, _i64, _i64, _i64, _i32, _i32]),
     "egnn_rowptr_from_sorted_rows_i64": (_i32, [_p, _i64, _i64, _p, _p]),
@@ -36,6 +36,13 @@ SIGNATURES = {
     "egnn_nce_ws_floats": (_sz, [_i64]),
     "egnn_nce_fwd_f32": (_i32, [_p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _p, _sz, _p]),
     "egnn_nce_bwd_f32": (_i32, [_p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _p, _p, _p]),
+    "egnn_gsp_ws_floats": (_sz, [_i64]),
+    "egnn_gsp_fwd_f32": (_i32, [_p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _sz, _p]),
+    "egnn_rowsum_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p]),
+    "egnn_scale_rowcorr_f32": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _p, _i64, _p]),
+    "egnn_bce_pair_ws_floats": (_sz, []),
+    "egnn_bce_pair_fwd_f32": (_i32, [_p, _p, _p, _i64, _p, _p, _p]),
+    "egnn_bce_pair_bwd_f32": (_i32, [_p, _p, _p, _i64, _p, _p, _p, _p]),
 }
 
 _lib = None

@@ -32,9 +32,8 @@ struct SpmmArgs {
   int64_t ldy;
   int mean;
   int64_t* argmax;
-  const int64_t* long_rows;
-  int64_t n_long;
-  int64_t long_threshold;
+  const int64_t* rows;  // row list walked by the launch (nullptr: rows 0..n_list-1)
+  int64_t n_list;
   int logG;      // lanes per neighbour = 1 << logG
   int NS;        // number of column slices
   int map_mode;  // 0: slice = b % NS ; 1: NS divides 8 ; 2: NS multiple of 8
@@ -172,11 +171,11 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const SpmmArgs<IdxT> a) 
     slice = b % a.NS;
     rg = b / a.NS;
   }
-  const int64_t row = rg * 4 + wave;
-  if (row >= a.n_rows) return;
+  const int64_t ridx = rg * 4 + wave;
+  if (ridx >= a.n_list) return;
+  const int64_t row = a.rows ? a.rows[ridx] : ridx;
   const int64_t start = (int64_t)a.rowptr[row];
   const int64_t end = (int64_t)a.rowptr[row + 1];
-  if (a.long_rows != nullptr && end - start > a.long_threshold) return;  // workgroup-per-row kernel
 
   const int G = 1 << a.logG;
   const int sub = lane >> a.logG;
@@ -208,7 +207,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void spmm_long_rows_kernel(const S
   const int wave = egnn_wave_id();
   const int64_t b = blockIdx.x;
   const int64_t slice = b % a.NS;
-  const int64_t row = a.long_rows[b / a.NS];
+  const int64_t row = a.rows[b / a.NS];
   const int64_t start = (int64_t)a.rowptr[row];
   const int64_t end = (int64_t)a.rowptr[row + 1];
   // contiguous chunk per wave, multiple of 64 entries so index loads stay aligned/coalesced
@@ -257,14 +256,126 @@ __global__ __launch_bounds__(kLongWaves * 64) void spmm_long_rows_kernel(const S
   }
 }
 
+
+// ---- sub-group-per-(short row, slice) kernel ------------------------------------------------------
+// The power-law bulk (degree <= short_max): a wave walks 64/G rows at once, one G-lane sub-group per row,
+// so the rowptr -> col -> X dependency chain is paid once per 64/G rows and G gathers per row are in flight
+// without any cross-lane reduction.  The caller orders `rows` so that a wave's rows have similar lengths.
+// Persistent grid: each wave strides over row groups of its slice (slice <-> XCD binding as above).
+template <typename IdxT, int LOGG>
+__global__ __launch_bounds__(256) void spmm_short_rows_kernel(const SpmmArgs<IdxT> a) {
+  constexpr int G = 1 << LOGG;
+  constexpr int NPW = 64 >> LOGG;
+  constexpr int UN = G < 8 ? G : 8;
+  const int lane = egnn_lane();
+  const int wave = egnn_wave_id();
+  const int sub = lane >> LOGG;
+  const int li = lane & (G - 1);
+  const int lane0 = lane & ~(G - 1);
+  const int64_t n_groups = (a.n_list + NPW - 1) / NPW;
+  const int64_t b = blockIdx.x, nb = gridDim.x;
+  // enumerate this wave's (slice, group) items
+  int64_t slice0, slice_step, n_slices_mine, g0, gstep;
+  if (a.map_mode == 1) {
+    const int x = (int)(b & 7);
+    const int r = 8 / a.NS;
+    slice0 = x % a.NS; slice_step = 1; n_slices_mine = 1;
+    g0 = ((b >> 3) * r + x / a.NS) * 4 + wave;
+    gstep = (nb >> 3) * r * 4;
+  } else if (a.map_mode == 2) {
+    const int x = (int)(b & 7);
+    slice0 = x; slice_step = 8; n_slices_mine = a.NS >> 3;
+    g0 = (b >> 3) * 4 + wave;
+    gstep = (nb >> 3) * 4;
+  } else {
+    slice0 = 0; slice_step = 1; n_slices_mine = a.NS;
+    g0 = b * 4 + wave;
+    gstep = nb * 4;
+  }
+  for (int64_t si = 0; si < n_slices_mine; ++si) {
+    const int64_t slice = slice0 + si * slice_step;
+    const int64_t col0 = (slice * G + li) * 4;
+    const bool colok = col0 < a.K;
+    for (int64_t grp = g0; grp < n_groups; grp += gstep) {
+      const int64_t sg = grp * NPW + sub;
+      const bool live = sg < a.n_list;
+      int64_t row = 0, start = 0, end = 0;
+      if (live) {
+        row = a.rows ? a.rows[sg] : sg;
+        start = (int64_t)a.rowptr[row];
+        end = (int64_t)a.rowptr[row + 1];
+      }
+      float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+      for (int64_t e = start; e < end; e += G) {
+        const int64_t rem = end - e;
+        const int n = rem < G ? (int)rem : G;
+        const int64_t ee = e + (li < n ? li : 0);  // lanes past the row end re-read its first entry (weight 0)
+        const long long c_l = (long long)a.col[ee];
+        float v_l = 0.f;
+        if (li < n) {
+          v_l = a.val ? a.val[ee] : 1.f;
+          if (a.src_scale) v_l *= a.src_scale[c_l];
+        }
+#pragma unroll
+        for (int j0 = 0; j0 < G; j0 += UN) {
+          float4 x[UN];
+          float v[UN];
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            const long long c = __shfl(c_l, lane0 + j0 + u);
+            v[u] = __shfl(v_l, lane0 + j0 + u);
+            x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (colok) x[u] = *reinterpret_cast<const float4*>(a.X + c * a.ldx + col0);
+          }
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            const bool ok = j0 + u < n;  // select, not multiply: a padded lane must not turn inf/nan into nan
+            acc0 = ok ? fmaf(v[u], x[u].x, acc0) : acc0;
+            acc1 = ok ? fmaf(v[u], x[u].y, acc1) : acc1;
+            acc2 = ok ? fmaf(v[u], x[u].z, acc2) : acc2;
+            acc3 = ok ? fmaf(v[u], x[u].w, acc3) : acc3;
+          }
+        }
+      }
+      if (live && colok) {
+        const int64_t cnt = end - start;
+        const float inv = a.mean ? 1.f / (float)(cnt > 0 ? cnt : 1) : 1.f;
+        *reinterpret_cast<float4*>(a.Y + row * a.ldy + col0) = make_float4(acc0 * inv, acc1 * inv, acc2 * inv, acc3 * inv);
+      }
+    }
+  }
+}
+
 int ilog2_ceil(int64_t v) {
   int l = 0;
   while ((1LL << l) < v) ++l;
   return l;
 }
 
+struct RowPlan {
+  const int64_t* short_rows; int64_t n_short;
+  const int64_t* mid_rows; int64_t n_mid;
+  const int64_t* long_rows; int64_t n_long;
+};
+
 template <typename IdxT, int VEC, bool IS_MAX>
-int launch(SpmmArgs<IdxT> a, hipStream_t st) {
+void launch_wave_per_row(SpmmArgs<IdxT> a, const int64_t* rows, int64_t n_list, hipStream_t st) {
+  if (n_list <= 0) return;
+  a.rows = rows;
+  a.n_list = n_list;
+  const int64_t rgroups = (n_list + 3) / 4;
+  int64_t grid;
+  if (a.map_mode == 1) {
+    const int r = 8 / a.NS;
+    grid = ((rgroups + r - 1) / r) * 8;
+  } else {
+    grid = rgroups * a.NS;
+  }
+  hipLaunchKernelGGL((spmm_rows_kernel<IdxT, VEC, IS_MAX>), dim3((unsigned)grid), dim3(256), 0, st, a);
+}
+
+template <typename IdxT, int VEC, bool IS_MAX>
+int launch(SpmmArgs<IdxT> a, const RowPlan& plan, hipStream_t st) {
   // slice geometry: 128-byte slices (G = 8 float4 lanes) whenever K allows, else one slice per <=64 lanes
   const int64_t kv = (a.K + VEC - 1) / VEC;  // columns in VEC units
   if (VEC == 4 && kv % 8 == 0) {
@@ -274,34 +385,50 @@ int launch(SpmmArgs<IdxT> a, hipStream_t st) {
     a.logG = ilog2_ceil(kv < 64 ? kv : 64);
     a.NS = (int)((kv + (1 << a.logG) - 1) >> a.logG);
   }
-  int64_t rgroups = (a.n_rows + 3) / 4;
-  int64_t grid;
-  if (a.NS <= 8 && 8 % a.NS == 0) {
-    a.map_mode = 1;
-    const int r = 8 / a.NS;
-    grid = ((rgroups + r - 1) / r) * 8;
-  } else if (a.NS % 8 == 0) {
-    a.map_mode = 2;
-    grid = rgroups * a.NS;
-  } else {
-    a.map_mode = 0;
-    grid = rgroups * a.NS;
+  a.map_mode = (a.NS <= 8 && 8 % a.NS == 0) ? 1 : (a.NS % 8 == 0 ? 2 : 0);
+  if ((a.n_rows + 3) / 4 * (int64_t)a.NS > 0x7fffffffLL) return EGNN_EINVAL;
+  const bool planned = plan.short_rows || plan.mid_rows || plan.long_rows;
+  if (!planned) {
+    launch_wave_per_row<IdxT, VEC, IS_MAX>(a, nullptr, a.n_rows, st);
+    return egnn_launch_status();
   }
-  if (grid > 0x7fffffffLL) return EGNN_EINVAL;
-  if (a.n_rows > 0) hipLaunchKernelGGL((spmm_rows_kernel<IdxT, VEC, IS_MAX>), dim3((unsigned)grid), dim3(256), 0, st, a);
-  if (a.long_rows != nullptr && a.n_long > 0) {
-    const int64_t g2 = a.n_long * a.NS;
+  // short rows: sub-group-per-row kernel where it exists (float4 path, G in {8,16}, sum/mean)
+  bool short_done = false;
+  if constexpr (VEC == 4 && !IS_MAX) {
+    if (plan.n_short > 0 && (a.logG == 3 || a.logG == 4)) {
+      SpmmArgs<IdxT> s = a;
+      s.rows = plan.short_rows;
+      s.n_list = plan.n_short;
+      const int npw = 64 >> a.logG;
+      const int64_t n_groups = (plan.n_short + npw - 1) / npw;
+      // waves that share a slice; 8 resident blocks per CU x 32 CUs per XCD is the ceiling worth launching
+      const int teams = a.map_mode == 1 ? a.NS : (a.map_mode == 2 ? 8 : 1);
+      int64_t blocks = (n_groups + 3) / 4 * teams;
+      blocks = (blocks + 7) / 8 * 8;
+      if (blocks > 2048) blocks = 2048;
+      if (a.logG == 3) hipLaunchKernelGGL((spmm_short_rows_kernel<IdxT, 3>), dim3((unsigned)blocks), dim3(256), 0, st, s);
+      else hipLaunchKernelGGL((spmm_short_rows_kernel<IdxT, 4>), dim3((unsigned)blocks), dim3(256), 0, st, s);
+      short_done = true;
+    }
+  }
+  if (!short_done) launch_wave_per_row<IdxT, VEC, IS_MAX>(a, plan.short_rows, plan.n_short, st);
+  launch_wave_per_row<IdxT, VEC, IS_MAX>(a, plan.mid_rows, plan.n_mid, st);
+  if (plan.n_long > 0) {
+    SpmmArgs<IdxT> l = a;
+    l.rows = plan.long_rows;
+    l.n_list = plan.n_long;
+    const int64_t g2 = plan.n_long * a.NS;
     if (g2 > 0x7fffffffLL) return EGNN_EINVAL;
-    hipLaunchKernelGGL((spmm_long_rows_kernel<IdxT, VEC, IS_MAX>), dim3((unsigned)g2), dim3(kLongWaves * 64), 0, st, a);
+    hipLaunchKernelGGL((spmm_long_rows_kernel<IdxT, VEC, IS_MAX>), dim3((unsigned)g2), dim3(kLongWaves * 64), 0, st, l);
   }
   return egnn_launch_status();
 }
 
 template <typename IdxT>
-int dispatch(SpmmArgs<IdxT> a, int reduce, hipStream_t st) {
+int dispatch(SpmmArgs<IdxT> a, int reduce, const RowPlan& plan, hipStream_t st) {
   const bool vec4 = (a.K % 4 == 0) && (a.ldx % 4 == 0) && (a.ldy % 4 == 0) && egnn_aligned16(a.X) && egnn_aligned16(a.Y);
-  if (reduce == EGNN_MAX) return vec4 ? launch<IdxT, 4, true>(a, st) : launch<IdxT, 1, true>(a, st);
-  return vec4 ? launch<IdxT, 4, false>(a, st) : launch<IdxT, 1, false>(a, st);
+  if (reduce == EGNN_MAX) return vec4 ? launch<IdxT, 4, true>(a, plan, st) : launch<IdxT, 1, true>(a, plan, st);
+  return vec4 ? launch<IdxT, 4, false>(a, plan, st) : launch<IdxT, 1, false>(a, plan, st);
 }
 
 template <typename IdxT>
@@ -321,24 +448,29 @@ __global__ void spmm_max_bwd_kernel(int64_t total, int64_t K, const IdxT* col, c
 
 extern "C" int egnn_spmm_csr_f32(int64_t n_rows, int64_t n_src, int64_t K, const void* rowptr, const void* col,
                                  int index_bits, const float* val, const float* src_scale, const float* X, int64_t ldx,
-                                 float* Y, int64_t ldy, int reduce, int64_t* argmax, const int64_t* long_rows,
-                                 int64_t n_long, int64_t long_threshold, void* stream) {
+                                 float* Y, int64_t ldy, int reduce, int64_t* argmax, const int64_t* short_rows,
+                                 int64_t n_short, const int64_t* mid_rows, int64_t n_mid, const int64_t* long_rows,
+                                 int64_t n_long, void* stream) {
   EGNN_CHECK_ARG(n_rows >= 0 && n_src >= 0 && K >= 0 && ldx >= K && ldy >= K);
   EGNN_CHECK_ARG(index_bits == 32 || index_bits == 64);
   EGNN_CHECK_ARG(reduce == EGNN_SUM || reduce == EGNN_MEAN || reduce == EGNN_MAX);
   if (n_rows == 0 || K == 0) return EGNN_OK;
   EGNN_CHECK_ARG(rowptr && col && X && Y);
   EGNN_CHECK_ARG(reduce != EGNN_MAX || argmax != nullptr);
-  EGNN_CHECK_ARG(n_long >= 0 && (n_long == 0 || long_rows != nullptr));
+  EGNN_CHECK_ARG(n_short >= 0 && n_mid >= 0 && n_long >= 0);
+  EGNN_CHECK_ARG((n_short == 0 || short_rows) && (n_mid == 0 || mid_rows) && (n_long == 0 || long_rows));
+  const bool planned = short_rows || mid_rows || long_rows;
+  EGNN_CHECK_ARG(!planned || n_short + n_mid + n_long == n_rows);
+  const RowPlan plan{short_rows, n_short, mid_rows, n_mid, long_rows, n_long};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (index_bits == 32) {
     SpmmArgs<int32_t> a{n_rows, K, (const int32_t*)rowptr, (const int32_t*)col, val, src_scale, X, ldx, Y, ldy,
-                        reduce == EGNN_MEAN, argmax, n_long > 0 ? long_rows : nullptr, n_long, long_threshold, 0, 0, 0};
-    return dispatch(a, reduce, st);
+                        reduce == EGNN_MEAN, argmax, nullptr, 0, 0, 0, 0};
+    return dispatch(a, reduce, plan, st);
   }
   SpmmArgs<int64_t> a{n_rows, K, (const int64_t*)rowptr, (const int64_t*)col, val, src_scale, X, ldx, Y, ldy,
-                      reduce == EGNN_MEAN, argmax, n_long > 0 ? long_rows : nullptr, n_long, long_threshold, 0, 0, 0};
-  return dispatch(a, reduce, st);
+                      reduce == EGNN_MEAN, argmax, nullptr, 0, 0, 0, 0};
+  return dispatch(a, reduce, plan, st);
 }
 
 extern "C" int egnn_spmm_csr_max_bwd_f32(int64_t n_rows, int64_t K, const void* col, int index_bits, const float* val,

@@ -25,7 +25,7 @@ def _rowmajor(x: Tensor) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 # SpMM
 # ------------------------------------------------------------------------------------------------
-def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = None, use_long_rows: bool = True):
+def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = None, use_plan: bool = True):
     """Y = REDUCE(adj, X) on the GPU (egnn_spmm_csr_f32).  Returns (Y, argmax | None)."""
     _lib.require_gpu(x, adj._col)
     x = _rowmajor(x)
@@ -37,13 +37,14 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
     y = torch.empty(n_rows, K, dtype=torch.float32, device=x.device)
     arg = torch.empty(n_rows, K, dtype=torch.int64, device=x.device) if red == 2 else None
     rowptr, col, bits = adj._index_arrays()
-    long_rows = adj._long_rows() if use_long_rows else None
-    n_long = 0 if long_rows is None else long_rows.numel()
-    from .sparse import LONG_ROW_THRESHOLD
+    short, mid, long_ = adj._row_plan() if use_plan else (None, None, None)
+
+    def lst(t):
+        return (None, 0) if t is None or t.numel() == 0 else (_lib.ptr(t), t.numel())
+    (ps, ns), (pm, nm), (pl, nl) = lst(short), lst(mid), lst(long_)
     rc = _lib.load().egnn_spmm_csr_f32(
         n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), bits, _lib.ptr(adj._value), _lib.ptr(src_scale),
-        _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), red, _lib.ptr(arg),
-        _lib.ptr(long_rows) if n_long else None, n_long, LONG_ROW_THRESHOLD, _lib.stream())
+        _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), red, _lib.ptr(arg), ps, ns, pm, nm, pl, nl, _lib.stream())
     _lib.check(rc, "egnn_spmm_csr_f32")
     return y, arg
 

@@ -19,7 +19,9 @@ from torch import Tensor
 
 from . import _lib
 
+SHORT_ROW_MAX = 64        # entries; rows up to this length share a wavefront (one G-lane sub-group each)
 LONG_ROW_THRESHOLD = 512  # entries; rows above it are reduced by a 16-wave workgroup
+PLAN_CHUNK = 2048         # short rows are length-sorted inside chunks of this many consecutive rows
 
 
 def _ind2ptr(row: Tensor, n_rows: int) -> Tensor:
@@ -199,11 +201,27 @@ class SparseTensor:
                 self._struct["idx"] = (self._rowptr, self._col, 64)
         return self._struct["idx"]
 
-    def _long_rows(self):
-        if "long" not in self._struct:
+    def _row_plan(self):
+        """(short_rows, mid_rows, long_rows) int64 row-id lists for egnn_spmm_csr_f32 (cached per structure).
+
+        Short rows keep their natural order at PLAN_CHUNK granularity (index arrays stay L2-local) but are
+        sorted by length inside each chunk so the 64/G rows sharing a wavefront finish together."""
+        if "plan" not in self._struct:
             cnt = self._rowptr[1:] - self._rowptr[:-1]
-            self._struct["long"] = torch.nonzero(cnt > LONG_ROW_THRESHOLD).view(-1).contiguous()
-        return self._struct["long"]
+            dev = cnt.device
+            short = torch.nonzero(cnt <= SHORT_ROW_MAX).view(-1)
+            mid = torch.nonzero((cnt > SHORT_ROW_MAX) & (cnt <= LONG_ROW_THRESHOLD)).view(-1).contiguous()
+            long_ = torch.nonzero(cnt > LONG_ROW_THRESHOLD).view(-1).contiguous()
+            ns = short.numel()
+            if ns > 0:
+                pad = (-ns) % PLAN_CHUNK
+                ids = torch.cat([short, torch.full((pad,), -1, dtype=torch.int64, device=dev)]) if pad else short
+                deg = torch.where(ids >= 0, cnt[ids.clamp(min=0)], torch.full_like(ids, -1))
+                order = torch.argsort(deg.view(-1, PLAN_CHUNK), dim=1, descending=True, stable=True)
+                ids = torch.gather(ids.view(-1, PLAN_CHUNK), 1, order).view(-1)
+                short = ids[ids >= 0].contiguous()
+            self._struct["plan"] = (short, mid, long_)
+        return self._struct["plan"]
 
     def _inv_rowcount(self) -> Tensor:
         if "invcnt" not in self._struct:

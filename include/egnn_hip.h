@@ -55,10 +55,15 @@ int egnn_build_info(char* buf, size_t buf_bytes);
  * src_scale  [n_src]  nullable; per-source-row factor, used for the backward of mean
  *                     (dX = A^T (dY / cnt)) without materialising a per-entry value array
  * argmax     [n_rows, K] int64, required for EGNN_MAX, ignored otherwise
- * long_rows  [n_long] int64 ids of rows with more than `long_threshold` entries (nullable: then every
- *                     row is handled by the wave-per-row kernel).  Rows listed here are reduced by a
- *                     whole workgroup with a fixed-order LDS combine, so results are run-to-run
- *                     bit-stable for every degree distribution.
+ * Row schedule (built once per sparsity structure by the caller; integer preprocessing):
+ *   short_rows [n_short]  row ids whose entry count is small; a wavefront walks 64/G of them at once (one
+ *                         G-lane sub-group per row, G = lanes per 128-byte column slice), so list neighbours
+ *                         with similar lengths next to each other
+ *   mid_rows   [n_mid]    row ids reduced by one wavefront each
+ *   long_rows  [n_long]   row ids reduced by a whole 16-wave workgroup with a fixed-order LDS combine
+ * Every row id in [0, n_rows) must appear in exactly one list (n_short + n_mid + n_long == n_rows), or all
+ * three lists are NULL and every row takes the one-wavefront path.  The accumulation order is fixed by the
+ * schedule, so results are run-to-run bit-stable for every degree distribution.
  * ---------------------------------------------------------------------------------------------- */
 #define EGNN_SUM 0
 #define EGNN_MEAN 1
@@ -69,8 +74,8 @@ int egnn_spmm_csr_f32(int64_t n_rows, int64_t n_src, int64_t K,
                       const float* val, const float* src_scale,
                       const float* X, int64_t ldx, float* Y, int64_t ldy,
                       int reduce, int64_t* argmax,
-                      const int64_t* long_rows, int64_t n_long, int64_t long_threshold,
-                      void* stream);
+                      const int64_t* short_rows, int64_t n_short, const int64_t* mid_rows, int64_t n_mid,
+                      const int64_t* long_rows, int64_t n_long, void* stream);
 
 /* Backward of EGNN_MAX: dX[col[argmax[i,k]], k] += val * dY[i,k].  dX must be zero-filled by the
  * caller.  Uses float atomics (the only entry point that does); max-aggregation is never exercised
@@ -168,6 +173,34 @@ int egnn_nce_fwd_f32(const float* fhat, const float* that, int64_t S, int64_t P,
 int egnn_nce_bwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,
                      const float* Z, const float* lse, const float* g,
                      float* dfhat, float* dthat, void* stream);
+
+/* GSP all-pairs similarity loss, /root/reference/arxiv_pyg/criterion.py:69-88:
+ *   loss = mean_ij (k(xs_i,xs_j) - k(xt_i,xt_j))^2 ; kernel: EGNN_K_COSINE / _POLY (rows must be unit vectors,
+ *   criterion.py:71-72,76-77) or EGNN_K_L2 / _RBF (raw rows; ||a-b||^2 via ||a||^2+||b||^2-2<a,b>, diagonal exact 0;
+ *   the reference's [S,S,D] difference tensor is never formed).
+ * Writes Ws, Wt ([S,S], ld = S) such that, for an upstream gradient g,
+ *   dxs = g * (Ws xs - rowsum(Ws) o xs),  dxt = g * (Wt xt - rowsum(Wt) o xt)   (rowsum term for L2/RBF only),
+ * i.e. one egnn_gemm_f32 + egnn_rowsum_f32 + egnn_scale_rowcorr_f32 per side.  ws: egnn_gsp_ws_floats(S). */
+#define EGNN_K_COSINE 0
+#define EGNN_K_POLY 1
+#define EGNN_K_L2 2
+#define EGNN_K_RBF 3
+size_t egnn_gsp_ws_floats(int64_t S);
+int egnn_gsp_fwd_f32(const float* xs, int64_t ld_s, int64_t Ps, const float* xt, int64_t ld_t, int64_t Pt, int64_t S,
+                     int kernel, float* Ws, float* Wt, float* loss, float* ws, size_t ws_floats, void* stream);
+/* out[i] = sum_j W[i,j] (fixed order) */
+int egnn_rowsum_f32(const float* W, int64_t ld, int64_t n, int64_t m, float* out, void* stream);
+/* out[i,:] = g * (WX[i,:] - r[i] * X[i,:]);  r nullable (no correction), g nullable device scalar (= 1) */
+int egnn_scale_rowcorr_f32(const float* WX, int64_t ldw, const float* X, int64_t ldx, const float* r, const float* g,
+                           int64_t n, int64_t P, float* out, int64_t ldo, void* stream);
+
+/* PPI multi-label logit KD, /root/reference/ppi_pyg/criterion.py:11-13: out2[0] = mean BCEWithLogits(logits, labels),
+ * out2[1] = mean BCEWithLogits(logits, sigmoid(teacher)) over all `total` = n*C elements (contiguous arrays). */
+size_t egnn_bce_pair_ws_floats(void);
+int egnn_bce_pair_fwd_f32(const float* logits, const float* labels, const float* teacher, int64_t total, float* out2,
+                          float* ws, void* stream);
+int egnn_bce_pair_bwd_f32(const float* logits, const float* labels, const float* teacher, int64_t total,
+                          const float* g_cls, const float* g_kd, float* dlogits, void* stream);
 
 #ifdef __cplusplus
 }

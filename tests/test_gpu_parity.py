@@ -153,7 +153,7 @@ def test_spmm_int64_path_and_no_long_row_list_agree():
     p._struct["idx"] = (p._rowptr, p._col, 64)  # force the int64 kernels
     y64, _ = ops.spmm_raw(p, x.to(DEV), "sum")
     close(y64, ref)
-    y_nolong, _ = ops.spmm_raw(p, x.to(DEV), "sum", use_long_rows=False)
+    y_nolong, _ = ops.spmm_raw(p, x.to(DEV), "sum", use_plan=False)
     close(y_nolong, ref)
 
 

@@ -59,7 +59,7 @@ def main():
     for K in (256, 128, 40):
         x = torch.randn(n, K, device=DEV)
         for label, a, kw in (("gcn_sum_val", gn, {}), ("sage_mean", adj, {"reduce": "mean"}),
-                             ("gcn_sum_val_nolong", gn, {"use_long_rows": False})):
+                             ("gcn_sum_val_noplan", gn, {"use_plan": False})):
             t = timeit(lambda: ops.spmm_raw(a, x, **kw))
             nbytes = a.spmm_algorithmic_bytes(K)
             emit(f, what="spmm", variant=label, K=K, nnz=a.nnz(), us=round(t * 1e6, 2), alg_MB=round(nbytes / 1e6, 1),
