@@ -1,0 +1,188 @@
+// LSP building blocks (/root/reference/arxiv_pyg/criterion.py:95-126) for gfx950: per-edge similarity of
+// gathered feature rows and the segment softmax of torch_geometric.utils.softmax (criterion.py:5,103-113).
+//
+// The reference materialises feat[src], feat[dst] ([E,D] twice per feature matrix) and uses atomic
+// scatter_max / scatter_add for the softmax (K5/K6 in SURVEY.md 2.2).  Here an edge's two rows are read
+// straight into registers by one wavefront (never written back), and segments are CSR rows, so the softmax
+// needs no atomics and has a fixed summation order.  HBM/L2-bound gather work: no MFMA.
+#include "common.h"
+
+namespace {
+
+enum { K_COSINE = 0, K_POLY = 1, K_L2 = 2, K_RBF = 3 };
+constexpr float kCosEps = 1e-8f;
+
+// one wavefront per edge: aux = (dot, |a|^2, |b|^2) for cosine/poly, (d2, 0, 0) for l2/rbf
+template <bool VEC4>
+__global__ __launch_bounds__(256) void edge_sim_kernel(const float* __restrict__ F, int64_t ld, int64_t D,
+                                                       const int64_t* __restrict__ ia, const int64_t* __restrict__ ib,
+                                                       int64_t E, int kernel, float* __restrict__ sim,
+                                                       float* __restrict__ aux) {
+  const int lane = egnn_lane();
+  for (int64_t e = blockIdx.x * 4LL + egnn_wave_id(); e < E; e += (int64_t)gridDim.x * 4) {
+    const float* a = F + ia[e] * ld;
+    const float* b = F + ib[e] * ld;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if constexpr (VEC4) {
+      for (int64_t d = lane * 4; d < D; d += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(a + d);
+        const float4 y = *reinterpret_cast<const float4*>(b + d);
+        if (kernel <= K_POLY) {
+          s0 += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+          s1 += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+          s2 += y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+        } else {
+          const float d0 = x.x - y.x, d1 = x.y - y.y, d2 = x.z - y.z, d3 = x.w - y.w;
+          s0 += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+      }
+    } else {
+      for (int64_t d = lane; d < D; d += 64) {
+        const float x = a[d], y = b[d];
+        if (kernel <= K_POLY) { s0 = fmaf(x, y, s0); s1 = fmaf(x, x, s1); s2 = fmaf(y, y, s2); }
+        else { const float t = x - y; s0 = fmaf(t, t, s0); }
+      }
+    }
+    s0 = egnn_wave_sum(s0);
+    if (kernel <= K_POLY) { s1 = egnn_wave_sum(s1); s2 = egnn_wave_sum(s2); }
+    if (lane == 0) {
+      float v;
+      if (kernel <= K_POLY) {
+        // torch 1.7 F.cosine_similarity: dot / sqrt(max(|a|^2 |b|^2, eps^2))   
+        const float c = s0 / sqrtf(fmaxf(s1 * s2, kCosEps * kCosEps));
+        v = kernel == K_COSINE ? c : c * c;
+      } else {
+        v = kernel == K_L2 ? sqrtf(s0) : expf(-0.5f * s0);
+      }
+      sim[e] = v;
+      aux[3 * e] = s0; aux[3 * e + 1] = s1; aux[3 * e + 2] = s2;
+    }
+  }
+}
+
+// d(sim)/d(a) = alpha * b + beta_a * a ; d(sim)/d(b) = alpha * a + beta_b * b   (times the upstream g[e])
+__global__ __launch_bounds__(256) void edge_coef_kernel(const float* __restrict__ g, const float* __restrict__ sim,
+                                                        const float* __restrict__ aux, int64_t E, int kernel,
+                                                        float* __restrict__ alpha, float* __restrict__ beta_a,
+                                                        float* __restrict__ beta_b) {
+  for (int64_t e = blockIdx.x * 256LL + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
+    const float ge = g[e];
+    float al, ba, bb;
+    if (kernel <= K_POLY) {
+      const float dot = aux[3 * e], na2 = aux[3 * e + 1], nb2 = aux[3 * e + 2];
+      const float den = sqrtf(fmaxf(na2 * nb2, kCosEps * kCosEps));
+      const float c = dot / den;
+      const float gg = kernel == K_COSINE ? ge : ge * 2.f * c;
+      const bool clamped = na2 * nb2 <= kCosEps * kCosEps;
+      al = gg / den;
+      ba = clamped ? 0.f : -gg * c / na2;
+      bb = clamped ? 0.f : -gg * c / nb2;
+    } else if (kernel == K_L2) {
+      const float d = sim[e];
+      const float q = d > 0.f ? ge / d : 0.f;
+      al = -q; ba = q; bb = q;
+    } else {
+      const float q = ge * sim[e];
+      al = q; ba = -q; bb = -q;
+    }
+    alpha[e] = al; beta_a[e] = ba; beta_b[e] = bb;
+  }
+}
+
+__global__ __launch_bounds__(256) void seg_softmax_fwd_kernel(const int64_t* __restrict__ ptr, const float* __restrict__ x,
+                                                              int64_t n_seg, float* __restrict__ p) {
+  const int lane = egnn_lane();
+  for (int64_t s = blockIdx.x * 4LL + egnn_wave_id(); s < n_seg; s += (int64_t)gridDim.x * 4) {
+    const int64_t b = ptr[s], e = ptr[s + 1];
+    if (b == e) continue;
+    float m = -INFINITY;
+    for (int64_t i = b + lane; i < e; i += 64) m = fmaxf(m, x[i]);
+    m = egnn_wave_max(m);
+    float z = 0.f;
+    for (int64_t i = b + lane; i < e; i += 64) z += expf(x[i] - m);
+    z = egnn_wave_sum(z);
+    const float inv = 1.f / (z + 1e-16f);  // PyG: out / (sum + 1e-16)
+    for (int64_t i = b + lane; i < e; i += 64) p[i] = expf(x[i] - m) * inv;
+  }
+}
+
+// gx = p * (gp - sum_seg p * gp)
+__global__ __launch_bounds__(256) void seg_softmax_bwd_kernel(const int64_t* __restrict__ ptr, const float* __restrict__ p,
+                                                              const float* __restrict__ gp, int64_t n_seg,
+                                                              float* __restrict__ gx) {
+  const int lane = egnn_lane();
+  for (int64_t s = blockIdx.x * 4LL + egnn_wave_id(); s < n_seg; s += (int64_t)gridDim.x * 4) {
+    const int64_t b = ptr[s], e = ptr[s + 1];
+    float d = 0.f;
+    for (int64_t i = b + lane; i < e; i += 64) d = fmaf(p[i], gp[i], d);
+    d = egnn_wave_sum(d);
+    for (int64_t i = b + lane; i < e; i += 64) gx[i] = p[i] * (gp[i] - d);
+  }
+}
+
+__global__ __launch_bounds__(256) void seg_sum_kernel(const int64_t* __restrict__ ptr, const float* __restrict__ x,
+                                                      int64_t n_seg, float* __restrict__ out) {
+  const int lane = egnn_lane();
+  for (int64_t s = blockIdx.x * 4LL + egnn_wave_id(); s < n_seg; s += (int64_t)gridDim.x * 4) {
+    const int64_t b = ptr[s], e = ptr[s + 1];
+    float d = 0.f;
+    for (int64_t i = b + lane; i < e; i += 64) d += x[i];
+    d = egnn_wave_sum(d);
+    if (lane == 0) out[s] = d;
+  }
+}
+
+inline unsigned wave_grid(int64_t n) {
+  const int64_t b = (n + 3) / 4;
+  return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace
+
+extern "C" int egnn_edge_sim_f32(const float* F, int64_t ld, int64_t D, const int64_t* idx_a, const int64_t* idx_b, int64_t E,
+                                 int kernel, float* sim, float* aux3, void* stream) {
+  EGNN_CHECK_ARG(E >= 0 && D > 0 && ld >= D && kernel >= 0 && kernel <= 3);
+  if (E == 0) return EGNN_OK;
+  EGNN_CHECK_ARG(F && idx_a && idx_b && sim && aux3);
+  const bool vec4 = (D % 4 == 0) && (ld % 4 == 0) && egnn_aligned16(F);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec4) hipLaunchKernelGGL(edge_sim_kernel<true>, dim3(wave_grid(E)), dim3(256), 0, st, F, ld, D, idx_a, idx_b, E, kernel, sim, aux3);
+  else hipLaunchKernelGGL(edge_sim_kernel<false>, dim3(wave_grid(E)), dim3(256), 0, st, F, ld, D, idx_a, idx_b, E, kernel, sim, aux3);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_edge_sim_coef_f32(const float* g, const float* sim, const float* aux3, int64_t E, int kernel,
+                                      float* alpha, float* beta_a, float* beta_b, void* stream) {
+  EGNN_CHECK_ARG(E >= 0 && kernel >= 0 && kernel <= 3);
+  if (E == 0) return EGNN_OK;
+  EGNN_CHECK_ARG(g && sim && aux3 && alpha && beta_a && beta_b);
+  const int64_t blocks = (E + 255) / 256;
+  hipLaunchKernelGGL(edge_coef_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, g, sim,
+                     aux3, E, kernel, alpha, beta_a, beta_b);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_segment_softmax_fwd_f32(const int64_t* seg_ptr, const float* x, int64_t n_seg, float* p, void* stream) {
+  EGNN_CHECK_ARG(n_seg >= 0);
+  if (n_seg == 0) return EGNN_OK;
+  EGNN_CHECK_ARG(seg_ptr && x && p);
+  hipLaunchKernelGGL(seg_softmax_fwd_kernel, dim3(wave_grid(n_seg)), dim3(256), 0, (hipStream_t)stream, seg_ptr, x, n_seg, p);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_segment_softmax_bwd_f32(const int64_t* seg_ptr, const float* p, const float* gp, int64_t n_seg, float* gx,
+                                            void* stream) {
+  EGNN_CHECK_ARG(n_seg >= 0);
+  if (n_seg == 0) return EGNN_OK;
+  EGNN_CHECK_ARG(seg_ptr && p && gp && gx);
+  hipLaunchKernelGGL(seg_softmax_bwd_kernel, dim3(wave_grid(n_seg)), dim3(256), 0, (hipStream_t)stream, seg_ptr, p, gp, n_seg, gx);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_segment_sum_f32(const int64_t* seg_ptr, const float* x, int64_t n_seg, float* out, void* stream) {
+  EGNN_CHECK_ARG(n_seg >= 0);
+  if (n_seg == 0) return EGNN_OK;
+  EGNN_CHECK_ARG(seg_ptr && x && out);
+  hipLaunchKernelGGL(seg_sum_kernel, dim3(wave_grid(n_seg)), dim3(256), 0, (hipStream_t)stream, seg_ptr, x, n_seg, out);
+  return egnn_launch_status();
+}

@@ -405,7 +405,9 @@ int launch(SpmmArgs<IdxT> a, const RowPlan& plan, hipStream_t st) {
       const int teams = a.map_mode == 1 ? a.NS : (a.map_mode == 2 ? 8 : 1);
       int64_t blocks = (n_groups + 3) / 4 * teams;
       blocks = (blocks + 7) / 8 * 8;
-      if (blocks > 2048) blocks = 2048;
+      // one row group per wave: a static stride over length-sorted chunks would give some waves only the
+      // heavy groups; let the hardware dispatcher balance instead (the in-kernel loop then runs once)
+      if (blocks > 0x7ffffff8LL) blocks = 0x7ffffff8LL;
       if (a.logG == 3) hipLaunchKernelGGL((spmm_short_rows_kernel<IdxT, 3>), dim3((unsigned)blocks), dim3(256), 0, st, s);
       else hipLaunchKernelGGL((spmm_short_rows_kernel<IdxT, 4>), dim3((unsigned)blocks), dim3(256), 0, st, s);
       short_done = true;

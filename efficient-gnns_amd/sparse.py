@@ -19,9 +19,11 @@ from torch import Tensor
 
 from . import _lib
 
-SHORT_ROW_MAX = 64        # entries; rows up to this length share a wavefront (one G-lane sub-group each)
-LONG_ROW_THRESHOLD = 512  # entries; rows above it are reduced by a 16-wave workgroup
-PLAN_CHUNK = 2048         # short rows are length-sorted inside chunks of this many consecutive rows
+import os
+
+SHORT_ROW_MAX = int(os.environ.get("EGNN_SHORT_ROW_MAX", "64"))    # rows up to this length share a wavefront
+LONG_ROW_THRESHOLD = int(os.environ.get("EGNN_LONG_ROW_MIN", "512"))  # rows above it get a 16-wave workgroup
+PLAN_CHUNK = int(os.environ.get("EGNN_PLAN_CHUNK", "2048"))        # short rows are length-sorted inside such chunks
 
 
 def _ind2ptr(row: Tensor, n_rows: int) -> Tensor:

@@ -202,6 +202,25 @@ int egnn_bce_pair_fwd_f32(const float* logits, const float* labels, const float*
 int egnn_bce_pair_bwd_f32(const float* logits, const float* labels, const float* teacher, int64_t total,
                           const float* g_cls, const float* g_kd, float* dlogits, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * LSP building blocks, /root/reference/arxiv_pyg/criterion.py:95-126 (K5/K6 in SURVEY.md 2.2)
+ * ---------------------------------------------------------------------------------------------- */
+/* Per-edge similarity of rows a = F[idx_a[e]], b = F[idx_b[e]] (never materialising feat[src] / feat[dst]):
+ *   EGNN_K_COSINE  <a,b> / sqrt(max(|a|^2 |b|^2, 1e-16))   (F.cosine_similarity, criterion.py:103)
+ *   EGNN_K_POLY    cosine^2 (:106)      EGNN_K_L2  ||a-b||_2 (:109)      EGNN_K_RBF  exp(-||a-b||^2 / 2) (:112)
+ * aux3 [E,3] keeps (dot,|a|^2,|b|^2) or (||a-b||^2,0,0) for the backward. */
+int egnn_edge_sim_f32(const float* F, int64_t ld, int64_t D, const int64_t* idx_a, const int64_t* idx_b, int64_t E,
+                      int kernel, float* sim, float* aux3, void* stream);
+/* Backward coefficients: with g = dL/dsim,  dL/dF[a] += alpha*b + beta_a*a  and  dL/dF[b] += alpha*a + beta_b*b per edge;
+ * the caller turns them into two egnn_spmm_csr_f32 calls (values = alpha) plus a per-row scale (segment sums of beta). */
+int egnn_edge_sim_coef_f32(const float* g, const float* sim, const float* aux3, int64_t E, int kernel,
+                           float* alpha, float* beta_a, float* beta_b, void* stream);
+/* torch_geometric.utils.softmax over CSR segments: p = exp(x - max_seg) / (sum_seg + 1e-16); x, p in segment
+ * order (seg_ptr [n_seg+1]).  bwd: gx = p * (gp - sum_seg p*gp).  No atomics, fixed order. */
+int egnn_segment_softmax_fwd_f32(const int64_t* seg_ptr, const float* x, int64_t n_seg, float* p, void* stream);
+int egnn_segment_softmax_bwd_f32(const int64_t* seg_ptr, const float* p, const float* gp, int64_t n_seg, float* gx, void* stream);
+int egnn_segment_sum_f32(const int64_t* seg_ptr, const float* x, int64_t n_seg, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -451,3 +451,85 @@ def test_train_and_eval_match_reference_goldens(golden_train):
         except AssertionError as ex:
             failures.append(f"{name}: {str(ex)[:400]}")
     assert not failures, "\n".join(failures)
+
+
+# ------------------------------------------------------------------------------------------------
+# LSP / GSP building blocks at larger sizes than the goldens
+# ------------------------------------------------------------------------------------------------
+def test_segment_softmax_unsorted_index_vs_oracle():
+    g = torch.Generator().manual_seed(0)
+    E_, n = 5000, 300
+    src = (torch.randn(E_, generator=g) * 3).requires_grad_(True)
+    index = torch.randint(0, n, (E_,), generator=g)
+    index[:900] = 7  # one long segment (> 64 entries), some empty segments exist too
+    ref = OU.softmax(src, index, n)
+    sp = src.detach().to(DEV).requires_grad_(True)
+    out = E.softmax(sp, index.to(DEV), num_nodes=n)
+    close(out, ref, rtol=1e-5, atol_scale=1e-6)
+    w = torch.randn(E_, generator=g)
+    (ref * w).sum().backward()
+    (out * w.to(DEV)).sum().backward()
+    close(sp.grad, src.grad, rtol=1e-4, atol_scale=1e-5)
+
+
+@pytest.mark.parametrize("kernel", ["cosine", "poly", "l2", "rbf"])
+@pytest.mark.parametrize("crit", ["kld", "mse"])
+def test_lsp_vs_oracle_on_train_subgraph(kernel, crit):
+    d = D.arxiv_like(scale=0.02, seed=5)
+    tr = d.split_idx["train"]
+    ei = OU.subgraph(tr, torch.stack(d.adj_t.coo()[:2]), relabel_nodes=True, num_nodes=d.num_nodes)[0]
+    g = torch.Generator().manual_seed(1)
+    n_tr = tr.numel()
+    scale = 0.15 if kernel in ("l2", "rbf") else 1.0   # keep rbf similarities away from exp underflow
+    f = (torch.relu(torch.randn(n_tr, 256, generator=g)) * scale)
+    t = (torch.relu(torch.randn(n_tr, 750, generator=g)) * scale * 0.6)
+    logits, labels = torch.randn(n_tr, 40, generator=g), torch.randint(0, 40, (n_tr,), generator=g)
+    fo, to_ = f.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    fp, tp = f.to(DEV).requires_grad_(True), t.to(DEV).requires_grad_(True)
+    ref = OC.lpw_criterion(logits, labels, fo, to_, ei, kernel, 100, crit)
+    out = E.lpw_criterion(logits.to(DEV), labels.to(DEV), fp, tp, ei.to(DEV), kernel, 100, crit)
+    close(out[2], ref[2], rtol=5e-5, atol_scale=0, msg="loss_lpw")
+    ref[2].backward()
+    out[2].backward()
+    close(fp.grad, fo.grad, rtol=2e-4, atol_scale=2e-5)
+    close(tp.grad, to_.grad, rtol=2e-4, atol_scale=2e-5)
+
+
+@pytest.mark.parametrize("kernel,S,P", [("cosine", 1000, 128), ("poly", 777, 128), ("l2", 600, 64), ("rbf", 900, 128), ("cosine", 4096, 128)])
+def test_gsp_vs_oracle(kernel, S, P):
+    g = torch.Generator().manual_seed(S)
+    n = S + 500
+    scale = 0.12 if kernel in ("l2", "rbf") else 1.0
+    f = torch.relu(torch.randn(n, P, generator=g)) * scale
+    t = torch.relu(torch.randn(n, P, generator=g) + 0.2 * f) * scale
+    logits, labels = torch.randn(n, 5, generator=g), torch.randint(0, 5, (n,), generator=g)
+    fo, to_ = f.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    fp, tp = f.to(DEV).requires_grad_(True), t.to(DEV).requires_grad_(True)
+    np.random.seed(S)
+    ref = OC.gpw_criterion(logits, labels, fo, to_, kernel, 1.0, S)
+    np.random.seed(S)
+    out = E.gpw_criterion(logits.to(DEV), labels.to(DEV), fp, tp, kernel, 1.0, S)
+    close(out[2], ref[2], rtol=1e-4, atol_scale=0, msg="loss_gpw")
+    ref[2].backward()
+    out[2].backward()
+    close(fp.grad, fo.grad, rtol=5e-4, atol_scale=1e-4)
+    close(tp.grad, to_.grad, rtol=5e-4, atol_scale=1e-4)
+
+
+def test_gsp_stress_all_pairs_beyond_reference_capacity():
+    """S = 16384 with the rbf kernel: the reference would need a [S,S,P] fp32 tensor (137 GB at P=128)."""
+    S, P = 16384, 128
+    g = torch.Generator(device=DEV).manual_seed(0)
+    f = torch.randn(S, P, device=DEV, generator=g) * 0.1
+    from efficient_gnns_amd.ops_pairwise import gsp_loss
+    same = gsp_loss(f, f.clone(), None, "rbf")
+    assert float(same) == 0.0, "identical student and teacher => exactly zero loss"
+    t = f + 0.01 * torch.randn(S, P, device=DEV, generator=g)
+    rows = torch.arange(0, S, 1237, device=DEV)
+    l = gsp_loss(f, t, None, "rbf")
+
+    def k(x):
+        d2 = (x[rows].double().unsqueeze(1) - x.double().unsqueeze(0)).pow(2).sum(-1)
+        return torch.exp(-0.5 * d2)
+    est = (k(f) - k(t)).pow(2).mean()
+    assert abs(float(l) - float(est)) < 0.2 * float(est) + 1e-12  # row-sample estimate of the same mean

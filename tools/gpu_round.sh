@@ -1,14 +1,16 @@
 #!/bin/bash
-# One GPU-box session: smoke, GPU parity tests, kernel microbench, bench line, rocprof kernel stats.
+# One GPU-box session. Usage: bash tools/gpu_round.sh [stages...]   (default: all)
 set +e
 export TMPDIR=/tmp
-mkdir -p gpurun_out
-echo "== smoke"; timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/smoke.log
-echo "== pytest -m gpu"; timeout 1200 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -40 gpurun_out/pytest_gpu.log | cut -c1-300
-echo "== kernel bench"; timeout 900 python tools/kernel_bench.py > gpurun_out/kernel_bench.log 2>&1; echo "kb rc=$?"; tail -40 gpurun_out/kernel_bench.log | cut -c1-400
-echo "== bench"; timeout 900 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -5 gpurun_out/bench.log | cut -c1-3000
-echo "== bench blas"; EGNN_GEMM=blas timeout 600 python bench.py --steps 20 --warmup 3 --cpu-epochs 0 > gpurun_out/bench_blas.log 2>&1; echo "bench rc=$?"; tail -2 gpurun_out/bench_blas.log | cut -c1-3000
-echo "== rocprof"; cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --cpu-epochs 0 > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1; echo "rocprof rc=$?"; cd $GRAFT_REPO_ROOT
-find gpurun_out/prof -name "*stats*" | head; for f in $(find gpurun_out/prof -name "*kernel_stats*.csv" | head -1); do head -25 $f | cut -c1-200; done
-# keep the merge-back small: drop the raw trace, keep stats
-find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p $R/gpurun_out
+STAGES=${@:-smoke tests kbench bench rocprof}
+for s in $STAGES; do case $s in
+smoke) echo "== smoke"; timeout 600 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log | cut -c1-400;;
+tests) echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -q -rfE --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -60 gpurun_out/pytest_gpu.log | cut -c1-400;;
+kbench) echo "== kernel bench"; timeout 900 python tools/kernel_bench.py $KBENCH_ARGS > gpurun_out/kernel_bench.log 2>&1; echo "kb rc=$?"; grep -v Warn gpurun_out/kernel_bench.log | tail -45 | cut -c1-400;;
+bench) echo "== bench"; timeout 900 python bench.py --steps 20 --warmup 3 $BENCH_ARGS > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench.log | cut -c1-3000;;
+rocprof) echo "== rocprof"; rm -rf /tmp/prof; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o r01 -- python $R/bench.py --steps 10 --warmup 2 --cpu-epochs 0 > $R/gpurun_out/rocprof.log 2>&1); echo "rocprof rc=$?";
+   mkdir -p gpurun_out/prof; find /tmp/prof -name "*stats*" -exec cp {} gpurun_out/prof/ \; ; ls gpurun_out/prof; for f in $(ls gpurun_out/prof/*kernel_stats*.csv 2>/dev/null | head -1); do head -40 $f | cut -c1-220; done;;
+esac; done
+du -sh gpurun_out

@@ -46,7 +46,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "kernel_bench.jsonl"))
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="", help="comma list of sections: spmm,gemm,nce,misc")
     args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    want = lambda sec: not only or sec in only  # noqa: E731
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     f = open(args.out, "w")
     emit(f, what="device", name=torch.cuda.get_device_name(0), lib=E._lib.build_info())
@@ -56,7 +59,7 @@ def main():
     gn = E.gcn_norm(adj)
     n = data.num_nodes
     # ---- SpMM ------------------------------------------------------------------------------------
-    for K in (256, 128, 40):
+    for K in ((256, 128, 40) if want('spmm') else ()):
         x = torch.randn(n, K, device=DEV)
         for label, a, kw in (("gcn_sum_val", gn, {}), ("sage_mean", adj, {"reduce": "mean"}),
                              ("gcn_sum_val_noplan", gn, {"use_plan": False})):
@@ -71,6 +74,8 @@ def main():
         emit(f, what="spmm", variant="gcn_sum_val_int64", K=K, us=round(t * 1e6, 2))
     # torch baseline for the same op (rocSPARSE via torch.sparse) for context
     try:
+        if not want('spmm') or args.quick:
+            raise RuntimeError('skipped')
         csr = torch.sparse_csr_tensor(gn.csr()[0], gn.csr()[1], gn.csr()[2], size=(n, n))
         x = torch.randn(n, 256, device=DEV)
         t = timeit(lambda: torch.sparse.mm(csr, x), iters=5, warmup=1)
@@ -89,7 +94,7 @@ def main():
     shapes = [("xW1 NN", n, 256, 128, False, False), ("xW2 NN", n, 256, 256, False, False), ("xW3 NN", n, 40, 256, False, False),
               ("proj_s NT", n_tr, 256, 256, False, True), ("proj_t NT", n_tr, 256, 750, False, True),
               ("dX NT", n, 256, 256, False, True), ("dW TN", 256, 256, n, True, False), ("dWt TN", 256, 750, n_tr, True, False)]
-    for label, M, N, K, ta, tb in shapes:
+    for label, M, N, K, ta, tb in (shapes if want('gemm') else ()):
         a = torch.randn((K, M) if ta else (M, K), device=DEV)
         b = torch.randn((N, K) if tb else (K, N), device=DEV)
         flops = 2.0 * M * N * K
@@ -99,7 +104,7 @@ def main():
              blas_us=round(t2 * 1e6, 1), blas_TF=round(flops / t2 / 1e12, 1))
 
     # ---- G-CRD ----------------------------------------------------------------------------------------
-    for S in ((8192,) if args.quick else (8192, 16384)):
+    for S in (() if not want('nce') else ((8192,) if args.quick else (8192, 16384))):
         P = 256
         fh = torch.nn.functional.normalize(torch.randn(S, P, device=DEV), dim=-1)
         th = torch.nn.functional.normalize(torch.randn(S, P, device=DEV), dim=-1)
@@ -122,6 +127,9 @@ def main():
              fwd_bwd_TF=round(3 * fl / t_fb / 1e12, 1), torch_fwd_bwd_us=round(t_t * 1e6, 1))
 
     # ---- elementwise neighbours of the convs (next row f-1), torch ops today -----------------------------
+    if not want('misc'):
+        f.close()
+        return
     h = torch.randn(n, 256, device=DEV, requires_grad=True)
     bn = torch.nn.BatchNorm1d(256).to(DEV)
     t = timeit(lambda: torch.nn.functional.dropout(torch.relu(bn(h)), 0.5, True), iters=10)
