@@ -23,7 +23,7 @@ import os
 
 SHORT_ROW_MAX = int(os.environ.get("EGNN_SHORT_ROW_MAX", "64"))    # rows up to this length share a wavefront
 LONG_ROW_THRESHOLD = int(os.environ.get("EGNN_LONG_ROW_MIN", "512"))  # rows above it get a 16-wave workgroup
-PLAN_CHUNK = int(os.environ.get("EGNN_PLAN_CHUNK", "2048"))        # short rows are length-sorted inside such chunks
+PLAN_CHUNK = int(os.environ.get("EGNN_PLAN_CHUNK", "1"))  # >1: length-sort short rows inside chunks of this many rows (measured slower: locality wins)
 
 
 def _ind2ptr(row: Tensor, n_rows: int) -> Tensor:
