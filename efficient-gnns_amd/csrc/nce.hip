@@ -27,8 +27,9 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float om, float os
 }
 
 template <bool VEC4>
-__global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ fhat, const float* __restrict__ that,
-                                                      int64_t S, int64_t P, int64_t ld, float inv_tau,
+__global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ fhat, int64_t ldf,
+                                                      const float* __restrict__ that, int64_t ldt, int64_t Sr, int64_t Sc,
+                                                      int64_t diag_off, int64_t P, float inv_tau,
                                                       float* __restrict__ Z, float* __restrict__ zdiag,
                                                       float* __restrict__ pm, float* __restrict__ ps, int nsplit,
                                                       int cb_per_split) {
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t i0 = (int64_t)blockIdx.x * FB;
   const int split = blockIdx.y;
-  const int64_t ncb = (S + FB - 1) / FB;
+  const int64_t ncb = (Sc + FB - 1) / FB;
   const int64_t cb0 = (int64_t)split * cb_per_split;
   int64_t cb1 = cb0 + cb_per_split;
   if (cb1 > ncb) cb1 = ncb;
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
     const int64_t j0 = cb * FB;
     f32x16 acc[TS::TM][TS::TN];
     zero_acc(acc);
-    mainloop<FB, FB, KMAJOR, KMAJOR, VEC4>(acc, fhat, ld, i0, S, that, ld, j0, S, 0, P, id, id, smem);
+    mainloop<FB, FB, KMAJOR, KMAJOR, VEC4>(acc, fhat, ldf, i0, Sr, that, ldt, j0, Sc, 0, P, id, id, smem);
 #pragma unroll
     for (int tm = 0; tm < TS::TM; ++tm) {
 #pragma unroll
@@ -67,10 +68,10 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
         for (int tn = 0; tn < TS::TN; ++tn) {
           const int64_t c = j0 + acc_col<FB, FB>(wn, tn, lane);
           const float z = acc[tm][tn][r] * inv_tau;
-          const bool ok = row < S && c < S;
+          const bool ok = row < Sr && c < Sc;
           if (ok) {
-            if (Z) Z[row * S + c] = z;
-            if (row == c) zdiag[row] = z;
+            if (Z) Z[row * Sc + c] = z;
+            if (row + diag_off == c) zdiag[row] = z;
           }
           zt[tn] = ok ? z : -INFINITY;
           mt = fmaxf(mt, zt[tn]);
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
   __syncthreads();
   if (threadIdx.x < FB) {
     const int64_t row = i0 + threadIdx.x;
-    if (row < S) {
+    if (row < Sr) {
       float m = lm[threadIdx.x], s = lsum[threadIdx.x];
       lse_merge(m, s, lm[FB + threadIdx.x], lsum[FB + threadIdx.x]);
       pm[row * nsplit + split] = m;
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(1024) void nce_finalize_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
                                                             const float* __restrict__ zdiag, int64_t S, int nsplit,
-                                                            float* __restrict__ lse, float* __restrict__ loss) {
+                                                            float inv_count, float* __restrict__ lse,
+                                                            float* __restrict__ loss) {
   __shared__ float red[1024];
   float local = 0.f;
   for (int64_t row = threadIdx.x; row < S; row += 1024) {
@@ -138,22 +140,25 @@ __global__ __launch_bounds__(1024) void nce_finalize_kernel(const float* __restr
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) loss[0] = red[0] / (float)S;
+  if (threadIdx.x == 0) loss[0] = red[0] * inv_count;
 }
 
 // A-operand transform of the backward GEMMs: z -> exp(z - lse[i]) - [i == j]
 struct NceGradXf {
   const float* lse;
-  int lse_by_k;  // 0: i = gemm row (A = Z, k-major);  1: i = gemm k (A = Z^T, stored [k][m])
+  int lse_by_k;      // 0: i = gemm row (A = Z, k-major);  1: i = gemm k (A = Z^T, stored [k][m])
+  int64_t diag_off;  // the positive of Z row i sits in column i + diag_off
   __device__ __forceinline__ float operator()(float v, int64_t r, int64_t k) const {
     const int64_t i = lse_by_k ? k : r;
-    return expf(v - lse[i]) - (r == k ? 1.f : 0.f);
+    const int64_t j = lse_by_k ? r : k;
+    return expf(v - lse[i]) - (i + diag_off == j ? 1.f : 0.f);
   }
 };
 
-// C[M=S, N=P] = scale * xf(Z or Z^T) [S,S] * B[S,P]   (B row-major, n contiguous)
+// C[M, N=P] = scale * xf(Z or Z^T) [M,Kd] * B[Kd,P]   (B row-major, n contiguous; Z is [Sr,Sc], ld = Sc)
 template <int BM, int AMAJ, bool VEC4>
-__global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ Z, int64_t S, const float* __restrict__ lse,
+__global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ Z, int64_t ldz, int64_t M, int64_t Kd,
+                                                      int64_t diag_off, const float* __restrict__ lse,
                                                       const float* __restrict__ Bm, int64_t P, int64_t ldb,
                                                       float coef, const float* __restrict__ g, float* __restrict__ C,
                                                       int64_t ldc) {
@@ -165,9 +170,9 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ 
   const int64_t n0 = (blockIdx.x % tiles_n) * BN;
   f32x16 acc[TS::TM][TS::TN];
   zero_acc(acc);
-  NceGradXf xf{lse, AMAJ == MNMAJOR};
+  NceGradXf xf{lse, AMAJ == MNMAJOR, diag_off};
   IdentityXf id;
-  mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, S, m0, S, Bm, ldb, n0, P, 0, S, xf, id, smem);
+  mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, 0, Kd, xf, id, smem);
   const int lane = egnn_lane();
   const int wave = egnn_wave_id();
   const int wm = wave >> 1, wn = wave & 1;
@@ -181,23 +186,23 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + acc_row<BM, BN>(wm, tm, r, lane);
-        if (row < S) C[row * ldc + c] = scale * acc[tm][tn][r];
+        if (row < M) C[row * ldc + c] = scale * acc[tm][tn][r];
       }
   }
 }
 
 template <int AMAJ>
-void launch_bwd(const float* Z, int64_t S, const float* lse, const float* Bm, int64_t P, int64_t ld, float coef,
-                const float* g, float* C, bool vec4, hipStream_t st) {
+void launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag_off, const float* lse, const float* Bm,
+                int64_t P, int64_t ldb, float coef, const float* g, float* C, int64_t ldc, bool vec4, hipStream_t st) {
   const int64_t tiles_n = (P + 127) / 128;
-  const int64_t t128 = ((S + 127) / 128) * tiles_n;
+  const int64_t t128 = ((M + 127) / 128) * tiles_n;
   if (t128 >= 200) {
-    if (vec4) hipLaunchKernelGGL((nce_bwd_kernel<128, AMAJ, true>), dim3((unsigned)t128), dim3(256), 0, st, Z, S, lse, Bm, P, ld, coef, g, C, ld);
-    else hipLaunchKernelGGL((nce_bwd_kernel<128, AMAJ, false>), dim3((unsigned)t128), dim3(256), 0, st, Z, S, lse, Bm, P, ld, coef, g, C, ld);
+    if (vec4) hipLaunchKernelGGL((nce_bwd_kernel<128, AMAJ, true>), dim3((unsigned)t128), dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, Bm, P, ldb, coef, g, C, ldc);
+    else hipLaunchKernelGGL((nce_bwd_kernel<128, AMAJ, false>), dim3((unsigned)t128), dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, Bm, P, ldb, coef, g, C, ldc);
   } else {  // fewer than ~one block per CU: halve the row tile
-    const int64_t t64 = ((S + 63) / 64) * tiles_n;
-    if (vec4) hipLaunchKernelGGL((nce_bwd_kernel<64, AMAJ, true>), dim3((unsigned)t64), dim3(256), 0, st, Z, S, lse, Bm, P, ld, coef, g, C, ld);
-    else hipLaunchKernelGGL((nce_bwd_kernel<64, AMAJ, false>), dim3((unsigned)t64), dim3(256), 0, st, Z, S, lse, Bm, P, ld, coef, g, C, ld);
+    const int64_t t64 = ((M + 63) / 64) * tiles_n;
+    if (vec4) hipLaunchKernelGGL((nce_bwd_kernel<64, AMAJ, true>), dim3((unsigned)t64), dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, Bm, P, ldb, coef, g, C, ldc);
+    else hipLaunchKernelGGL((nce_bwd_kernel<64, AMAJ, false>), dim3((unsigned)t64), dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, Bm, P, ldb, coef, g, C, ldc);
   }
 }
 
@@ -205,37 +210,53 @@ void launch_bwd(const float* Z, int64_t S, const float* lse, const float* Bm, in
 
 extern "C" size_t egnn_nce_ws_floats(int64_t S) { return (size_t)S * (1 + 2 * kMaxSplit); }
 
-extern "C" int egnn_nce_fwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,
-                                float* Z, float* lse, float* loss, float* ws, size_t ws_floats, void* stream) {
-  EGNN_CHECK_ARG(S > 0 && P > 0 && ld >= P && tau > 0.f && fhat && that && lse && loss && ws);
-  if (ws_floats < egnn_nce_ws_floats(S)) return EGNN_EWORKSPACE;
+extern "C" int egnn_nce_block_fwd_f32(const float* fhat, int64_t ld_f, const float* that, int64_t ld_t, int64_t Sr, int64_t Sc,
+                                      int64_t diag_off, int64_t P, float tau, float inv_count, float* Z, float* lse,
+                                      float* loss, float* ws, size_t ws_floats, void* stream) {
+  EGNN_CHECK_ARG(Sr > 0 && Sc > 0 && P > 0 && ld_f >= P && ld_t >= P && tau > 0.f && fhat && that && lse && loss && ws);
+  EGNN_CHECK_ARG(diag_off >= 0 && diag_off + Sr <= Sc);
+  if (ws_floats < egnn_nce_ws_floats(Sr)) return EGNN_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t rb = (S + FB - 1) / FB;
+  const int64_t rb = (Sr + FB - 1) / FB;
+  const int64_t ncb = (Sc + FB - 1) / FB;
   int nsplit = (int)((512 + rb - 1) / rb);
   if (nsplit > kMaxSplit) nsplit = kMaxSplit;
-  if (nsplit > rb) nsplit = (int)rb;
+  if (nsplit > ncb) nsplit = (int)ncb;
   if (nsplit < 1) nsplit = 1;
-  const int cb_per_split = (int)((rb + nsplit - 1) / nsplit);
-  nsplit = (int)((rb + cb_per_split - 1) / cb_per_split);  // no empty splits
+  const int cb_per_split = (int)((ncb + nsplit - 1) / nsplit);
+  nsplit = (int)((ncb + cb_per_split - 1) / cb_per_split);  // no empty splits
   float* zdiag = ws;
-  float* pm = ws + S;
-  float* ps = pm + S * kMaxSplit;
-  const bool vec4 = (ld % 4 == 0) && egnn_aligned16(fhat) && egnn_aligned16(that);
+  float* pm = ws + Sr;
+  float* ps = pm + Sr * kMaxSplit;
+  const bool vec4 = (ld_f % 4 == 0) && (ld_t % 4 == 0) && egnn_aligned16(fhat) && egnn_aligned16(that);
   dim3 grid((unsigned)rb, (unsigned)nsplit);
-  if (vec4) hipLaunchKernelGGL(nce_fwd_kernel<true>, grid, dim3(256), 0, st, fhat, that, S, P, ld, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split);
-  else hipLaunchKernelGGL(nce_fwd_kernel<false>, grid, dim3(256), 0, st, fhat, that, S, P, ld, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split);
-  hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(1024), 0, st, pm, ps, zdiag, S, nsplit, lse, loss);
+  if (vec4) hipLaunchKernelGGL(nce_fwd_kernel<true>, grid, dim3(256), 0, st, fhat, ld_f, that, ld_t, Sr, Sc, diag_off, P, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split);
+  else hipLaunchKernelGGL(nce_fwd_kernel<false>, grid, dim3(256), 0, st, fhat, ld_f, that, ld_t, Sr, Sc, diag_off, P, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split);
+  hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(1024), 0, st, pm, ps, zdiag, Sr, nsplit, inv_count, lse, loss);
   return egnn_launch_status();
+}
+
+extern "C" int egnn_nce_block_bwd_f32(const float* fhat, int64_t ld_f, const float* that, int64_t ld_t, int64_t Sr, int64_t Sc,
+                                      int64_t diag_off, int64_t P, float scale, const float* Z, const float* lse, const float* g,
+                                      float* dfhat, int64_t ld_df, float* dthat, int64_t ld_dt, void* stream) {
+  EGNN_CHECK_ARG(Sr > 0 && Sc > 0 && P > 0 && ld_f >= P && ld_t >= P && fhat && that && Z && lse);
+  EGNN_CHECK_ARG((dfhat == nullptr || ld_df >= P) && (dthat == nullptr || ld_dt >= P));
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec4 = (ld_f % 4 == 0) && (ld_t % 4 == 0) && (Sc % 4 == 0) && egnn_aligned16(fhat) && egnn_aligned16(that) && egnn_aligned16(Z);
+  // dfhat [Sr,P] = scale g (P - I) that ;  dthat [Sc,P] = scale g (P - I)^T fhat
+  if (dfhat) launch_bwd<KMAJOR>(Z, Sc, Sr, Sc, diag_off, lse, that, P, ld_t, scale, g, dfhat, ld_df, vec4, st);
+  if (dthat) launch_bwd<MNMAJOR>(Z, Sc, Sc, Sr, diag_off, lse, fhat, P, ld_f, scale, g, dthat, ld_dt, vec4, st);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_nce_fwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,
+                                float* Z, float* lse, float* loss, float* ws, size_t ws_floats, void* stream) {
+  return egnn_nce_block_fwd_f32(fhat, ld, that, ld, S, S, 0, P, tau, S > 0 ? 1.f / (float)S : 0.f, Z, lse, loss, ws, ws_floats, stream);
 }
 
 extern "C" int egnn_nce_bwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,
                                 const float* Z, const float* lse, const float* g, float* dfhat, float* dthat,
                                 void* stream) {
-  EGNN_CHECK_ARG(S > 0 && P > 0 && ld >= P && tau > 0.f && fhat && that && Z && lse);
-  hipStream_t st = (hipStream_t)stream;
-  const float coef = 1.f / ((float)S * tau);
-  const bool vec4 = (ld % 4 == 0) && (S % 4 == 0) && egnn_aligned16(fhat) && egnn_aligned16(that) && egnn_aligned16(Z);
-  if (dfhat) launch_bwd<KMAJOR>(Z, S, lse, that, P, ld, coef, g, dfhat, vec4, st);
-  if (dthat) launch_bwd<MNMAJOR>(Z, S, lse, fhat, P, ld, coef, g, dthat, vec4, st);
-  return egnn_launch_status();
+  EGNN_CHECK_ARG(S > 0 && tau > 0.f);
+  return egnn_nce_block_bwd_f32(fhat, ld, that, ld, S, S, 0, P, 1.f / ((float)S * tau), Z, lse, g, dfhat, ld, dthat, ld, stream);
 }

@@ -1,0 +1,469 @@
+"""Node-range sharded full-graph training over RCCL / xGMI.
+
+The reference has no multi-GPU code (replicas with different seeds only, run_gcn.sh:24-27).  Here rank r owns the
+contiguous node range [lo_r, hi_r): its rows of the adjacency, of every activation, of the labels and of the
+teacher artefacts.  One process per GPU, ``torch.distributed`` (backend "nccl" == RCCL on ROCm; "gloo" in the CPU
+tests).  Collectives on the data path, all with autograd:
+
+  * halo exchange per layer  -- ``all_to_all_single`` of exactly the boundary rows a peer's rows reference
+    (send lists are integer preprocessing, built once from the global CSR); backward = the reverse exchange and a
+    fixed-order accumulation into the owner's rows;
+  * BatchNorm statistics     -- ``all_reduce`` of per-column (sum, centred sum of squares) so that BN matches the
+    reference's full-graph batch statistics (SyncBN semantics), forward and backward;
+  * G-CRD                    -- every rank draws the same NumPy sample; the sampled unit teacher rows are
+    all-gathered, each rank evaluates its own row block of Z on the MFMA kernels and the teacher-side gradient
+    is all-reduced;
+  * parameters               -- one flat ``all_reduce`` of all gradients per step (~0.5 MB: latency-bound).
+
+Everything else (local aggregation, GEMMs, losses) is the single-GPU kernel path on the local shard.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import time
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from . import _lib, ops
+from .sparse import SparseTensor
+
+
+# ------------------------------------------------------------------------------------------------
+# partition plan (integer, deterministic, identical on every rank)
+# ------------------------------------------------------------------------------------------------
+def node_range(n: int, world: int, rank: int):
+    per = (n + world - 1) // world
+    lo = min(rank * per, n)
+    return lo, min(lo + per, n), per
+
+
+class ShardPlan:
+    """Local view of a global CSR for one rank: remapped columns + halo send / receive lists."""
+
+    def __init__(self, rowptr: Tensor, col: Tensor, value: Tensor | None, n: int, world: int, rank: int):
+        rowptr, col = rowptr.cpu(), col.cpu()
+        self.n, self.world, self.rank = n, world, rank
+        lo, hi, per = node_range(n, world, rank)
+        self.lo, self.hi, self.per, self.n_local = lo, hi, per, hi - lo
+        e0, e1 = int(rowptr[lo]), int(rowptr[hi])
+        c = col[e0:e1]
+        remote = (c < lo) | (c >= hi)
+        self.halo_ids = torch.unique(c[remote])                       # ascending => grouped by owner
+        owner = torch.div(self.halo_ids, per, rounding_mode="floor")
+        self.recv_counts = torch.bincount(owner, minlength=world).tolist()
+        col_ext = torch.where(remote, self.n_local + torch.searchsorted(self.halo_ids, c), c - lo)
+        self.rowptr_local = (rowptr[lo:hi + 1] - e0).contiguous()
+        self.col_ext = col_ext.contiguous()
+        self.value_local = None if value is None else value.cpu()[e0:e1].contiguous()
+        send, counts = [], []
+        for p in range(world):
+            if p == rank:
+                counts.append(0)
+                continue
+            plo, phi, _ = node_range(n, world, p)
+            cp = col[int(rowptr[plo]):int(rowptr[phi])]
+            need = torch.unique(cp[(cp >= lo) & (cp < hi)]) - lo      # my rows that p's rows reference
+            send.append(need)
+            counts.append(need.numel())
+        self.send_idx = torch.cat(send) if send else torch.zeros(0, dtype=torch.int64)
+        self.send_counts = counts
+        self.n_halo = self.halo_ids.numel()
+
+    def local_adj(self, device) -> SparseTensor:
+        return SparseTensor(rowptr=self.rowptr_local.to(device), col=self.col_ext.to(device),
+                            value=None if self.value_local is None else self.value_local.to(device),
+                            sparse_sizes=(self.n_local, self.n_local + self.n_halo))
+
+
+class _HaloExchange(torch.autograd.Function):
+    """x_local [n_local,K] -> x_ext [n_local + n_halo, K] (own rows first, then halo rows ordered by global id)."""
+
+    @staticmethod
+    def forward(ctx, x_local, sadj):
+        plan, group = sadj.plan, sadj.group
+        K = x_local.shape[1]
+        send_buf = x_local.index_select(0, sadj.send_idx_dev).contiguous()
+        recv_buf = torch.empty(plan.n_halo, K, dtype=x_local.dtype, device=x_local.device)
+        dist.all_to_all_single(recv_buf, send_buf, plan.recv_counts, plan.send_counts, group=group)
+        ctx.sadj = sadj
+        return torch.cat([x_local, recv_buf], dim=0)
+
+    @staticmethod
+    def backward(ctx, g_ext):
+        sadj = ctx.sadj
+        plan, group = sadj.plan, sadj.group
+        K = g_ext.shape[1]
+        g_local = g_ext[:plan.n_local].clone()
+        g_halo = g_ext[plan.n_local:].contiguous()
+        back = torch.empty(plan.send_idx.numel(), K, dtype=g_ext.dtype, device=g_ext.device)
+        dist.all_to_all_single(back, g_halo, plan.send_counts, plan.recv_counts, group=group)
+        off = 0
+        for p, cnt in enumerate(plan.send_counts):  # ids are unique within one peer's list: fixed-order, no atomics
+            if cnt:
+                idx = sadj.send_idx_dev[off:off + cnt]
+                g_local[idx] += back[off:off + cnt]
+                off += cnt
+        return g_local, None
+
+
+class ShardedAdj:
+    """What the convs receive as ``adj_t`` on a sharded run: the rank's rows of A (and of A^ = gcn_norm(A))."""
+
+    def __init__(self, adj_global: SparseTensor, world: int, rank: int, device, group=None, gcn_values: Tensor | None = None,
+                 gcn_struct: SparseTensor | None = None):
+        rowptr, col, _ = adj_global.csr()
+        n = adj_global.sparse_size(0)
+        self.group, self.device = group, device
+        self.plan = ShardPlan(rowptr, col, None, n, world, rank)
+        self.send_idx_dev = self.plan.send_idx.to(device)
+        self.raw = self.plan.local_adj(device)
+        self._gcn = None
+        if gcn_struct is not None:  # normalised adjacency (structure differs: self loops inserted)
+            rp, c, v = gcn_struct.csr()
+            self._gcn = ShardedAdj.__new__(ShardedAdj)
+            self._gcn.group, self._gcn.device = group, device
+            self._gcn.plan = ShardPlan(rp, c, v, n, world, rank)
+            self._gcn.send_idx_dev = self._gcn.plan.send_idx.to(device)
+            self._gcn.raw = self._gcn.plan.local_adj(device)
+            self._gcn._gcn = None
+
+    def gcn_normalized(self) -> "ShardedAdj":
+        if self._gcn is None:
+            raise RuntimeError("ShardedAdj was built without the normalised adjacency (pass gcn_struct=)")
+        return self._gcn
+
+    def aggregate(self, x_local: Tensor, reduce: str, valueless: bool = False) -> Tensor:
+        x_ext = _HaloExchange.apply(x_local, self)
+        adj = self.raw.set_value(None) if valueless and self.raw.has_value() else self.raw
+        return ops.spmm(adj, x_ext, reduce)
+
+    def halo_fraction(self) -> float:
+        return self.plan.n_halo / max(1, self.plan.n - self.plan.n_local)
+
+
+# ------------------------------------------------------------------------------------------------
+# BatchNorm with global (all-rank) batch statistics
+# ------------------------------------------------------------------------------------------------
+class _SyncBNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, group):
+        n_local = torch.tensor([float(x.shape[0])], dtype=torch.float32, device=x.device)
+        s = torch.cat([x.sum(0), n_local])
+        dist.all_reduce(s, group=group)
+        n = s[-1]
+        mean = s[:-1] / n
+        xc = x - mean
+        ss = (xc * xc).sum(0)
+        dist.all_reduce(ss, group=group)
+        var = ss / n
+        rstd = torch.rsqrt(var + eps)
+        xhat = xc * rstd
+        ctx.save_for_backward(xhat, weight, rstd, n)
+        ctx.group = group
+        return xhat * weight + bias, mean, var, n
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv, _gn):
+        xhat, weight, rstd, n = ctx.saved_tensors
+        gw_local = (g * xhat).sum(0)
+        gb_local = g.sum(0)
+        tot = torch.cat([gb_local, gw_local])
+        dist.all_reduce(tot, group=ctx.group)
+        C = gb_local.numel()
+        sg, sgx = tot[:C], tot[C:]
+        gx = (weight * rstd) * (g - sg / n - xhat * (sgx / n))
+        return gx, gw_local, gb_local, None, None  # parameter grads stay local: the flat all-reduce sums them
+
+
+class SyncBatchNorm1d(nn.Module):
+    """Drop-in for ``torch.nn.BatchNorm1d`` (same parameter / buffer names) whose training statistics span all ranks."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5, momentum: float = 0.1, group=None):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.group = num_features, eps, momentum, group
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            self.weight.fill_(1.0)
+            self.bias.zero_()
+            self.running_mean.zero_()
+            self.running_var.fill_(1.0)
+            self.num_batches_tracked.zero_()
+
+    def forward(self, x: Tensor) -> Tensor:
+        if not self.training:
+            return (x - self.running_mean) * torch.rsqrt(self.running_var + self.eps) * self.weight + self.bias
+        y, mean, var, n = _SyncBNFn.apply(x, self.weight, self.bias, self.eps, self.group)
+        with torch.no_grad():
+            m = self.momentum
+            self.running_mean.mul_(1 - m).add_(mean.detach(), alpha=m)
+            self.running_var.mul_(1 - m).add_(var.detach() * (n / (n - 1).clamp(min=1)), alpha=m)
+            self.num_batches_tracked += 1
+        return y
+
+
+# ------------------------------------------------------------------------------------------------
+# G-CRD across ranks: row block of Z per rank
+# ------------------------------------------------------------------------------------------------
+def _all_gather_rows(x: Tensor, counts: list[int], group) -> Tensor:
+    """Concatenate per-rank row blocks of differing length (padded all_gather_into_tensor)."""
+    world = len(counts)
+    mx = max(counts)
+    pad = torch.zeros(mx, x.shape[1], dtype=x.dtype, device=x.device)
+    pad[:x.shape[0]] = x
+    out = torch.empty(world * mx, x.shape[1], dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[p * mx:p * mx + c] for p, c in enumerate(counts)], dim=0)
+
+
+class _DistNCE(torch.autograd.Function):
+    """fhat_local, that_local: this rank's sampled unit rows; returns the GLOBAL mean loss (identical on every rank)."""
+
+    @staticmethod
+    def forward(ctx, fhat, that, tau, counts, rank, group):
+        fhat, that = fhat.contiguous(), that.contiguous()
+        S = int(sum(counts))
+        off = int(sum(counts[:rank]))
+        t_all = _all_gather_rows(that, counts, group)
+        Sr, P = fhat.shape
+        loss = torch.zeros(1, dtype=torch.float32, device=fhat.device)
+        Z = lse = None
+        if Sr > 0:
+            Z, lse, loss = ops.nce_block_fwd(fhat, t_all, off, tau, 1.0 / S)
+        dist.all_reduce(loss, group=group)
+        ctx.save_for_backward(fhat, t_all, *([Z, lse] if Sr > 0 else []))
+        ctx.meta = (tau, counts, rank, group, S, off)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        tau, counts, rank, group, S, off = ctx.meta
+        saved = ctx.saved_tensors
+        fhat, t_all = saved[0], saved[1]
+        Sr, P = fhat.shape
+        dt_all = torch.zeros_like(t_all)
+        df = torch.zeros_like(fhat)
+        if Sr > 0:
+            Z, lse = saved[2], saved[3]
+            df, dt_all = ops.nce_block_bwd(fhat, t_all, off, 1.0 / (S * tau), Z, lse, g.contiguous().to(torch.float32))
+        dist.all_reduce(dt_all, group=group)  # every row block contributes to every teacher row
+        return df, dt_all[off:off + Sr].contiguous(), None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# sharded problem + train / eval step
+# ------------------------------------------------------------------------------------------------
+def swap_batchnorm(module: nn.Module, group=None) -> nn.Module:
+    """Replace every BatchNorm1d by SyncBatchNorm1d (state is copied; names unchanged)."""
+    for name, child in list(module.named_children()):
+        if isinstance(child, nn.BatchNorm1d):
+            sb = SyncBatchNorm1d(child.num_features, child.eps, child.momentum if child.momentum is not None else 0.1, group)
+            sb.load_state_dict(child.state_dict())
+            setattr(module, name, sb.to(child.weight.device))
+        else:
+            swap_batchnorm(child, group)
+    return module
+
+
+class ShardedProblem:
+    """Everything one rank holds: its rows of x / y / teacher artefacts, local train / eval index sets."""
+
+    def __init__(self, data, world: int, rank: int, device, group=None, need_gcn: bool = True):
+        from .sparse import gcn_norm
+        n = data.num_nodes
+        self.world, self.rank, self.group, self.device = world, rank, group, device
+        lo, hi, _ = node_range(n, world, rank)
+        self.lo, self.hi, self.n = lo, hi, n
+        gcn_struct = None
+        if need_gcn:
+            gcn_struct = gcn_norm(data.adj_t.to(device)) if torch.device(device).type == "cuda" else data.gcn_struct
+        self.adj = ShardedAdj(data.adj_t, world, rank, device, group, gcn_struct=gcn_struct)
+        self.x = data.x[lo:hi].to(device)
+        self.y = data.y[lo:hi].to(device)
+        self.teacher_out_feat = data.teacher_out_feat[lo:hi].to(device) if getattr(data, "teacher_out_feat", None) is not None else None
+        self.teacher_logits = data.teacher_logits[lo:hi].to(device) if getattr(data, "teacher_logits", None) is not None else None
+        # global train order (gnn.py:243-244) restricted to my range; positions keep the global order
+        tr = data.split_idx["train"]
+        self.n_train_global = tr.numel()
+        mine = (tr >= lo) & (tr < hi)
+        self.train_pos = torch.nonzero(mine).view(-1)                 # positions in the global train list
+        self.train_local = (tr[mine] - lo).to(device)                 # local row ids
+        owner = torch.div(tr, (n + world - 1) // world, rounding_mode="floor")
+        self.train_owner = owner                                       # CPU, per global train position
+        localpos = torch.zeros_like(tr)
+        localpos[mine] = torch.arange(int(mine.sum()))
+        self.train_localpos = localpos                                 # valid where owner == rank
+        self.split_local = {}
+        self.split_sizes = {}
+        for k, idx in data.split_idx.items():
+            m = (idx >= lo) & (idx < hi)
+            self.split_local[k] = (idx[m] - lo).to(device)
+            self.split_sizes[k] = idx.numel()
+
+
+def allreduce_grads(params, group=None):
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, group=group)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
+def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: dict, student_proj=None, teacher_proj=None):
+    """The reference's ``train()`` (gnn.py:102-195) on one shard; returns the GLOBAL (loss, loss_cls, loss_aux)."""
+    from . import criterion as C
+    model.train()
+    for p in (student_proj, teacher_proj):
+        if p is not None:
+            p.train()
+    group = prob.group
+    out = model(prob.x, prob.adj)[prob.train_local]
+    labels = prob.y.squeeze(1)[prob.train_local]
+    frac = out.shape[0] / prob.n_train_global               # local mean -> contribution to the global mean
+    dev = out.device
+    zero = torch.zeros((), dtype=torch.float32, device=dev)
+    if mode == "supervised":
+        loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else zero
+        loss_aux = zero
+        loss = loss_cls
+    elif mode == "kd":
+        if out.shape[0]:
+            lc, lk = ops.ce_and_kd(out, labels, prob.teacher_logits[prob.train_local], hp["kd_T"])
+            loss_cls, loss_aux = lc * frac, lk * frac
+        else:
+            loss_cls = loss_aux = zero
+        loss = loss_aux * (hp["alpha"] * hp["kd_T"] ** 2) + loss_cls * (1 - hp["alpha"])
+    elif mode == "nce":
+        loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else zero
+        f = student_proj(model.out_feat[prob.train_local])
+        t = teacher_proj(prob.teacher_out_feat[prob.train_local])
+        S = hp["max_samples"]
+        ntr = prob.n_train_global
+        pick = np.random.choice(ntr, S, replace=False) if S < ntr else np.arange(ntr)   # same draw on every rank
+        pick_t = torch.from_numpy(pick)
+        owner = prob.train_owner[pick_t]
+        counts = torch.bincount(owner, minlength=prob.world).tolist()
+        mine = pick_t[owner == prob.rank]
+        idx = prob.train_localpos[mine].to(dev)
+        fhat = ops.gather_normalize(f, idx)
+        that = ops.gather_normalize(t, idx)
+        loss_aux = _DistNCE.apply(fhat, that, hp["nce_T"], counts, prob.rank, group)
+        # loss_aux is already the global value on every rank: scale its gradient contribution once (1/world per rank
+        # would double count the all-reduce of parameter grads), so only the local row block's graph carries grad
+        loss = loss_cls + hp["beta"] * loss_aux
+    else:
+        raise NotImplementedError(f"sharded training mode '{mode}'")
+    optimizer.zero_grad()
+    loss.backward()
+    params = [p for g in optimizer.param_groups for p in g["params"]]
+    allreduce_grads(params, group)
+    optimizer.step()
+    rep = torch.stack([loss_cls.detach(), loss_aux.detach() if mode != "nce" else zero])
+    dist.all_reduce(rep, group=group)
+    loss_cls_g = float(rep[0])
+    loss_aux_g = float(loss_aux.detach()) if mode == "nce" else float(rep[1])
+    if mode == "kd":
+        loss_g = loss_aux_g * (hp["alpha"] * hp["kd_T"] ** 2) + loss_cls_g * (1 - hp["alpha"])
+    elif mode == "nce":
+        loss_g = loss_cls_g + hp["beta"] * loss_aux_g
+    else:
+        loss_g = loss_cls_g
+    return loss_g, loss_cls_g, loss_aux_g
+
+
+@torch.no_grad()
+def sharded_evaluate(model, prob: ShardedProblem):
+    model.eval()
+    out = model(prob.x, prob.adj)
+    y_pred = out.argmax(dim=-1, keepdim=True)
+    correct = torch.stack([(prob.y[prob.split_local[k]] == y_pred[prob.split_local[k]]).sum() for k in ("train", "valid", "test")]).float()
+    dist.all_reduce(correct, group=prob.group)
+    accs = tuple(float(correct[i]) / max(1, prob.split_sizes[k]) for i, k in enumerate(("train", "valid", "test")))
+    return out, accs
+
+
+# ------------------------------------------------------------------------------------------------
+# bench entry (called by bench.py when WORLD_SIZE > 1)
+# ------------------------------------------------------------------------------------------------
+def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", emit=print):
+    from . import data as D
+    from . import models as PM
+    device = torch.device(device)
+    on_gpu = device.type == "cuda"
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, **({"device_id": device} if on_gpu else {}))
+    import random
+    for s in (random.seed, np.random.seed, torch.manual_seed):
+        s(args.seed)
+    if on_gpu:
+        torch.cuda.manual_seed_all(args.seed)
+
+    def sync():
+        dist.barrier()
+        if on_gpu:
+            torch.cuda.synchronize()
+    data = D.arxiv_like(args.scale, seed=args.seed)        # same seeded graph on every rank (host-side, one-off)
+    if not on_gpu:  # CPU (gloo) runs get the normalised structure from the caller-provided hook
+        data.gcn_struct = args.cpu_gcn_struct(data)
+    prob = ShardedProblem(data, world, rank, device, None, need_gcn=(args.gnn == "gcn"))
+    Net = PM.GCN if args.gnn == "gcn" else PM.SAGE
+    model = Net(data.num_features, model_cfg["hidden"], data.num_classes, model_cfg["layers"], model_cfg["dropout"]).to(device)
+    swap_batchnorm(model)
+    sp = tp = None
+    groups = [{"params": model.parameters(), "lr": model_cfg["lr"]}]
+    if args.training == "nce":
+        sp = swap_batchnorm(PM.make_projection(model_cfg["hidden"], hp["proj_dim"]).to(device))
+        tp = swap_batchnorm(PM.make_projection(data.teacher_out_feat.shape[1], hp["proj_dim"]).to(device))
+        groups += [{"params": sp.parameters(), "lr": model_cfg["lr"]}, {"params": tp.parameters(), "lr": model_cfg["lr"]}]
+    opt = torch.optim.Adam(groups)
+    torch.manual_seed(args.seed + 1000 + rank)               # dropout masks differ per shard
+
+    def epoch():
+        l = sharded_train_step(model, prob, opt, args.training, hp, sp, tp)
+        _, a = sharded_evaluate(model, prob)
+        return l, a
+
+    for _ in range(args.warmup):
+        epoch()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses, accs = epoch()
+    sync()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    halo = torch.tensor([float(prob.adj.plan.n_halo)], device=device)
+    dist.all_reduce(halo)
+    if rank == 0:
+        el = float(elapsed)
+        out = dict(
+            metric="training epochs/sec, ogbn-arxiv 3-layer GCN student + G-CRD, 1/2/4/8 MI355X",
+            value=round(args.steps / el, 3), unit="epochs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+            ms_per_step=round(1e3 * el / args.steps, 3), higher_is_better=True, scaling="strong", vs_baseline=None,
+            dtype="f32", data="synthetic",
+            config=dict(workload=f"ogbn-arxiv-shaped synthetic graph (N={data.num_nodes}, nnz_sym={data.adj_t.nnz()}), "
+                                 f"3-layer {args.gnn.upper()}-256 student + {args.training} loss, full-graph train step + eval "
+                                 f"per epoch", gnn=args.gnn, training=args.training, hidden=model_cfg["hidden"],
+                        layers=model_cfg["layers"], max_samples=hp["max_samples"], proj_dim=hp["proj_dim"],
+                        partitioning=f"node-range shards x{world}, halo all_to_all + SyncBN all-reduce + flat grad all-reduce over RCCL",
+                        mean_halo_rows_per_rank=int(float(halo) / world)),
+            roofline=None, cpu_baseline=None,
+            last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs])
+        emit(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()

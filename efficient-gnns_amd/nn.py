@@ -59,6 +59,9 @@ class GCNConv(nn.Module):
         self._cached_adj_t = None
 
     def forward(self, x: Tensor, edge_index) -> Tensor:
+        if hasattr(edge_index, "gcn_normalized"):  # node-range shard (dist.ShardedAdj): halo exchange + local rows of A^
+            out = edge_index.gcn_normalized().aggregate(ops.matmul(x, self.weight), "sum")
+            return out + self.bias if self.bias is not None else out
         norm = self._cached_adj_t
         if norm is None:
             if isinstance(edge_index, SparseTensor):
@@ -94,8 +97,11 @@ class SAGEConv(nn.Module):
         self.lin_r.reset_parameters()
 
     def forward(self, x: Tensor, edge_index) -> Tensor:
-        adj = edge_index if isinstance(edge_index, SparseTensor) else _adj_from_edge_index(edge_index, x.shape[0])
-        agg = ops.spmm(adj.set_value(None), x, self.aggr)
+        if hasattr(edge_index, "aggregate"):  # node-range shard (dist.ShardedAdj)
+            agg = edge_index.aggregate(x, self.aggr, valueless=True)
+        else:
+            adj = edge_index if isinstance(edge_index, SparseTensor) else _adj_from_edge_index(edge_index, x.shape[0])
+            agg = ops.spmm(adj.set_value(None), x, self.aggr)
         return ops.linear(agg, self.lin_l.weight, self.lin_l.bias) + ops.linear(x, self.lin_r.weight, None)
 
     def __repr__(self):

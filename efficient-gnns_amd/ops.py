@@ -280,3 +280,32 @@ class _NCE(torch.autograd.Function):
 def nce_unit(fhat: Tensor, that: Tensor, tau: float) -> Tensor:
     """mean_i(logsumexp_j(fhat_i . that_j / tau) - fhat_i . that_i / tau) for unit-norm rows."""
     return _NCE.apply(fhat, that, tau)
+
+
+def nce_block_fwd(fhat: Tensor, t_all: Tensor, diag_off: int, tau: float, inv_count: float):
+    """Row block of the G-CRD loss (egnn_nce_block_fwd_f32): returns (Z [Sr,Sc], lse [Sr], loss_sum*inv_count [1])."""
+    _lib.require_gpu(fhat, t_all)
+    Sr, P = fhat.shape
+    Sc = t_all.shape[0]
+    lib, dev = _lib.load(), fhat.device
+    Z = torch.empty(Sr, Sc, dtype=torch.float32, device=dev)
+    lse = torch.empty(Sr, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    nws = lib.egnn_nce_ws_floats(Sr)
+    ws = torch.empty(nws, dtype=torch.float32, device=dev)
+    rc = lib.egnn_nce_block_fwd_f32(_lib.ptr(fhat), fhat.stride(0), _lib.ptr(t_all), t_all.stride(0), Sr, Sc, diag_off, P, float(tau),
+                                    float(inv_count), _lib.ptr(Z), _lib.ptr(lse), _lib.ptr(loss), _lib.ptr(ws), nws, _lib.stream())
+    _lib.check(rc, "egnn_nce_block_fwd_f32")
+    return Z, lse, loss
+
+
+def nce_block_bwd(fhat: Tensor, t_all: Tensor, diag_off: int, scale: float, Z: Tensor, lse: Tensor, g: Tensor):
+    """(dfhat [Sr,P], this rank's contribution to dthat_all [Sc,P]) via egnn_nce_block_bwd_f32."""
+    Sr, P = fhat.shape
+    Sc = t_all.shape[0]
+    df, dt = torch.empty_like(fhat), torch.empty_like(t_all)
+    rc = _lib.load().egnn_nce_block_bwd_f32(_lib.ptr(fhat), fhat.stride(0), _lib.ptr(t_all), t_all.stride(0), Sr, Sc, diag_off, P,
+                                            float(scale), _lib.ptr(Z), _lib.ptr(lse), _lib.ptr(g), _lib.ptr(df), df.stride(0),
+                                            _lib.ptr(dt), dt.stride(0), _lib.stream())
+    _lib.check(rc, "egnn_nce_block_bwd_f32")
+    return df, dt

@@ -174,6 +174,18 @@ int egnn_nce_bwd_f32(const float* fhat, const float* that, int64_t S, int64_t P,
                      const float* Z, const float* lse, const float* g,
                      float* dfhat, float* dthat, void* stream);
 
+/* Row-block form of the two entry points above, for node-range sharding: this rank owns Sr of the
+ * S_total sampled rows, `that` holds ALL Sc = S_total teacher rows (all-gathered over RCCL), and the positive of
+ * local row i is column i + diag_off.  loss = inv_count * sum_i (lse_i - Z_i,i+off)  (pass 1/S_total and all-reduce);
+ * dfhat [Sr,P] is complete, dthat [Sc,P] is this rank's contribution (all-reduce it); scale = 1 / (S_total * tau).
+ * Z is [Sr,Sc] (ld = Sc); ws: egnn_nce_ws_floats(Sr). */
+int egnn_nce_block_fwd_f32(const float* fhat, int64_t ld_f, const float* that, int64_t ld_t, int64_t Sr, int64_t Sc,
+                           int64_t diag_off, int64_t P, float tau, float inv_count, float* Z, float* lse, float* loss,
+                           float* ws, size_t ws_floats, void* stream);
+int egnn_nce_block_bwd_f32(const float* fhat, int64_t ld_f, const float* that, int64_t ld_t, int64_t Sr, int64_t Sc,
+                           int64_t diag_off, int64_t P, float scale, const float* Z, const float* lse, const float* g,
+                           float* dfhat, int64_t ld_df, float* dthat, int64_t ld_dt, void* stream);
+
 /* GSP all-pairs similarity loss, /root/reference/arxiv_pyg/criterion.py:69-88:
  *   loss = mean_ij (k(xs_i,xs_j) - k(xt_i,xt_j))^2 ; kernel: EGNN_K_COSINE / _POLY (rows must be unit vectors,
  *   criterion.py:71-72,76-77) or EGNN_K_L2 / _RBF (raw rows; ||a-b||^2 via ||a||^2+||b||^2-2<a,b>, diagonal exact 0;
