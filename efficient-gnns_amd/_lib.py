@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libegnn_hip.so")
 
-_p, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
+_p, _i64, _i32, _f32, _sz, _u64 = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 
 # name -> (restype, argtypes); must list every symbol include/egnn_hip.h declares
 SIGNATURES = {
@@ -50,6 +50,11 @@ SIGNATURES = {
     "egnn_segment_softmax_fwd_f32": (_i32, [_p, _p, _i64, _p, _p]),
     "egnn_segment_softmax_bwd_f32": (_i32, [_p, _p, _p, _i64, _p, _p]),
     "egnn_segment_sum_f32": (_i32, [_p, _p, _i64, _p, _p]),
+    "egnn_bn_ws_floats": (_sz, [_i64]),
+    "egnn_bn_stats_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),
+    "egnn_bn_act_fwd_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _i64, _p]),
+    "egnn_bn_act_bwd_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _i32, _p, _p, _p, _i64,
+                                   _p, _sz, _p]),
 }
 
 _lib = None

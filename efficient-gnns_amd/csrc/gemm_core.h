@@ -3,10 +3,12 @@
 // Block tile BM x BN, 256 threads = 4 waves in a 2 x 2 arrangement, each wave owning
 // (BM/2) x (BN/2) as TM x TN MFMA tiles of 32 x 32.  K is consumed in steps of BK = 16 through two
 // LDS buffers; global loads for step k+1 are issued before the MFMAs of step k and written to the
-// other LDS buffer after them (one barrier per step).  Both operands live in LDS k-contiguous
-// ([rows][BK+4]) whatever their global layout, so the inner loop is one ds_read_b128 per operand tile
-// per 4 MFMAs: lane l reads k = {4h .. 4h+3}, h = l >> 5, and MFMA #m of the group consumes element m
-// of both fragments -- a permutation of the k order that A and B share, so the sum is unchanged.
+// other LDS buffer after them (one barrier per step).  An operand keeps its global orientation in LDS so
+// that staging is always a conflict-free ds_write_b128: k-major operands live as [rows][BK+4] and are read
+// with one ds_read_b128 per 4 MFMAs; row-major-in-k operands ([K, rows] in memory) live as [BK][rows+4] and
+// are read with four conflict-free ds_read_b32.  Either way lane l holds k = {4h .. 4h+3}, h = l >> 5, and
+// MFMA #m of a group consumes element m of both fragments -- a permutation of the k order that A and B
+// share, so the sum is unchanged.
 // At 64 cycles per MFMA per SIMD the LDS and the staging VALU have an order of magnitude of slack;
 // the kernel is paced by the matrix pipe.
 #pragma once
@@ -34,8 +36,10 @@ struct Stager {
   static constexpr int NV = R / 64;
   float v[NV][4];
 
-  __device__ __forceinline__ void load(const float* __restrict__ p, int64_t ld, int64_t r0, int64_t rmax, int64_t k0,
-                                       int64_t kmax, const XF& xf) {
+  // FULL: the whole R x BK tile is in range (block-uniform) -> straight-line vector loads, no per-element guards
+  template <bool FULL>
+  __device__ __forceinline__ void load_impl(const float* __restrict__ p, int64_t ld, int64_t r0, int64_t rmax, int64_t k0,
+                                            int64_t kmax, const XF& xf) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -43,9 +47,11 @@ struct Stager {
         const int64_t r = r0 + (t >> 2) + 64 * i;
         const int64_t k = k0 + (t & 3) * 4;
         const float* q = p + r * ld + k;
-        if (r < rmax && VEC4 && k + 3 < kmax) {
-          const float4 x = *reinterpret_cast<const float4*>(q);
-          v[i][0] = xf(x.x, r, k); v[i][1] = xf(x.y, r, k + 1); v[i][2] = xf(x.z, r, k + 2); v[i][3] = xf(x.w, r, k + 3);
+        if constexpr (FULL) {
+          float x0, x1, x2, x3;
+          if constexpr (VEC4) { const float4 x = *reinterpret_cast<const float4*>(q); x0 = x.x; x1 = x.y; x2 = x.z; x3 = x.w; }
+          else { x0 = q[0]; x1 = q[1]; x2 = q[2]; x3 = q[3]; }
+          v[i][0] = xf(x0, r, k); v[i][1] = xf(x1, r, k + 1); v[i][2] = xf(x2, r, k + 2); v[i][3] = xf(x3, r, k + 3);
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[i][j] = (r < rmax && k + j < kmax) ? xf(q[j], r, k + j) : 0.f;
@@ -56,9 +62,11 @@ struct Stager {
         const int64_t k = k0 + t / TPR + KPP * i;
         const int64_t r = r0 + (t % TPR) * 4;
         const float* q = p + k * ld + r;
-        if (k < kmax && VEC4 && r + 3 < rmax) {
-          const float4 x = *reinterpret_cast<const float4*>(q);
-          v[i][0] = xf(x.x, r, k); v[i][1] = xf(x.y, r + 1, k); v[i][2] = xf(x.z, r + 2, k); v[i][3] = xf(x.w, r + 3, k);
+        if constexpr (FULL) {
+          float x0, x1, x2, x3;
+          if constexpr (VEC4) { const float4 x = *reinterpret_cast<const float4*>(q); x0 = x.x; x1 = x.y; x2 = x.z; x3 = x.w; }
+          else { x0 = q[0]; x1 = q[1]; x2 = q[2]; x3 = q[3]; }
+          v[i][0] = xf(x0, r, k); v[i][1] = xf(x1, r + 1, k); v[i][2] = xf(x2, r + 2, k); v[i][3] = xf(x3, r + 3, k);
         } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[i][j] = (k < kmax && r + j < rmax) ? xf(q[j], r + j, k) : 0.f;
@@ -67,24 +75,41 @@ struct Stager {
     }
   }
 
-  __device__ __forceinline__ void store(float (*lds)[LDS_LD]) const {
+  __device__ __forceinline__ void load(const float* __restrict__ p, int64_t ld, int64_t r0, int64_t rmax, int64_t k0,
+                                       int64_t kmax, const XF& xf) {
+    const bool full = (r0 + R <= rmax) && (k0 + BK <= kmax);  // block-uniform
+    if (full) load_impl<true>(p, ld, r0, rmax, k0, kmax, xf);
+    else load_impl<false>(p, ld, r0, rmax, k0, kmax, xf);
+  }
+
+  // LDS image: KMAJOR -> [R][LDS_LD] ; MNMAJOR -> [BK][R + 4]   (both fit in R * LDS_LD floats)
+  __device__ __forceinline__ void store(float* lds) const {
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
+      const f32x4v x = {v[i][0], v[i][1], v[i][2], v[i][3]};
       if constexpr (MAJOR == KMAJOR) {
-        f32x4v x = {v[i][0], v[i][1], v[i][2], v[i][3]};
-        *reinterpret_cast<f32x4v*>(&lds[(t >> 2) + 64 * i][(t & 3) * 4]) = x;
+        *reinterpret_cast<f32x4v*>(lds + ((t >> 2) + 64 * i) * LDS_LD + (t & 3) * 4) = x;
       } else {
         constexpr int TPR = R / 4;
         constexpr int KPP = 256 / TPR;
-        const int k = t / TPR + KPP * i;
-        const int r = (t % TPR) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) lds[r + j][k] = v[i][j];
+        *reinterpret_cast<f32x4v*>(lds + (t / TPR + KPP * i) * (R + 4) + (t % TPR) * 4) = x;
       }
     }
   }
 };
+
+// MFMA fragment of 32 rows starting at `row0` for k-block kb (8 k values): element m <-> k = kb*8 + 4*(lane>>5) + m
+template <int R, int MAJOR>
+__device__ __forceinline__ f32x4v load_frag(const float* lds, int row0, int kb, int lane) {
+  if constexpr (MAJOR == KMAJOR) {
+    return *reinterpret_cast<const f32x4v*>(lds + (row0 + (lane & 31)) * LDS_LD + kb * 8 + (lane >> 5) * 4);
+  } else {
+    const float* p = lds + (kb * 8 + (lane >> 5) * 4) * (R + 4) + row0 + (lane & 31);
+    f32x4v f = {p[0], p[R + 4], p[2 * (R + 4)], p[3 * (R + 4)]};
+    return f;
+  }
+}
 
 template <int BM, int BN>
 struct TileShape {
@@ -112,8 +137,9 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM_][TN_],
                                          int64_t kbeg, int64_t kend, const XFA& xfa, const XFB& xfb, float* smem) {
   using TS = TileShape<BM, BN>;
   static_assert(TM_ == TS::TM && TN_ == TS::TN, "accumulator shape does not match the block tile");
-  float (*As)[BM][LDS_LD] = reinterpret_cast<float (*)[BM][LDS_LD]>(smem);
-  float (*Bs)[BN][LDS_LD] = reinterpret_cast<float (*)[BN][LDS_LD]>(smem + 2 * BM * LDS_LD);
+  // plain offset arithmetic on the __shared__ base keeps the LDS address space visible to the compiler
+  // (an array of buffer pointers indexed by `cur` decays to flat loads, which also drain the global prefetch)
+  constexpr int A_BUF = BM * LDS_LD, B_BUF = BN * LDS_LD, B_OFF = 2 * BM * LDS_LD;
   Stager<BM, AMAJ, VEC4, XFA> sa;
   Stager<BN, BMAJ, VEC4, XFB> sb;
   const int nk = (int)((kend - kbeg + BK - 1) / BK);
@@ -124,8 +150,8 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM_][TN_],
 
   sa.load(A, lda, m0, M, kbeg, kend, xfa);
   sb.load(B, ldb, n0, N, kbeg, kend, xfb);
-  sa.store(As[0]);
-  sb.store(Bs[0]);
+  sa.store(smem);
+  sb.store(smem + B_OFF);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -134,15 +160,13 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM_][TN_],
       sa.load(A, lda, m0, M, kbeg + (int64_t)(kt + 1) * BK, kend, xfa);
       sb.load(B, ldb, n0, N, kbeg + (int64_t)(kt + 1) * BK, kend, xfb);
     }
-    const float* ab = &As[cur][wm * TS::WM + (lane & 31)][(lane >> 5) * 4];
-    const float* bb = &Bs[cur][wn * TS::WN + (lane & 31)][(lane >> 5) * 4];
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
       f32x4v a[TS::TM], b[TS::TN];
 #pragma unroll
-      for (int tm = 0; tm < TS::TM; ++tm) a[tm] = *reinterpret_cast<const f32x4v*>(ab + tm * 32 * LDS_LD + kb * 8);
+      for (int tm = 0; tm < TS::TM; ++tm) a[tm] = load_frag<BM, AMAJ>(smem + cur * A_BUF, wm * TS::WM + tm * 32, kb, lane);
 #pragma unroll
-      for (int tn = 0; tn < TS::TN; ++tn) b[tn] = *reinterpret_cast<const f32x4v*>(bb + tn * 32 * LDS_LD + kb * 8);
+      for (int tn = 0; tn < TS::TN; ++tn) b[tn] = load_frag<BN, BMAJ>(smem + B_OFF + cur * B_BUF, wn * TS::WN + tn * 32, kb, lane);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -152,8 +176,8 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM_][TN_],
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][m], b[tn][m], acc[tm][tn], 0, 0, 0);
     }
     if (more) {
-      sa.store(As[cur ^ 1]);
-      sb.store(Bs[cur ^ 1]);
+      sa.store(smem + (cur ^ 1) * A_BUF);
+      sb.store(smem + B_OFF + (cur ^ 1) * B_BUF);
     }
     __syncthreads();
   }

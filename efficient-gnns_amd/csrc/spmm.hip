@@ -462,7 +462,7 @@ extern "C" int egnn_spmm_csr_f32(int64_t n_rows, int64_t n_src, int64_t K, const
   EGNN_CHECK_ARG(n_short >= 0 && n_mid >= 0 && n_long >= 0);
   EGNN_CHECK_ARG((n_short == 0 || short_rows) && (n_mid == 0 || mid_rows) && (n_long == 0 || long_rows));
   const bool planned = short_rows || mid_rows || long_rows;
-  EGNN_CHECK_ARG(!planned || n_short + n_mid + n_long == n_rows);
+  EGNN_CHECK_ARG(!planned || n_short + n_mid + n_long <= n_rows);
   const RowPlan plan{short_rows, n_short, mid_rows, n_mid, long_rows, n_long};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (index_bits == 32) {

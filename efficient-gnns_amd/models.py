@@ -12,6 +12,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import criterion as C
+from . import ops
 from .nn import GCNConv, SAGEConv
 
 
@@ -30,7 +31,11 @@ class _Student(nn.Module):
 
     def forward(self, x, adj_t):
         for conv, bn in zip(self.convs[:-1], self.bns):
-            x = F.dropout(F.relu(bn(conv(x, adj_t))), p=self.dropout, training=self.training)
+            x = conv(x, adj_t)
+            if isinstance(bn, nn.BatchNorm1d) and x.is_cuda:   # fused BN + ReLU + dropout kernels (gnn.py:48-50)
+                x = ops.bn_act(x, bn, relu=True, p=self.dropout, training=self.training)
+            else:                                               # SyncBatchNorm1d on sharded runs
+                x = F.dropout(F.relu(bn(x)), p=self.dropout, training=self.training)
             self.out_feat = x
         return self.convs[-1](x, adj_t)
 
@@ -58,14 +63,27 @@ class ProjectionGCD(nn.Module):
         return F.relu(self.bn(self.lin(x) + self.conv(x, adj_t)))
 
 
+class ProjectionHead(nn.Sequential):
+    """Linear + BatchNorm1d + ReLU (gnn.py:296-306) with the reference's Sequential state_dict keys (0.*, 1.*);
+    the forward runs the MFMA GEMM and the fused BN + ReLU kernels."""
+
+    def __init__(self, in_dim, proj_dim):
+        super().__init__(nn.Linear(in_dim, proj_dim), nn.BatchNorm1d(proj_dim), nn.ReLU())
+
+    def forward(self, x):
+        lin, bn = self[0], self[1]
+        if not x.is_cuda or not isinstance(bn, nn.BatchNorm1d):
+            return super().forward(x)
+        return ops.bn_act(ops.linear(x, lin.weight, lin.bias), bn, relu=True, p=0.0, training=self.training)
+
+
 def make_projection(in_dim, proj_dim):
-    return nn.Sequential(nn.Linear(in_dim, proj_dim), nn.BatchNorm1d(proj_dim), nn.ReLU())
+    return ProjectionHead(in_dim, proj_dim)
 
 
 def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_logits, hp,
                  student_proj=None, teacher_proj=None, edge_index=None, adj_t=None, kd_and_aux=False):
     if mode == "supervised":
-        from . import ops
         loss = ops.cross_entropy(out, labels)
         return loss, loss, loss * 0
     if mode == "kd":

@@ -9,6 +9,16 @@ from torch import Tensor
 from . import _lib
 
 _REDUCE = {"sum": 0, "add": 0, "mean": 1, "max": 2}
+_OVERLAP_HEAVY_ROWS = os.environ.get("EGNN_SPMM_OVERLAP", "1") != "0"
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
 
 
 def _rowmajor(x: Tensor) -> Tensor:
@@ -38,13 +48,36 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
     arg = torch.empty(n_rows, K, dtype=torch.int64, device=x.device) if red == 2 else None
     rowptr, col, bits = adj._index_arrays()
     short, mid, long_ = adj._row_plan() if use_plan else (None, None, None)
+    lib = _lib.load()
 
     def lst(t):
         return (None, 0) if t is None or t.numel() == 0 else (_lib.ptr(t), t.numel())
-    (ps, ns), (pm, nm), (pl, nl) = lst(short), lst(mid), lst(long_)
-    rc = _lib.load().egnn_spmm_csr_f32(
-        n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), bits, _lib.ptr(adj._value), _lib.ptr(src_scale),
-        _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), red, _lib.ptr(arg), ps, ns, pm, nm, pl, nl, _lib.stream())
+
+    def launch(s, m, l, stream):
+        (ps, ns), (pm, nm), (pl, nl) = lst(s), lst(m), lst(l)
+        return lib.egnn_spmm_csr_f32(
+            n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), bits, _lib.ptr(adj._value), _lib.ptr(src_scale),
+            _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), red, _lib.ptr(arg), ps, ns, pm, nm, pl, nl, stream)
+
+    heavy = use_plan and short is not None and short.numel() > 0 and (mid.numel() + long_.numel()) > 0
+    if heavy and _OVERLAP_HEAVY_ROWS:
+        # the few mid / long rows run on a side stream underneath the short-row bulk (fork / join with events)
+        main = torch.cuda.current_stream()
+        side = _side_stream(x.device)
+        fork = torch.cuda.Event()
+        fork.record(main)
+        side.wait_event(fork)
+        rc = launch(None, mid, long_, side.cuda_stream)
+        _lib.check(rc, "egnn_spmm_csr_f32")
+        rc = launch(short, None, None, main.cuda_stream)
+        join = torch.cuda.Event()
+        join.record(side)
+        main.wait_event(join)
+        for t in (x, y, arg, adj._value, src_scale):
+            if t is not None:
+                t.record_stream(side)
+    else:
+        rc = launch(short, mid, long_, _lib.stream())
     _lib.check(rc, "egnn_spmm_csr_f32")
     return y, arg
 
@@ -309,3 +342,75 @@ def nce_block_bwd(fhat: Tensor, t_all: Tensor, diag_off: int, scale: float, Z: T
                                             _lib.ptr(dt), dt.stride(0), _lib.stream())
     _lib.check(rc, "egnn_nce_block_bwd_f32")
     return df, dt
+
+
+# ------------------------------------------------------------------------------------------------
+# fused BatchNorm1d (+ ReLU + dropout)
+# ------------------------------------------------------------------------------------------------
+def _bn_shape_ok(x: Tensor) -> bool:
+    C = x.shape[1]
+    return x.is_cuda and C % 4 == 0 and C <= 1024 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+
+
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, var, eps, relu, p, seed, batch_stats):
+        x = _rowmajor(x)
+        n, C = x.shape
+        y = torch.empty(n, C, dtype=torch.float32, device=x.device)
+        rc = _lib.load().egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
+                                             _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(y), y.stride(0), _lib.stream())
+        _lib.check(rc, "egnn_bn_act_fwd_f32")
+        ctx.save_for_backward(x, gamma, beta, mean, var)
+        ctx.cfg = (float(eps), int(relu), float(p), int(seed), int(batch_stats))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, mean, var = ctx.saved_tensors
+        eps, relu, p, seed, batch_stats = ctx.cfg
+        gy = _rowmajor(gy)
+        n, C = x.shape
+        lib, dev = _lib.load(), x.device
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        nws = lib.egnn_bn_ws_floats(C)
+        ws = torch.empty(nws, dtype=torch.float32, device=dev)
+        rc = lib.egnn_bn_act_bwd_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), eps,
+                                     _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, batch_stats, _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                     _lib.ptr(dx), dx.stride(0), _lib.ptr(ws), nws, _lib.stream())
+        _lib.check(rc, "egnn_bn_act_bwd_f32")
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def bn_act(x: Tensor, bn: "torch.nn.BatchNorm1d", relu: bool = True, p: float = 0.0, training: bool | None = None) -> Tensor:
+    """dropout(relu(bn(x)), p) in two kernels (statistics + apply); same module state updates as nn.BatchNorm1d.
+
+    Falls back to the torch operators (still on the GPU) for shapes the kernel does not take (C % 4 != 0, C > 1024)."""
+    training = bn.training if training is None else training
+    if not _bn_shape_ok(_rowmajor(x)) or not bn.track_running_stats or bn.weight is None:
+        y = bn(x)
+        y = torch.relu(y) if relu else y
+        return torch.nn.functional.dropout(y, p, training) if p > 0 else y
+    x = _rowmajor(x)
+    n, C = x.shape
+    use_batch = training  # nn.BatchNorm1d: batch statistics in training mode, running statistics in eval mode
+    if use_batch:
+        lib, dev = _lib.load(), x.device
+        mean = torch.empty(C, dtype=torch.float32, device=dev)
+        var = torch.empty(C, dtype=torch.float32, device=dev)
+        nws = lib.egnn_bn_ws_floats(C)
+        ws = torch.empty(nws, dtype=torch.float32, device=dev)
+        _lib.check(lib.egnn_bn_stats_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(ws), nws, _lib.stream()),
+                   "egnn_bn_stats_f32")
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1 - m).add_(var, alpha=m * n / max(n - 1, 1))
+    else:
+        mean, var = bn.running_mean, bn.running_var
+    drop = p if (training and p > 0) else 0.0
+    seed = int(torch.empty((), dtype=torch.int64).random_()) if drop > 0 else 0  # host generator: torch.manual_seed reproducible
+    return _BnAct.apply(x, bn.weight, bn.bias, mean, var, bn.eps, relu, drop, seed & 0x7FFFFFFFFFFFFFFF, use_batch)

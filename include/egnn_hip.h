@@ -61,9 +61,10 @@ int egnn_build_info(char* buf, size_t buf_bytes);
  *                         with similar lengths next to each other
  *   mid_rows   [n_mid]    row ids reduced by one wavefront each
  *   long_rows  [n_long]   row ids reduced by a whole 16-wave workgroup with a fixed-order LDS combine
- * Every row id in [0, n_rows) must appear in exactly one list (n_short + n_mid + n_long == n_rows), or all
- * three lists are NULL and every row takes the one-wavefront path.  The accumulation order is fixed by the
- * schedule, so results are run-to-run bit-stable for every degree distribution.
+ * A call writes exactly the rows it lists (each at most once); with all three lists NULL every row of
+ * [0, n_rows) takes the one-wavefront path.  The host normally covers all rows with one call, or with two calls
+ * on two streams (short rows | mid + long rows) so the few heavy rows overlap the bulk.  The accumulation order
+ * is fixed by the schedule, so results are run-to-run bit-stable for every degree distribution.
  * ---------------------------------------------------------------------------------------------- */
 #define EGNN_SUM 0
 #define EGNN_MEAN 1
@@ -232,6 +233,29 @@ int egnn_edge_sim_coef_f32(const float* g, const float* sim, const float* aux3, 
 int egnn_segment_softmax_fwd_f32(const int64_t* seg_ptr, const float* x, int64_t n_seg, float* p, void* stream);
 int egnn_segment_softmax_bwd_f32(const int64_t* seg_ptr, const float* p, const float* gp, int64_t n_seg, float* gx, void* stream);
 int egnn_segment_sum_f32(const int64_t* seg_ptr, const float* x, int64_t n_seg, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused BatchNorm1d (+ ReLU + dropout) over node rows -- SURVEY.md 8(f) rank 1; replaces the ATen BatchNorm /
+ * threshold / fused_dropout chain at /root/reference/arxiv_pyg/gnn.py:48-50,80-82,296-306.
+ * Shapes: x [n,C] fp32, C % 4 == 0, C <= 1024, ld % 4 == 0, 16-byte aligned (else EGNN_EALIGN: the host uses
+ * the torch operators for such shapes).
+ *   egnn_bn_stats_f32     mean[c], biased var[c] over the n rows (training statistics)
+ *   egnn_bn_act_fwd_f32   y = drop_p(relu?(gamma * (x - mean) * rsqrt(var + eps) + beta)); the dropout mask is a
+ *                         counter-based hash of (seed, row*C + c): keep if u >= p, kept values scaled 1/(1-p)
+ *   egnn_bn_act_bwd_f32   recomputes xhat / ReLU sign / mask from x and seed; dgamma, dbeta [C]; dx [n,C];
+ *                         batch_stats != 0: mean/var are this batch's statistics (training backward, the
+ *                         -(sum d + xhat sum d xhat)/n terms apply); 0: running statistics (eval-mode graph)
+ * ws: egnn_bn_ws_floats(C) floats. */
+size_t egnn_bn_ws_floats(int64_t C);
+int egnn_bn_stats_f32(const float* x, int64_t ld, int64_t n, int64_t C, float* mean, float* var, float* ws, size_t ws_floats,
+                      void* stream);
+int egnn_bn_act_fwd_f32(const float* x, int64_t ld, int64_t n, int64_t C, const float* mean, const float* var, float eps,
+                        const float* gamma, const float* beta, int relu, float p, uint64_t seed, float* y, int64_t ldy,
+                        void* stream);
+int egnn_bn_act_bwd_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C, const float* mean,
+                        const float* var, float eps, const float* gamma, const float* beta, int relu, float p, uint64_t seed,
+                        int batch_stats, float* dgamma, float* dbeta, float* dx, int64_t ld_dx, float* ws, size_t ws_floats,
+                        void* stream);
 
 #ifdef __cplusplus
 }
