@@ -81,18 +81,35 @@ def make_projection(in_dim, proj_dim):
     return ProjectionHead(in_dim, proj_dim)
 
 
+_ROW_CACHE: dict = {}
+
+
+def _const_rows(t, idx):
+    """``t[idx]`` for a constant tensor (teacher artefacts): the reference re-gathers 273 MB every step (gnn.py:155);
+    the rows do not change within a run, so the gather is done once per (tensor, index) identity + version."""
+    if t.requires_grad:
+        return t[idx]
+    key = (t.data_ptr(), t._version, tuple(t.shape), idx.data_ptr(), idx._version, idx.numel())
+    hit = _ROW_CACHE.get(key)
+    if hit is None:
+        if len(_ROW_CACHE) > 8:
+            _ROW_CACHE.clear()
+        hit = _ROW_CACHE[key] = t[idx]
+    return hit
+
+
 def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_logits, hp,
                  student_proj=None, teacher_proj=None, edge_index=None, adj_t=None, kd_and_aux=False):
     if mode == "supervised":
         loss = ops.cross_entropy(out, labels)
         return loss, loss, loss * 0
     if mode == "kd":
-        return C.kd_criterion(out, labels, teacher_logits[train_idx], hp["alpha"], hp["kd_T"])
+        return C.kd_criterion(out, labels, _const_rows(teacher_logits, train_idx), hp["alpha"], hp["kd_T"])
     if mode in ("fitnet", "gpw", "nce"):
         f = student_proj(model.out_feat[train_idx])
-        t = teacher_proj(teacher_out_feat[train_idx])
+        t = teacher_proj(_const_rows(teacher_out_feat, train_idx))
     elif mode in ("at", "lpw"):
-        f, t = model.out_feat[train_idx], teacher_out_feat[train_idx]
+        f, t = model.out_feat[train_idx], _const_rows(teacher_out_feat, train_idx)
     elif mode == "gcd":
         f = student_proj(model.out_feat, adj_t)[train_idx]
         t = teacher_proj(teacher_out_feat, adj_t)[train_idx]
@@ -111,7 +128,7 @@ def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_
     if not kd_and_aux:
         return res
     loss_aux = res[2]
-    loss, loss_cls, _ = C.kd_criterion(out, labels, teacher_logits[train_idx], hp["alpha"], hp["kd_T"])
+    loss, loss_cls, _ = C.kd_criterion(out, labels, _const_rows(teacher_logits, train_idx), hp["alpha"], hp["kd_T"])
     return loss + hp["beta"] * loss_aux, loss_cls, loss_aux
 
 

@@ -12,7 +12,11 @@ import torch
 from torch import Tensor, nn
 
 from . import ops
+import os
+
 from .sparse import SparseTensor, _ind2ptr, gcn_norm
+
+_MEMOISE_AX = os.environ.get("EGNN_GCN_MEMOISE_AX", "1") != "0"
 
 
 def _adj_from_edge_index(edge_index: Tensor, n: int, value: Tensor | None = None) -> SparseTensor:
@@ -48,6 +52,7 @@ class GCNConv(nn.Module):
         self.weight = nn.Parameter(torch.empty(in_channels, out_channels))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self._cached_adj_t = None
+        self._cached_ax = None  # (key, A^ x) for a constant input tensor, see forward()
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -57,6 +62,7 @@ class GCNConv(nn.Module):
             if self.bias is not None:
                 self.bias.zero_()
         self._cached_adj_t = None
+        self._cached_ax = None
 
     def forward(self, x: Tensor, edge_index) -> Tensor:
         if hasattr(edge_index, "gcn_normalized"):  # node-range shard (dist.ShardedAdj): halo exchange + local rows of A^
@@ -70,7 +76,18 @@ class GCNConv(nn.Module):
                 norm = _gcn_norm_edge_index(edge_index, x.shape[0])
             if self.cached:
                 self._cached_adj_t = norm
-        out = ops.spmm(norm, ops.matmul(x, self.weight), "sum")
+        if (self.cached and _MEMOISE_AX and not x.requires_grad and self.in_channels <= self.out_channels
+                and isinstance(edge_index, SparseTensor)):
+            # constant input (the first layer's node features): A^ (x W) == (A^ x) W, and A^ x does not change between
+            # steps, so it is kept next to the cached A^ (same lifetime) and the per-step aggregation disappears from
+            # forward, backward (dW = (A^ x)^T dOut, no dX needed) and eval.  Keyed on the tensor's identity + version.
+            key = (x.data_ptr(), x._version, tuple(x.shape), id(norm))
+            if self._cached_ax is None or self._cached_ax[0] != key:
+                with torch.no_grad():
+                    self._cached_ax = (key, ops.spmm_raw(norm, x, "sum")[0])
+            out = ops.matmul(self._cached_ax[1], self.weight)
+        else:
+            out = ops.spmm(norm, ops.matmul(x, self.weight), "sum")
         if self.bias is not None:
             out = out + self.bias
         return out
