@@ -36,6 +36,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s
 
 HP = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=16384, proj_dim=256, kernel="rbf")
 MODEL = dict(hidden=256, layers=3, dropout=0.5, lr=0.01)
+# per-loss hyper-parameters of record for the secondary configs (scripts/run_gcn.sh:52-145, run_sage.sh)
+MODE_HP = {"lpw": dict(beta=100.0, kernel="rbf"), "gpw": dict(beta=100.0, kernel="cosine", max_samples=4096, proj_dim=128),
+           "kd": dict(alpha=0.9, kd_T=4.0)}
 
 
 def parse():
@@ -158,6 +161,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     hp = dict(HP, max_samples=args.max_samples)
+    if args.training in MODE_HP:
+        hp.update(MODE_HP[args.training])
 
     import efficient_gnns_amd  # noqa: F401  (fails loudly if libegnn_hip.so is missing)
     import efficient_gnns_amd.data as D
@@ -228,11 +233,13 @@ def main():
         ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True, scaling="strong", vs_baseline=None,
         dtype="f32", data="synthetic",
         config=dict(workload=f"ogbn-arxiv-shaped synthetic graph (N={d.num_nodes}, nnz_sym={d.adj_t.nnz()}), "
-                             f"3-layer {args.gnn.upper()}-256 student + {args.training} (G-CRD) loss, full-graph "
-                             f"train step + eval per epoch",
+                             f"3-layer {args.gnn.upper()}-256 student + {args.training}"
+                             f"{' (G-CRD)' if args.training == 'nce' else ''} loss, full-graph train step + eval per epoch",
                     gnn=args.gnn, training=args.training, hidden=MODEL["hidden"], layers=MODEL["layers"],
                     max_samples=hp["max_samples"], proj_dim=hp["proj_dim"], nce_T=hp["nce_T"], beta=hp["beta"],
-                    gemm_backend=ops.gemm_backend(), partitioning="single GPU"),
+                    gemm_backend=ops.gemm_backend(), partitioning="single GPU",
+                    memoise_first_layer_aggregation=os.environ.get("EGNN_GCN_MEMOISE_AX", "0") == "1",
+                    cache_constant_row_gathers=os.environ.get("EGNN_CACHE_CONST_ROWS", "0") == "1"),
         roofline=roofline, cpu_baseline=cpu,
         phases_ms=dict(train_step=round(train_ms / args.steps, 3), eval=round(eval_ms / args.steps, 3)),
         last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs],

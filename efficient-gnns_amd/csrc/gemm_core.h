@@ -19,8 +19,12 @@ namespace egnn_gemm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 16;
-constexpr int LDS_LD = BK + 4;  // floats per LDS row: 80 B keeps every row 16-byte aligned
+#ifndef EGNN_BK
+#define EGNN_BK 16
+#endif
+constexpr int BK = EGNN_BK;     // k-step per barrier (16 or 32)
+constexpr int LDS_LD = BK + 4;  // floats per LDS row: (BK+4)*4 B keeps every row 16-byte aligned
+constexpr int KQ = BK / 4;      // float4 per k-row segment
 
 constexpr int KMAJOR = 0;   // operand stored [rows, K] (k contiguous)
 constexpr int MNMAJOR = 1;  // operand stored [K, rows] (row index contiguous)
@@ -33,7 +37,8 @@ struct IdentityXf {
 // (value, global row, global k) on the way; out-of-range elements are exact zeros.
 template <int R, int MAJOR, bool VEC4, class XF>
 struct Stager {
-  static constexpr int NV = R / 64;
+  static constexpr int NV = R * BK / 1024;  // float4 per thread per k-step
+  static constexpr int RPP = 256 / KQ;        // k-major: rows covered per pass of the 256 threads
   float v[NV][4];
 
   // FULL: the whole R x BK tile is in range (block-uniform) -> straight-line vector loads, no per-element guards
@@ -44,8 +49,8 @@ struct Stager {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       if constexpr (MAJOR == KMAJOR) {
-        const int64_t r = r0 + (t >> 2) + 64 * i;
-        const int64_t k = k0 + (t & 3) * 4;
+        const int64_t r = r0 + t / KQ + RPP * i;
+        const int64_t k = k0 + (t % KQ) * 4;
         const float* q = p + r * ld + k;
         if constexpr (FULL) {
           float x0, x1, x2, x3;
@@ -89,7 +94,7 @@ struct Stager {
     for (int i = 0; i < NV; ++i) {
       const f32x4v x = {v[i][0], v[i][1], v[i][2], v[i][3]};
       if constexpr (MAJOR == KMAJOR) {
-        *reinterpret_cast<f32x4v*>(lds + ((t >> 2) + 64 * i) * LDS_LD + (t & 3) * 4) = x;
+        *reinterpret_cast<f32x4v*>(lds + (t / KQ + RPP * i) * LDS_LD + (t % KQ) * 4) = x;
       } else {
         constexpr int TPR = R / 4;
         constexpr int KPP = 256 / TPR;

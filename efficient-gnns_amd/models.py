@@ -7,6 +7,8 @@ signatures, ``convs`` / ``bns`` state_dict keys, ``.out_feat`` side channel); ``
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -82,12 +84,13 @@ def make_projection(in_dim, proj_dim):
 
 
 _ROW_CACHE: dict = {}
+_CACHE_CONST_ROWS = os.environ.get("EGNN_CACHE_CONST_ROWS", "0") == "1"  # opt-in (the reference re-gathers every step)
 
 
 def _const_rows(t, idx):
     """``t[idx]`` for a constant tensor (teacher artefacts): the reference re-gathers 273 MB every step (gnn.py:155);
     the rows do not change within a run, so the gather is done once per (tensor, index) identity + version."""
-    if t.requires_grad:
+    if t.requires_grad or not _CACHE_CONST_ROWS:
         return t[idx]
     key = (t.data_ptr(), t._version, tuple(t.shape), idx.data_ptr(), idx._version, idx.numel())
     hit = _ROW_CACHE.get(key)

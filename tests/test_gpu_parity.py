@@ -596,3 +596,46 @@ def test_fused_bn_dropout_mask_is_consistent_and_unbiased():
     bn.eval()
     ye = ops.bn_act(x.detach(), bn, relu=True, p=p)
     close(ye, torch.relu(bn(x.detach())), rtol=1e-4, atol_scale=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json configs[0]: PPI 2-layer GCN student, logit-KD, mini-batch = one graph (ppi_pyg/gnn.py:185-274)
+# ------------------------------------------------------------------------------------------------
+def test_ppi_gcn_kd_steps_vs_oracle():
+    train, _, _ = D.ppi_like(seed=1, n_train=3, total_train_nodes=2400)
+    torch.manual_seed(0)
+    om = OM.GCN(50, 64, 121, 2, 0.0, cached=False)
+    pm = PM.GCN(50, 64, 121, 2, 0.0, cached=False).to(DEV)
+    pm.load_state_dict(om.state_dict())
+    oo, po = torch.optim.Adam(om.parameters(), lr=0.005), torch.optim.Adam(pm.parameters(), lr=0.005)
+    for g in train:  # one optimisation step per graph, edge_index LongTensor input, BCE-with-logits KD
+        om.train(); pm.train()
+        ref = OC.ppi_kd_criterion(om(g.x, g.edge_index), g.y, g.teacher_logits, 0.5, 1.0)
+        oo.zero_grad(); ref[0].backward(); oo.step()
+        out = E.ppi_kd_criterion(pm(g.x.to(DEV), g.edge_index.to(DEV)), g.y.to(DEV), g.teacher_logits.to(DEV), 0.5, 1.0)
+        po.zero_grad(); out[0].backward(); po.step()
+        for a, b in zip(out, ref):
+            close(a, b, rtol=2e-4, atol_scale=0)
+    om.eval(); pm.eval()
+    g = train[0]
+    with torch.no_grad():
+        lo, lp = om(g.x, g.edge_index), pm(g.x.to(DEV), g.edge_index.to(DEV))
+    # micro-F1 inputs (ppi_pyg/gnn.py:285-288): predictions (out > 0) agree except on numerically-zero logits
+    agree = ((lo > 0) == (lp.cpu() > 0)).float().mean()
+    assert agree > 0.999
+
+
+def test_mag_shaped_mean_aggregation_properties():
+    """BASELINE.json configs[4] kernel: SAGE-mean aggregation on a MAG-shaped graph (mag_pyg/gnn.py:162), scaled."""
+    d = D.mag_like(scale=0.05, seed=0)
+    adj = d.adj_t.to(DEV)
+    x = d.x.to(DEV)
+    y, _ = ops.spmm_raw(adj, x, "mean")
+    rowptr, col, _ = adj.csr()
+    cnt = (rowptr[1:] - rowptr[:-1]).float()
+    ysum, _ = ops.spmm_raw(adj, x, "sum")
+    close(y * cnt.clamp(min=1).unsqueeze(1), ysum, rtol=1e-5)
+    for r in (0, int(torch.argmax(cnt)), d.num_nodes - 1):
+        s, e = int(rowptr[r]), int(rowptr[r + 1])
+        ref = x[col[s:e]].double().mean(0) if e > s else torch.zeros(x.shape[1], dtype=torch.float64, device=DEV)
+        close(y[r], ref, rtol=1e-5)
