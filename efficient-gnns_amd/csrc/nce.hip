@@ -10,12 +10,17 @@
 // flash-style recompute (3 GEMM passes instead of 4).
 // Backward: dfhat = c (P - I) that, dthat = c (P - I)^T fhat with P = exp(Z - lse): two GEMMs whose A
 // operand is transformed from Z while it is staged into LDS.
+#include <stdlib.h>
+
 #include "gemm_core.h"
 
 using namespace egnn_gemm;
 
 namespace {
 
+#ifndef EGNN_NCE_FWD_WAVES
+#define EGNN_NCE_FWD_WAVES 1  // waves per SIMD the forward kernel is compiled for (2 spills 47 floats per lane and measures the same)
+#endif
 constexpr int kMaxSplit = 8;
 constexpr int FB = 128;  // forward block tile (rows and columns)
 
@@ -26,8 +31,10 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float om, float os
   m = mn;
 }
 
-template <bool VEC4>
-__global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ fhat, int64_t ldf,
+// FIXED: rows are unit vectors, so every logit is <= 1/tau and that bound serves as the soft-max shift: one exp per
+// element and half the per-lane state of the online-max form (which costs a whole wave per SIMD in registers).
+template <bool VEC4, bool FIXED>
+__global__ __launch_bounds__(256, EGNN_NCE_FWD_WAVES) void nce_fwd_kernel(const float* __restrict__ fhat, int64_t ldf,
                                                       const float* __restrict__ that, int64_t ldt, int64_t Sr, int64_t Sc,
                                                       int64_t diag_off, int64_t P, float inv_tau,
                                                       float* __restrict__ Z, float* __restrict__ zdiag,
@@ -45,11 +52,15 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
   int64_t cb1 = cb0 + cb_per_split;
   if (cb1 > ncb) cb1 = ncb;
 
-  float rm[TS::TM][16], rs[TS::TM][16];
+  float rm[FIXED ? 1 : TS::TM][FIXED ? 1 : 16], rs[TS::TM][16];
+  const float shift = inv_tau * 1.0001f;
 #pragma unroll
   for (int tm = 0; tm < TS::TM; ++tm)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { rm[tm][r] = -INFINITY; rs[tm][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) {
+      if constexpr (!FIXED) rm[tm][r] = -INFINITY;
+      rs[tm][r] = 0.f;
+    }
 
   IdentityXf id;
   for (int64_t cb = cb0; cb < cb1; ++cb) {
@@ -76,11 +87,14 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
           zt[tn] = ok ? z : -INFINITY;
           mt = fmaxf(mt, zt[tn]);
         }
-        if (mt > -INFINITY) {
+        if constexpr (FIXED) {
+#pragma unroll
+          for (int tn = 0; tn < TS::TN; ++tn) rs[tm][r] += expf(zt[tn] - shift);  // exp(-inf) == 0 for masked columns
+        } else if (mt > -INFINITY) {
           const float mn = fmaxf(rm[tm][r], mt);
           float s = rs[tm][r] * expf(rm[tm][r] - mn);
 #pragma unroll
-          for (int tn = 0; tn < TS::TN; ++tn) s += expf(zt[tn] - mn);  // exp(-inf) == 0 for masked columns
+          for (int tn = 0; tn < TS::TN; ++tn) s += expf(zt[tn] - mn);
           rs[tm][r] = s;
           rm[tm][r] = mn;
         }
@@ -95,12 +109,19 @@ __global__ __launch_bounds__(256) void nce_fwd_kernel(const float* __restrict__ 
   for (int tm = 0; tm < TS::TM; ++tm) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      float m = rm[tm][r], s = rs[tm][r];
+      float m, s = rs[tm][r];
+      if constexpr (FIXED) {
+        m = shift;
 #pragma unroll
-      for (int o = 1; o < 32; o <<= 1) {
-        const float om = __shfl_xor(m, o);
-        const float os = __shfl_xor(s, o);
-        lse_merge(m, s, om, os);
+        for (int o = 1; o < 32; o <<= 1) s += __shfl_xor(s, o);
+      } else {
+        m = rm[tm][r];
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+          const float om = __shfl_xor(m, o);
+          const float os = __shfl_xor(s, o);
+          lse_merge(m, s, om, os);
+        }
       }
       if ((lane & 31) == 0) {
         const int lr = acc_row<FB, FB>(wm, tm, r, lane);
@@ -196,7 +217,10 @@ void launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag
                 int64_t P, int64_t ldb, float coef, const float* g, float* C, int64_t ldc, bool vec4, hipStream_t st) {
   const int64_t tiles_n = (P + 127) / 128;
   const int64_t t128 = ((M + 127) / 128) * tiles_n;
-  if (t128 >= 200) {
+  // 128-row tiles only when they still give every CU at least two workgroups (one wave per SIMD cannot hide its own
+  // staging); below that the 64-row tile doubles the workgroup count.  EGNN_NCE_BM128_MIN_TILES overrides (tuning).
+  static const int64_t min_tiles = getenv("EGNN_NCE_BM128_MIN_TILES") ? atoll(getenv("EGNN_NCE_BM128_MIN_TILES")) : 600;
+  if (t128 >= min_tiles) {
     if (vec4) hipLaunchKernelGGL((nce_bwd_kernel<128, AMAJ, true>), dim3((unsigned)t128), dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, Bm, P, ldb, coef, g, C, ldc);
     else hipLaunchKernelGGL((nce_bwd_kernel<128, AMAJ, false>), dim3((unsigned)t128), dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, Bm, P, ldb, coef, g, C, ldc);
   } else {  // fewer than ~one block per CU: halve the row tile
@@ -211,8 +235,8 @@ void launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag
 extern "C" size_t egnn_nce_ws_floats(int64_t S) { return (size_t)S * (1 + 2 * kMaxSplit); }
 
 extern "C" int egnn_nce_block_fwd_f32(const float* fhat, int64_t ld_f, const float* that, int64_t ld_t, int64_t Sr, int64_t Sc,
-                                      int64_t diag_off, int64_t P, float tau, float inv_count, float* Z, float* lse,
-                                      float* loss, float* ws, size_t ws_floats, void* stream) {
+                                      int64_t diag_off, int64_t P, float tau, float inv_count, int unit_rows, float* Z,
+                                      float* lse, float* loss, float* ws, size_t ws_floats, void* stream) {
   EGNN_CHECK_ARG(Sr > 0 && Sc > 0 && P > 0 && ld_f >= P && ld_t >= P && tau > 0.f && fhat && that && lse && loss && ws);
   EGNN_CHECK_ARG(diag_off >= 0 && diag_off + Sr <= Sc);
   if (ws_floats < egnn_nce_ws_floats(Sr)) return EGNN_EWORKSPACE;
@@ -230,8 +254,12 @@ extern "C" int egnn_nce_block_fwd_f32(const float* fhat, int64_t ld_f, const flo
   float* ps = pm + Sr * kMaxSplit;
   const bool vec4 = (ld_f % 4 == 0) && (ld_t % 4 == 0) && egnn_aligned16(fhat) && egnn_aligned16(that);
   dim3 grid((unsigned)rb, (unsigned)nsplit);
-  if (vec4) hipLaunchKernelGGL(nce_fwd_kernel<true>, grid, dim3(256), 0, st, fhat, ld_f, that, ld_t, Sr, Sc, diag_off, P, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split);
-  else hipLaunchKernelGGL(nce_fwd_kernel<false>, grid, dim3(256), 0, st, fhat, ld_f, that, ld_t, Sr, Sc, diag_off, P, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split);
+  // the bound 1/tau is a usable shift while exp(-2/tau) stays a normal float (tau >= 0.025 leaves ample room)
+  const bool fixed = unit_rows && (2.f / tau) <= 80.f;
+#define EGNN_NCE_FWD(V, F) hipLaunchKernelGGL((nce_fwd_kernel<V, F>), grid, dim3(256), 0, st, fhat, ld_f, that, ld_t, Sr, Sc, diag_off, P, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split)
+  if (vec4) { if (fixed) EGNN_NCE_FWD(true, true); else EGNN_NCE_FWD(true, false); }
+  else { if (fixed) EGNN_NCE_FWD(false, true); else EGNN_NCE_FWD(false, false); }
+#undef EGNN_NCE_FWD
   hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(1024), 0, st, pm, ps, zdiag, Sr, nsplit, inv_count, lse, loss);
   return egnn_launch_status();
 }
@@ -249,9 +277,9 @@ extern "C" int egnn_nce_block_bwd_f32(const float* fhat, int64_t ld_f, const flo
   return egnn_launch_status();
 }
 
-extern "C" int egnn_nce_fwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,
+extern "C" int egnn_nce_fwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau, int unit_rows,
                                 float* Z, float* lse, float* loss, float* ws, size_t ws_floats, void* stream) {
-  return egnn_nce_block_fwd_f32(fhat, ld, that, ld, S, S, 0, P, tau, S > 0 ? 1.f / (float)S : 0.f, Z, lse, loss, ws, ws_floats, stream);
+  return egnn_nce_block_fwd_f32(fhat, ld, that, ld, S, S, 0, P, tau, S > 0 ? 1.f / (float)S : 0.f, unit_rows, Z, lse, loss, ws, ws_floats, stream);
 }
 
 extern "C" int egnn_nce_bwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,

@@ -290,7 +290,7 @@ class _NCE(torch.autograd.Function):
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         nws = lib.egnn_nce_ws_floats(S)
         ws = torch.empty(nws, dtype=torch.float32, device=dev)
-        rc = lib.egnn_nce_fwd_f32(_lib.ptr(fhat), _lib.ptr(that), S, P, fhat.stride(0), float(tau), _lib.ptr(Z), _lib.ptr(lse),
+        rc = lib.egnn_nce_fwd_f32(_lib.ptr(fhat), _lib.ptr(that), S, P, fhat.stride(0), float(tau), 1, _lib.ptr(Z), _lib.ptr(lse),
                                   _lib.ptr(loss), _lib.ptr(ws), nws, _lib.stream())
         _lib.check(rc, "egnn_nce_fwd_f32")
         ctx.save_for_backward(fhat, that, Z, lse)
@@ -315,7 +315,7 @@ def nce_unit(fhat: Tensor, that: Tensor, tau: float) -> Tensor:
     return _NCE.apply(fhat, that, tau)
 
 
-def nce_block_fwd(fhat: Tensor, t_all: Tensor, diag_off: int, tau: float, inv_count: float):
+def nce_block_fwd(fhat: Tensor, t_all: Tensor, diag_off: int, tau: float, inv_count: float, unit_rows: bool = True):
     """Row block of the G-CRD loss (egnn_nce_block_fwd_f32): returns (Z [Sr,Sc], lse [Sr], loss_sum*inv_count [1])."""
     _lib.require_gpu(fhat, t_all)
     Sr, P = fhat.shape
@@ -327,7 +327,7 @@ def nce_block_fwd(fhat: Tensor, t_all: Tensor, diag_off: int, tau: float, inv_co
     nws = lib.egnn_nce_ws_floats(Sr)
     ws = torch.empty(nws, dtype=torch.float32, device=dev)
     rc = lib.egnn_nce_block_fwd_f32(_lib.ptr(fhat), fhat.stride(0), _lib.ptr(t_all), t_all.stride(0), Sr, Sc, diag_off, P, float(tau),
-                                    float(inv_count), _lib.ptr(Z), _lib.ptr(lse), _lib.ptr(loss), _lib.ptr(ws), nws, _lib.stream())
+                                    float(inv_count), int(unit_rows), _lib.ptr(Z), _lib.ptr(lse), _lib.ptr(loss), _lib.ptr(ws), nws, _lib.stream())
     _lib.check(rc, "egnn_nce_block_fwd_f32")
     return Z, lse, loss
 

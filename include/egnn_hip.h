@@ -166,10 +166,13 @@ int egnn_normalize_rows_bwd_f32(const float* xhat, int64_t ldh, const float* dou
  * fwd: Z tiles are produced on the fp32 MFMA, the row log-sum-exp is accumulated online per lane and
  *      merged in a fixed order; Z is written to `Z` ([S,S], ld = S) for the backward when Z != NULL.
  *      lse [S] and the scalar loss are outputs.  ws: egnn_nce_ws_floats(S) floats.
+ *      unit_rows != 0 asserts ||fhat_i|| = ||that_j|| = 1 (what criterion.py:139-140 guarantees): logits are then
+ *      bounded by 1/tau and that bound replaces the running row maximum (one exp per element, half the state);
+ *      with unit_rows == 0 (or tau < 0.025) the general online-max form runs.
  * bwd: dfhat = g/(S tau) (P - I) that ; dthat = g/(S tau) (P - I)^T fhat, P = exp(Z - lse); g device scalar.
  *      Requires the Z written by fwd. */
 size_t egnn_nce_ws_floats(int64_t S);
-int egnn_nce_fwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,
+int egnn_nce_fwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau, int unit_rows,
                      float* Z, float* lse, float* loss, float* ws, size_t ws_floats, void* stream);
 int egnn_nce_bwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,
                      const float* Z, const float* lse, const float* g,
@@ -181,8 +184,8 @@ int egnn_nce_bwd_f32(const float* fhat, const float* that, int64_t S, int64_t P,
  * dfhat [Sr,P] is complete, dthat [Sc,P] is this rank's contribution (all-reduce it); scale = 1 / (S_total * tau).
  * Z is [Sr,Sc] (ld = Sc); ws: egnn_nce_ws_floats(Sr). */
 int egnn_nce_block_fwd_f32(const float* fhat, int64_t ld_f, const float* that, int64_t ld_t, int64_t Sr, int64_t Sc,
-                           int64_t diag_off, int64_t P, float tau, float inv_count, float* Z, float* lse, float* loss,
-                           float* ws, size_t ws_floats, void* stream);
+                           int64_t diag_off, int64_t P, float tau, float inv_count, int unit_rows, float* Z, float* lse,
+                           float* loss, float* ws, size_t ws_floats, void* stream);
 int egnn_nce_block_bwd_f32(const float* fhat, int64_t ld_f, const float* that, int64_t ld_t, int64_t Sr, int64_t Sc,
                            int64_t diag_off, int64_t P, float scale, const float* Z, const float* lse, const float* g,
                            float* dfhat, int64_t ld_df, float* dthat, int64_t ld_dt, void* stream);

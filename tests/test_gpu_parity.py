@@ -639,3 +639,25 @@ def test_mag_shaped_mean_aggregation_properties():
         s, e = int(rowptr[r]), int(rowptr[r + 1])
         ref = x[col[s:e]].double().mean(0) if e > s else torch.zeros(x.shape[1], dtype=torch.float64, device=DEV)
         close(y[r], ref, rtol=1e-5)
+
+
+@pytest.mark.parametrize("Sr,Sc,off,P", [(100, 300, 37, 48), (256, 2048, 1024, 256), (77, 77, 0, 20), (513, 1100, 587, 128)])
+def test_nce_row_block_kernels_vs_torch(Sr, Sc, off, P):
+    """The sharded G-CRD pieces (egnn_nce_block_*): a rank's Sr rows against all Sc teacher rows, positives at i+off."""
+    g = torch.Generator().manual_seed(Sr + Sc)
+    f = torch.nn.functional.normalize(torch.randn(Sr, P, generator=g), dim=-1)
+    t = torch.nn.functional.normalize(torch.randn(Sc, P, generator=g) + 0.1, dim=-1)
+    tau, S_total = 0.075, 4096
+    fd, td = f.double().requires_grad_(True), t.double().requires_grad_(True)
+    z = fd @ td.t() / tau
+    lse = torch.logsumexp(z, dim=1)
+    loss_ref = (lse - z[torch.arange(Sr), torch.arange(Sr) + off]).sum() / S_total
+    loss_ref.backward()
+    Z, lse_k, loss = ops.nce_block_fwd(f.to(DEV), t.to(DEV), off, tau, 1.0 / S_total)
+    close(loss[0], loss_ref, rtol=2e-5, atol_scale=0)
+    close(lse_k, lse, rtol=1e-5, atol_scale=1e-6)
+    close(Z, z, rtol=1e-5, atol_scale=1e-6)
+    gscale = torch.tensor([0.7], device=DEV)
+    df, dt = ops.nce_block_bwd(f.to(DEV), t.to(DEV), off, 1.0 / (S_total * tau), Z, lse_k, gscale)
+    close(df, 0.7 * fd.grad, rtol=1e-4, atol_scale=2e-5)
+    close(dt, 0.7 * td.grad, rtol=1e-4, atol_scale=2e-5)
