@@ -104,12 +104,12 @@ class SpmmProbe:
         self._orig = ops.spmm_raw
 
     def __enter__(self):
-        def wrapped(adj, x, reduce="sum", src_scale=None, use_plan=True):
+        def wrapped(adj, x, *args, **kw):
             if not self.active:
-                return self._orig(adj, x, reduce, src_scale, use_plan)
+                return self._orig(adj, x, *args, **kw)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            out = self._orig(adj, x, reduce, src_scale, use_plan)
+            out = self._orig(adj, x, *args, **kw)
             b.record()
             self.records.append((x.shape[1], adj.nnz(), adj.spmm_algorithmic_bytes(x.shape[1]), a, b))
             return out

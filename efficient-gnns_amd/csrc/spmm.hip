@@ -26,6 +26,7 @@ struct SpmmArgs {
   const IdxT* col;
   const float* val;
   const float* src_scale;
+  const float* bias;  // optional [K], added to every written row (GCNConv's `out += bias`)
   const float* X;
   int64_t ldx;
   float* Y;
@@ -143,9 +144,11 @@ __device__ __forceinline__ void store_row(const SpmmArgs<IdxT>& a, int64_t row, 
       ap[q] = arg[q];
     }
   } else if constexpr (VEC == 4) {
-    *reinterpret_cast<float4*>(yp) = make_float4(acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv);
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + col0);
+    *reinterpret_cast<float4*>(yp) = make_float4(acc[0] * inv + b.x, acc[1] * inv + b.y, acc[2] * inv + b.z, acc[3] * inv + b.w);
   } else {
-    yp[0] = acc[0] * inv;
+    yp[0] = acc[0] * inv + (a.bias ? a.bias[col0] : 0.f);
   }
 }
 
@@ -340,7 +343,10 @@ __global__ __launch_bounds__(256) void spmm_short_rows_kernel(const SpmmArgs<Idx
       if (live && colok) {
         const int64_t cnt = end - start;
         const float inv = a.mean ? 1.f / (float)(cnt > 0 ? cnt : 1) : 1.f;
-        *reinterpret_cast<float4*>(a.Y + row * a.ldy + col0) = make_float4(acc0 * inv, acc1 * inv, acc2 * inv, acc3 * inv);
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + col0);
+        *reinterpret_cast<float4*>(a.Y + row * a.ldy + col0) =
+            make_float4(acc0 * inv + b.x, acc1 * inv + b.y, acc2 * inv + b.z, acc3 * inv + b.w);
       }
     }
   }
@@ -449,8 +455,8 @@ __global__ void spmm_max_bwd_kernel(int64_t total, int64_t K, const IdxT* col, c
 }  // namespace
 
 extern "C" int egnn_spmm_csr_f32(int64_t n_rows, int64_t n_src, int64_t K, const void* rowptr, const void* col,
-                                 int index_bits, const float* val, const float* src_scale, const float* X, int64_t ldx,
-                                 float* Y, int64_t ldy, int reduce, int64_t* argmax, const int64_t* short_rows,
+                                 int index_bits, const float* val, const float* src_scale, const float* bias, const float* X,
+                                 int64_t ldx, float* Y, int64_t ldy, int reduce, int64_t* argmax, const int64_t* short_rows,
                                  int64_t n_short, const int64_t* mid_rows, int64_t n_mid, const int64_t* long_rows,
                                  int64_t n_long, void* stream) {
   EGNN_CHECK_ARG(n_rows >= 0 && n_src >= 0 && K >= 0 && ldx >= K && ldy >= K);
@@ -459,6 +465,7 @@ extern "C" int egnn_spmm_csr_f32(int64_t n_rows, int64_t n_src, int64_t K, const
   if (n_rows == 0 || K == 0) return EGNN_OK;
   EGNN_CHECK_ARG(rowptr && col && X && Y);
   EGNN_CHECK_ARG(reduce != EGNN_MAX || argmax != nullptr);
+  EGNN_CHECK_ARG(bias == nullptr || (reduce != EGNN_MAX && (K % 4 != 0 || egnn_aligned16(bias))));
   EGNN_CHECK_ARG(n_short >= 0 && n_mid >= 0 && n_long >= 0);
   EGNN_CHECK_ARG((n_short == 0 || short_rows) && (n_mid == 0 || mid_rows) && (n_long == 0 || long_rows));
   const bool planned = short_rows || mid_rows || long_rows;
@@ -466,11 +473,11 @@ extern "C" int egnn_spmm_csr_f32(int64_t n_rows, int64_t n_src, int64_t K, const
   const RowPlan plan{short_rows, n_short, mid_rows, n_mid, long_rows, n_long};
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (index_bits == 32) {
-    SpmmArgs<int32_t> a{n_rows, K, (const int32_t*)rowptr, (const int32_t*)col, val, src_scale, X, ldx, Y, ldy,
+    SpmmArgs<int32_t> a{n_rows, K, (const int32_t*)rowptr, (const int32_t*)col, val, src_scale, bias, X, ldx, Y, ldy,
                         reduce == EGNN_MEAN, argmax, nullptr, 0, 0, 0, 0};
     return dispatch(a, reduce, plan, st);
   }
-  SpmmArgs<int64_t> a{n_rows, K, (const int64_t*)rowptr, (const int64_t*)col, val, src_scale, X, ldx, Y, ldy,
+  SpmmArgs<int64_t> a{n_rows, K, (const int64_t*)rowptr, (const int64_t*)col, val, src_scale, bias, X, ldx, Y, ldy,
                       reduce == EGNN_MEAN, argmax, nullptr, 0, 0, 0, 0};
   return dispatch(a, reduce, plan, st);
 }

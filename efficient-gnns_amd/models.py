@@ -109,10 +109,10 @@ def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_
     if mode == "kd":
         return C.kd_criterion(out, labels, _const_rows(teacher_logits, train_idx), hp["alpha"], hp["kd_T"])
     if mode in ("fitnet", "gpw", "nce"):
-        f = student_proj(model.out_feat[train_idx])
+        f = student_proj(ops.take_rows(model.out_feat, train_idx))
         t = teacher_proj(_const_rows(teacher_out_feat, train_idx))
     elif mode in ("at", "lpw"):
-        f, t = model.out_feat[train_idx], _const_rows(teacher_out_feat, train_idx)
+        f, t = ops.take_rows(model.out_feat, train_idx), _const_rows(teacher_out_feat, train_idx)
     elif mode == "gcd":
         f = student_proj(model.out_feat, adj_t)[train_idx]
         t = teacher_proj(teacher_out_feat, adj_t)[train_idx]
@@ -142,7 +142,7 @@ def train_step(model, x, adj_t, y, train_idx, optimizer, mode, hp, teacher_out_f
     for p in (student_proj, teacher_proj):
         if p is not None:
             p.train()
-    out = model(x, adj_t)[train_idx]
+    out = ops.take_rows(model(x, adj_t), train_idx)   # == model(...)[train_idx] (split ids are unique)
     labels = y.squeeze(1)[train_idx]
     loss, loss_cls, loss_aux = distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_logits, hp,
                                             student_proj, teacher_proj, edge_index, adj_t, kd_and_aux)

@@ -87,11 +87,8 @@ class GCNConv(nn.Module):
                 with torch.no_grad():
                     self._cached_ax = (key, ops.spmm_raw(norm, x, "sum")[0])
             out = ops.matmul(self._cached_ax[1], self.weight)
-        else:
-            out = ops.spmm(norm, ops.matmul(x, self.weight), "sum")
-        if self.bias is not None:
-            out = out + self.bias
-        return out
+            return out + self.bias if self.bias is not None else out
+        return ops.spmm(norm, ops.matmul(x, self.weight), "sum", bias=self.bias)  # bias added in the kernel's store
 
     def __repr__(self):
         return f"GCNConv({self.in_channels}, {self.out_channels})"

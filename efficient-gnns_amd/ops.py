@@ -35,7 +35,8 @@ def _rowmajor(x: Tensor) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 # SpMM
 # ------------------------------------------------------------------------------------------------
-def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = None, use_plan: bool = True):
+def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = None, use_plan: bool = True,
+             bias: Tensor | None = None):
     """Y = REDUCE(adj, X) on the GPU (egnn_spmm_csr_f32).  Returns (Y, argmax | None)."""
     _lib.require_gpu(x, adj._col)
     x = _rowmajor(x)
@@ -56,7 +57,7 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
     def launch(s, m, l, stream):
         (ps, ns), (pm, nm), (pl, nl) = lst(s), lst(m), lst(l)
         return lib.egnn_spmm_csr_f32(
-            n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), bits, _lib.ptr(adj._value), _lib.ptr(src_scale),
+            n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), bits, _lib.ptr(adj._value), _lib.ptr(src_scale), _lib.ptr(bias),
             _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), red, _lib.ptr(arg), ps, ns, pm, nm, pl, nl, stream)
 
     heavy = use_plan and short is not None and short.numel() > 0 and (mid.numel() + long_.numel()) > 0
@@ -73,7 +74,7 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
         join = torch.cuda.Event()
         join.record(side)
         main.wait_event(join)
-        for t in (x, y, arg, adj._value, src_scale):
+        for t in (x, y, arg, adj._value, src_scale, bias):
             if t is not None:
                 t.record_stream(side)
     else:
@@ -84,9 +85,9 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
 
 class _SpMM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, adj, reduce):
-        y, arg = spmm_raw(adj, x, reduce)
-        ctx.adj, ctx.reduce = adj, reduce
+    def forward(ctx, x, adj, reduce, bias=None):
+        y, arg = spmm_raw(adj, x, reduce, bias=None if bias is None else bias.detach().contiguous())
+        ctx.adj, ctx.reduce, ctx.has_bias = adj, reduce, bias is not None
         if arg is not None:
             ctx.save_for_backward(arg)
         return y
@@ -109,13 +110,38 @@ class _SpMM(torch.autograd.Function):
             rc = _lib.load().egnn_spmm_csr_max_bwd_f32(n_rows, K, _lib.ptr(col), bits, _lib.ptr(adj._value), _lib.ptr(arg),
                                                        _lib.ptr(gy), gy.stride(0), _lib.ptr(gx), gx.stride(0), _lib.stream())
             _lib.check(rc, "egnn_spmm_csr_max_bwd_f32")
-        return gx, None, None
+        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        return gx, None, None, gb
 
 
-def spmm(adj, x: Tensor, reduce: str = "sum") -> Tensor:
+def spmm(adj, x: Tensor, reduce: str = "sum", bias: Tensor | None = None) -> Tensor:
+    """adj @ x with the given reduction; ``bias`` ([K]) is added in the kernel's store (sum / mean only)."""
     if reduce not in _REDUCE:
         raise ValueError(f"unknown reduce '{reduce}'")
-    return _SpMM.apply(x, adj, reduce)
+    if bias is not None and (reduce == "max" or (x.shape[1] % 4 == 0 and bias.data_ptr() % 16 != 0)):
+        return _SpMM.apply(x, adj, reduce, None) + bias
+    return _SpMM.apply(x, adj, reduce, bias)
+
+
+class _TakeRows(torch.autograd.Function):
+    """x[idx] for UNIQUE row ids: the backward is a plain scatter (ATen's index backward sorts the ids every step)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.n = x.shape[0]
+        return x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gx = torch.zeros(ctx.n, *g.shape[1:], dtype=g.dtype, device=g.device)
+        gx.index_copy_(0, idx, g)
+        return gx, None
+
+
+def take_rows(x: Tensor, idx: Tensor) -> Tensor:
+    return _TakeRows.apply(x, idx)
 
 
 # ------------------------------------------------------------------------------------------------

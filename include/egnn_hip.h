@@ -41,7 +41,7 @@ const char* egnn_error_string(int code);
 int egnn_build_info(char* buf, size_t buf_bytes);
 
 /* ------------------------------------------------------------------------------------------------
- * Neighbour aggregation: Y[i,:] = REDUCE_{e in row i} val[e] * src_scale[col[e]] * X[col[e],:]
+ * Neighbour aggregation: Y[i,:] = REDUCE_{e in row i} val[e] * src_scale[col[e]] * X[col[e],:]  (+ bias)
  *
  * Replaces torch_sparse::spmm (K1/K2 in SURVEY.md 2.2), reached from
  *   GCNConv.forward      /root/reference/arxiv_pyg/gnn.py:47,52   (reduce=sum, val = gcn_norm)
@@ -54,6 +54,7 @@ int egnn_build_info(char* buf, size_t buf_bytes);
  * val        [nnz]    nullable (= 1.0)
  * src_scale  [n_src]  nullable; per-source-row factor, used for the backward of mean
  *                     (dX = A^T (dY / cnt)) without materialising a per-entry value array
+ * bias       [K]      nullable; added to every written row (GCNConv `out += bias`, gnn.py:47); not with EGNN_MAX
  * argmax     [n_rows, K] int64, required for EGNN_MAX, ignored otherwise
  * Row schedule (built once per sparsity structure by the caller; integer preprocessing):
  *   short_rows [n_short]  row ids whose entry count is small; a wavefront walks 64/G of them at once (one
@@ -72,7 +73,7 @@ int egnn_build_info(char* buf, size_t buf_bytes);
 
 int egnn_spmm_csr_f32(int64_t n_rows, int64_t n_src, int64_t K,
                       const void* rowptr, const void* col, int index_bits,
-                      const float* val, const float* src_scale,
+                      const float* val, const float* src_scale, const float* bias,
                       const float* X, int64_t ldx, float* Y, int64_t ldy,
                       int reduce, int64_t* argmax,
                       const int64_t* short_rows, int64_t n_short, const int64_t* mid_rows, int64_t n_mid,

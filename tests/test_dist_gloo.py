@@ -29,7 +29,8 @@ def _patch_ops_with_oracle():
         rowptr, col, val = adj.csr()
         return OS.SparseTensor(rowptr=rowptr, col=col, value=val, sparse_sizes=adj.sparse_sizes())
 
-    ops.spmm = lambda adj, x, reduce="sum": OS.matmul(to_oracle(adj), x, reduce)
+    ops.spmm = lambda adj, x, reduce="sum", bias=None: OS.matmul(to_oracle(adj), x, reduce) + (0 if bias is None else bias)
+    ops.take_rows = lambda x, idx: x[idx]
     ops.matmul = lambda x, w: x @ w
     ops.linear = lambda x, w, b=None: F.linear(x, w, b)
     ops.cross_entropy = lambda logits, labels: F.cross_entropy(logits, labels)
