@@ -35,9 +35,11 @@ SIGNATURES = {
     "egnn_normalize_rows_bwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _f32, _p, _i64, _i32, _p]),
     "egnn_nce_ws_floats": (_sz, [_i64]),
     "egnn_nce_fwd_f32": (_i32, [_p, _p, _i64, _i64, _i64, _f32, _i32, _p, _p, _p, _p, _sz, _p]),
-    "egnn_nce_bwd_f32": (_i32, [_p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _p, _p, _p]),
+    "egnn_nce_saves_exp": (_i32, [_f32, _i32]),
+    "egnn_nce_bwd_ws_floats": (_sz, [_i64, _i64, _i64]),
+    "egnn_nce_bwd_f32": (_i32, [_p, _p, _i64, _i64, _i64, _f32, _i32, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "egnn_nce_block_fwd_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _i32, _p, _p, _p, _p, _sz, _p]),
-    "egnn_nce_block_bwd_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _f32, _p, _p, _p, _p, _i64, _p, _i64, _p]),
+    "egnn_nce_block_bwd_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _i32, _p, _p, _p, _p, _i64, _p, _i64, _p, _sz, _p]),
     "egnn_gsp_ws_floats": (_sz, [_i64]),
     "egnn_gsp_fwd_f32": (_i32, [_p, _i64, _i64, _p, _i64, _i64, _i64, _i32, _p, _p, _p, _p, _sz, _p]),
     "egnn_rowsum_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p]),

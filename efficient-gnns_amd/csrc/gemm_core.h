@@ -80,11 +80,18 @@ struct Stager {
     }
   }
 
+  // FULLONLY: the caller guarantees that every tile is in range (the slow path is not even compiled: its loop-invariant
+  // masks and addresses otherwise get hoisted into the caller's loops and cost ~100 registers)
+  template <bool FULLONLY = false>
   __device__ __forceinline__ void load(const float* __restrict__ p, int64_t ld, int64_t r0, int64_t rmax, int64_t k0,
                                        int64_t kmax, const XF& xf) {
-    const bool full = (r0 + R <= rmax) && (k0 + BK <= kmax);  // block-uniform
-    if (full) load_impl<true>(p, ld, r0, rmax, k0, kmax, xf);
-    else load_impl<false>(p, ld, r0, rmax, k0, kmax, xf);
+    if constexpr (FULLONLY) {
+      load_impl<true>(p, ld, r0, rmax, k0, kmax, xf);
+    } else {
+      const bool full = (r0 + R <= rmax) && (k0 + BK <= kmax);  // block-uniform
+      if (full) load_impl<true>(p, ld, r0, rmax, k0, kmax, xf);
+      else load_impl<false>(p, ld, r0, rmax, k0, kmax, xf);
+    }
   }
 
   // LDS image: KMAJOR -> [R][LDS_LD] ; MNMAJOR -> [BK][R + 4]   (both fit in R * LDS_LD floats)
@@ -135,7 +142,7 @@ __device__ __forceinline__ int acc_col(int wn, int tn, int lane) {
 }
 
 // acc += A[m0:m0+BM, kbeg:kend] * B[kbeg:kend, n0:n0+BN]   (all 256 threads must call with equal bounds)
-template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, class XFA, class XFB, int TM_, int TN_>
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY = false, class XFA, class XFB, int TM_, int TN_>
 __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM_][TN_],
                                          const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
                                          const float* __restrict__ B, int64_t ldb, int64_t n0, int64_t N,
@@ -153,8 +160,8 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM_][TN_],
   const int wave = egnn_wave_id();
   const int wm = wave >> 1, wn = wave & 1;
 
-  sa.load(A, lda, m0, M, kbeg, kend, xfa);
-  sb.load(B, ldb, n0, N, kbeg, kend, xfb);
+  sa.template load<FULLONLY>(A, lda, m0, M, kbeg, kend, xfa);
+  sb.template load<FULLONLY>(B, ldb, n0, N, kbeg, kend, xfb);
   sa.store(smem);
   sb.store(smem + B_OFF);
   __syncthreads();
@@ -162,8 +169,8 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM_][TN_],
     const int cur = kt & 1;
     const bool more = kt + 1 < nk;
     if (more) {
-      sa.load(A, lda, m0, M, kbeg + (int64_t)(kt + 1) * BK, kend, xfa);
-      sb.load(B, ldb, n0, N, kbeg + (int64_t)(kt + 1) * BK, kend, xfb);
+      sa.template load<FULLONLY>(A, lda, m0, M, kbeg + (int64_t)(kt + 1) * BK, kend, xfa);
+      sb.template load<FULLONLY>(B, ldb, n0, N, kbeg + (int64_t)(kt + 1) * BK, kend, xfb);
     }
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {

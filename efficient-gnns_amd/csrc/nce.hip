@@ -5,11 +5,16 @@
 // Forward: one workgroup owns 128 rows and walks a contiguous range of 128-column blocks; every lane
 // keeps an ONLINE (max, sum-exp) pair for each of its 32 accumulator rows, so the soft-max statistics
 // never leave registers until the block is done; lanes / waves / column splits are then merged in a
-// fixed order.  Z is written once (fp32) for the backward: with the fp32 MFMA at 1/16 of the bf16 rate
-// a stored Z (HBM has room for it and the traffic hides under the matrix pipe) is cheaper than the
+// fixed order.  The scores are written once (fp32) for the backward: with the fp32 MFMA at 1/16 of the bf16 rate
+// a stored [S,S] matrix (HBM has room for it and the traffic hides under the matrix pipe) is cheaper than the
 // flash-style recompute (3 GEMM passes instead of 4).
-// Backward: dfhat = c (P - I) that, dthat = c (P - I)^T fhat with P = exp(Z - lse): two GEMMs whose A
-// operand is transformed from Z while it is staged into LDS.
+// Backward: dfhat = c (P - I) that, dthat = c (P - I)^T fhat with P = exp(Z - lse).
+//   general form : Z is stored; two GEMMs whose A operand is transformed from Z while it is staged into LDS;
+//   unit rows    : every logit is <= 1/tau, so the forward already evaluates E = exp(Z - shift) with the constant
+//                  shift = 1.0001/tau for the row sums.  It stores E instead of Z, and with w_i = exp(shift - lse_i)
+//                  = 1 / sum_j E_ij the backward needs no exp at all:
+//                      dfhat_i = c (w_i (E that)_i - that_{i+off}),  dthat_j = c ((E^T (w o fhat))_j - fhat_{j-off})
+//                  i.e. two plain GEMMs on E with a row scale on one side (one exp per 4 staged elements of fhat).
 #include <stdlib.h>
 
 #include "gemm_core.h"
@@ -18,11 +23,13 @@ using namespace egnn_gemm;
 
 namespace {
 
-#ifndef EGNN_NCE_FWD_WAVES
-#define EGNN_NCE_FWD_WAVES 1  // waves per SIMD the forward kernel is compiled for (2 spills 47 floats per lane and measures the same)
-#endif
 constexpr int kMaxSplit = 8;
 constexpr int FB = 128;  // forward block tile (rows and columns)
+
+// the constant soft-max shift of the unit-rows form; forward and backward must evaluate it identically
+__device__ __forceinline__ float nce_shift(float inv_tau) { return inv_tau * 1.0001f; }
+// the bound 1/tau is a usable shift while exp(-2/tau) stays a normal float (tau >= 0.025 leaves ample room)
+inline bool nce_unit_form(float tau, int unit_rows) { return unit_rows && (2.f / tau) <= 80.f; }
 
 __device__ __forceinline__ void lse_merge(float& m, float& s, float om, float os) {
   const float mn = fmaxf(m, om);
@@ -33,8 +40,10 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float om, float os
 
 // FIXED: rows are unit vectors, so every logit is <= 1/tau and that bound serves as the soft-max shift: one exp per
 // element and half the per-lane state of the online-max form (which costs a whole wave per SIMD in registers).
-template <bool VEC4, bool FIXED>
-__global__ __launch_bounds__(256, EGNN_NCE_FWD_WAVES) void nce_fwd_kernel(const float* __restrict__ fhat, int64_t ldf,
+// ALIGNED: Sr and Sc are multiples of the tile, P of the k-step and the operands are float4-addressable (the sampled
+// G-CRD problem: 16384 x 16384 x 256); no edge handling is compiled into that variant.
+template <bool VEC4, bool FIXED, bool ALIGNED>
+__global__ __launch_bounds__(256, ALIGNED ? 3 : 1) void nce_fwd_kernel(const float* __restrict__ fhat, int64_t ldf,
                                                       const float* __restrict__ that, int64_t ldt, int64_t Sr, int64_t Sc,
                                                       int64_t diag_off, int64_t P, float inv_tau,
                                                       float* __restrict__ Z, float* __restrict__ zdiag,
@@ -53,7 +62,7 @@ __global__ __launch_bounds__(256, EGNN_NCE_FWD_WAVES) void nce_fwd_kernel(const 
   if (cb1 > ncb) cb1 = ncb;
 
   float rm[FIXED ? 1 : TS::TM][FIXED ? 1 : 16], rs[TS::TM][16];
-  const float shift = inv_tau * 1.0001f;
+  const float shift = nce_shift(inv_tau);
 #pragma unroll
   for (int tm = 0; tm < TS::TM; ++tm)
 #pragma unroll
@@ -67,21 +76,63 @@ __global__ __launch_bounds__(256, EGNN_NCE_FWD_WAVES) void nce_fwd_kernel(const 
     const int64_t j0 = cb * FB;
     f32x16 acc[TS::TM][TS::TN];
     zero_acc(acc);
-    mainloop<FB, FB, KMAJOR, KMAJOR, VEC4>(acc, fhat, ldf, i0, Sr, that, ldt, j0, Sc, 0, P, id, id, smem);
+    mainloop<FB, FB, KMAJOR, KMAJOR, VEC4, ALIGNED>(acc, fhat, ldf, i0, Sr, that, ldt, j0, Sc, 0, P, id, id, smem);
+    // The epilogue addresses are functions of loop-invariant quantities (i0, Sc); left alone, the compiler hoists one
+    // 64-bit pointer per accumulator row out of the column-block loop (~150 registers, one wave per SIMD).  Laundering
+    // the two scalars through an empty asm makes it recompute them per tile instead (a few dozen scalar ops).
+    int64_t sc = Sc, ib = i0;
+    asm volatile("" : "+s"(sc), "+s"(ib));
+    const bool interior = ALIGNED || ((ib + FB <= Sr) && (j0 + FB <= sc));  // block-uniform
+    if (FIXED && interior && (ALIGNED || sc < (1LL << 28))) {
+      // interior tile of the unit-rows form: wave-uniform row bases + one 32-bit lane offset, no per-element guards
+      float* zb = Z ? Z + (ib + wm * TS::WM) * sc + (j0 + wn * TS::WN) : nullptr;
+      const unsigned voff = (unsigned)(4 * (lane >> 5)) * (unsigned)sc + (unsigned)(lane & 31);
+#pragma unroll
+      for (int tm = 0; tm < TS::TM; ++tm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* zr = zb + (int64_t)(tm * 32 + (r & 3) + 8 * (r >> 2)) * sc;
+#pragma unroll
+          for (int tn = 0; tn < TS::TN; ++tn) {
+            const float e = expf(acc[tm][tn][r] * inv_tau - shift);
+            if (ALIGNED || Z) zr[voff + tn * 32] = e;  // the aligned variant is only launched with Z != NULL
+            rs[tm][r] += e;
+          }
+          __builtin_amdgcn_sched_barrier(0);  // one row at a time: keeps the 64 exp chains from being interleaved (registers)
+        }
+      }
+      if (j0 < ib + diag_off + FB && ib + diag_off < j0 + FB) {  // the tile crosses the diagonal of positives
+        // element (lr, lc) of the tile is a positive iff lr - lc == d; split into a lane part and a wave-uniform part
+        // (32-bit: |d| < FB here) so that nothing per-row survives outside this rarely taken branch
+        const int d = (int)(j0 - ib - diag_off);
+        const int lv = 4 * (lane >> 5) - (lane & 31);
+#pragma unroll
+        for (int tm = 0; tm < TS::TM; ++tm)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ur = wm * TS::WM + tm * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+            for (int tn = 0; tn < TS::TN; ++tn)
+              if (lv == d - (ur - wn * TS::WN - tn * 32)) zdiag[ib + ur + 4 * (lane >> 5)] = acc[tm][tn][r] * inv_tau;
+          }
+      }
+      continue;
+    }
+    if constexpr (!(ALIGNED && FIXED))
 #pragma unroll
     for (int tm = 0; tm < TS::TM; ++tm) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = i0 + acc_row<FB, FB>(wm, tm, r, lane);
+        const int64_t row = ib + acc_row<FB, FB>(wm, tm, r, lane);
         float zt[TS::TN];
         float mt = -INFINITY;
 #pragma unroll
         for (int tn = 0; tn < TS::TN; ++tn) {
           const int64_t c = j0 + acc_col<FB, FB>(wn, tn, lane);
           const float z = acc[tm][tn][r] * inv_tau;
-          const bool ok = row < Sr && c < Sc;
+          const bool ok = row < Sr && c < sc;
           if (ok) {
-            if (Z) Z[row * Sc + c] = z;
+            if (Z) Z[row * sc + c] = FIXED ? expf(z - shift) : z;
             if (row + diag_off == c) zdiag[row] = z;
           }
           zt[tn] = ok ? z : -INFINITY;
@@ -98,6 +149,7 @@ __global__ __launch_bounds__(256, EGNN_NCE_FWD_WAVES) void nce_fwd_kernel(const 
           rs[tm][r] = s;
           rm[tm][r] = mn;
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -176,28 +228,79 @@ struct NceGradXf {
   }
 };
 
-// C[M, N=P] = scale * xf(Z or Z^T) [M,Kd] * B[Kd,P]   (B row-major, n contiguous; Z is [Sr,Sc], ld = Sc)
-template <int BM, int AMAJ, bool VEC4>
+// B-operand transform of the unit-rows backward: row k of fhat scaled by w_k = exp(shift - lse_k) = 1 / sum_j E_kj
+struct RowWeightXf {
+  const float* lse;
+  float shift;
+  __device__ __forceinline__ float operator()(float v, int64_t, int64_t k) const { return v * expf(shift - lse[k]); }
+};
+
+// C[M, N=P] = scale * (P - I or its transpose) [M,Kd] * B[Kd,P]   (B row-major, n contiguous; ZE is [Sr,Sc], ld = Sc)
+//   EXPZ = false: ZE holds Z, the A operand is transformed (NceGradXf) on its way into LDS
+//   EXPZ = true : ZE holds E = exp(Z - shift); A is staged as it is, the row weights and the "- I" term are applied
+//                 to B (AMAJ == MNMAJOR, i.e. the teacher side) or in the epilogue
+// epilogue shared by the GEMM kernel (one k range) and the split-K reduce: v = sum_k A_mk B_kc for element (row, c)
+template <int AMAJ, bool EXPZ>
+__device__ __forceinline__ float nce_bwd_finish(float v, int64_t row, int64_t c, int64_t Kd, int64_t diag_off,
+                                                const float* __restrict__ lse, float shift, const float* __restrict__ Im,
+                                                int64_t ldi, float scale) {
+  if constexpr (EXPZ) {
+    // Im = the matrix whose rows the "- I" term picks: that (student side, row i -> i + off) or fhat (row j -> j - off)
+    if constexpr (AMAJ == KMAJOR) {
+      v = v * expf(shift - lse[row]) - Im[(row + diag_off) * ldi + c];
+    } else {
+      const int64_t i = row - diag_off;
+      if (i >= 0 && i < Kd) v -= Im[i * ldi + c];
+    }
+  }
+  return scale * v;
+}
+
+template <int BM, int AMAJ, bool VEC4, bool EXPZ>
 __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ Z, int64_t ldz, int64_t M, int64_t Kd,
-                                                      int64_t diag_off, const float* __restrict__ lse,
+                                                      int64_t diag_off, const float* __restrict__ lse, float shift,
                                                       const float* __restrict__ Bm, int64_t P, int64_t ldb,
+                                                      const float* __restrict__ Im, int64_t ldi,
                                                       float coef, const float* __restrict__ g, float* __restrict__ C,
-                                                      int64_t ldc) {
+                                                      int64_t ldc, int64_t k_per_split, float* __restrict__ ws) {
   constexpr int BN = 128;
   using TS = TileShape<BM, BN>;
   __shared__ __attribute__((aligned(16))) float smem[TS::SMEM_FLOATS];
   const int64_t tiles_n = (P + BN - 1) / BN;
-  const int64_t m0 = (blockIdx.x / tiles_n) * BM;
-  const int64_t n0 = (blockIdx.x % tiles_n) * BN;
+  const int64_t tiles = (int64_t)gridDim.x;
+  // workgroup b runs on XCD b % 8: keep the column tiles of one row tile on the same XCD and next to each other in
+  // time, so that the second read of the (large) A tile hits that XCD's L2
+  int64_t mt, nt;
+  if (tiles_n > 1 && tiles % (8 * tiles_n) == 0) {
+    nt = (blockIdx.x >> 3) % tiles_n;
+    mt = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * tiles_n));
+  } else {
+    mt = blockIdx.x / tiles_n;
+    nt = blockIdx.x % tiles_n;
+  }
+  const int64_t m0 = mt * BM, n0 = nt * BN;
+  const int64_t kbeg = (int64_t)blockIdx.y * k_per_split;
+  int64_t kend = kbeg + k_per_split;
+  if (kend > Kd) kend = Kd;
   f32x16 acc[TS::TM][TS::TN];
   zero_acc(acc);
-  NceGradXf xf{lse, AMAJ == MNMAJOR, diag_off};
   IdentityXf id;
-  mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, 0, Kd, xf, id, smem);
+  if constexpr (!EXPZ) {
+    NceGradXf xf{lse, AMAJ == MNMAJOR, diag_off};
+    mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, kbeg, kend, xf, id, smem);
+  } else if constexpr (AMAJ == KMAJOR) {
+    mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, kbeg, kend, id, id, smem);
+  } else {
+    RowWeightXf xw{lse, shift};
+    mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, kbeg, kend, id, xw, smem);
+  }
   const int lane = egnn_lane();
   const int wave = egnn_wave_id();
   const int wm = wave >> 1, wn = wave & 1;
+  const bool partial = gridDim.y > 1;
   const float scale = coef * (g ? g[0] : 1.f);
+  float* out = partial ? ws + (int64_t)blockIdx.y * M * P : C;
+  const int64_t ldo = partial ? P : ldc;
 #pragma unroll
   for (int tn = 0; tn < TS::TN; ++tn) {
     const int64_t c = n0 + acc_col<BM, BN>(wn, tn, lane);
@@ -207,32 +310,82 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + acc_row<BM, BN>(wm, tm, r, lane);
-        if (row < M) C[row * ldc + c] = scale * acc[tm][tn][r];
+        if (row >= M) continue;
+        const float v = acc[tm][tn][r];
+        out[row * ldo + c] = partial ? v : nce_bwd_finish<AMAJ, EXPZ>(v, row, c, Kd, diag_off, lse, shift, Im, ldi, scale);
       }
   }
 }
 
+// fixed-order sum of the split-K partials + the epilogue
+template <int AMAJ, bool EXPZ>
+__global__ __launch_bounds__(256) void nce_bwd_reduce_kernel(const float* __restrict__ ws, int nsplit, int64_t M, int64_t P, int64_t Kd,
+                                                             int64_t diag_off, const float* __restrict__ lse, float shift,
+                                                             const float* __restrict__ Im, int64_t ldi, float coef,
+                                                             const float* __restrict__ g, float* __restrict__ C, int64_t ldc) {
+  const int64_t total = M * P;
+  const float scale = coef * (g ? g[0] : 1.f);
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    float v = 0.f;
+    for (int k = 0; k < nsplit; ++k) v += ws[(int64_t)k * total + t];
+    const int64_t row = t / P, c = t % P;
+    C[row * ldc + c] = nce_bwd_finish<AMAJ, EXPZ>(v, row, c, Kd, diag_off, lse, shift, Im, ldi, scale);
+  }
+}
+
+// split-K factor of a backward GEMM with M output rows over a reduction of Kd: aim at >= 3 workgroups of 128 x 128 per CU
+inline int nce_bwd_split(int64_t M, int64_t P, int64_t Kd) {
+  const int64_t t128 = ((M + 127) / 128) * ((P + 127) / 128);
+  int64_t n = (768 + t128 - 1) / t128;
+  const int64_t ksteps = (Kd + BK - 1) / BK;
+  if (n > ksteps / 8) n = ksteps / 8;  // at least 8 k-steps per split
+  if (n > kMaxSplit) n = kMaxSplit;
+  return n < 1 ? 1 : (int)n;
+}
+
 template <int AMAJ>
-void launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag_off, const float* lse, const float* Bm,
-                int64_t P, int64_t ldb, float coef, const float* g, float* C, int64_t ldc, bool vec4, hipStream_t st) {
+void launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag_off, const float* lse, float shift, bool expz,
+                const float* Bm, int64_t P, int64_t ldb, const float* Im, int64_t ldi, float coef, const float* g, float* C,
+                int64_t ldc, bool vec4, float* ws, hipStream_t st) {
   const int64_t tiles_n = (P + 127) / 128;
   const int64_t t128 = ((M + 127) / 128) * tiles_n;
-  // 128-row tiles only when they still give every CU at least two workgroups (one wave per SIMD cannot hide its own
-  // staging); below that the 64-row tile doubles the workgroup count.  EGNN_NCE_BM128_MIN_TILES overrides (tuning).
+  // With a workspace the reduction is split so that every CU gets ~3 workgroups of 128 x 128 (fixed-order reduce
+  // afterwards).  Without one: 128-row tiles only when they still give every CU at least two workgroups (one wave per
+  // SIMD cannot hide its own staging), else the 64-row tile doubles the workgroup count.
   static const int64_t min_tiles = getenv("EGNN_NCE_BM128_MIN_TILES") ? atoll(getenv("EGNN_NCE_BM128_MIN_TILES")) : 600;
-  if (t128 >= min_tiles) {
-    if (vec4) hipLaunchKernelGGL((nce_bwd_kernel<128, AMAJ, true>), dim3((unsigned)t128), dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, Bm, P, ldb, coef, g, C, ldc);
-    else hipLaunchKernelGGL((nce_bwd_kernel<128, AMAJ, false>), dim3((unsigned)t128), dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, Bm, P, ldb, coef, g, C, ldc);
-  } else {  // fewer than ~one block per CU: halve the row tile
-    const int64_t t64 = ((M + 63) / 64) * tiles_n;
-    if (vec4) hipLaunchKernelGGL((nce_bwd_kernel<64, AMAJ, true>), dim3((unsigned)t64), dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, Bm, P, ldb, coef, g, C, ldc);
-    else hipLaunchKernelGGL((nce_bwd_kernel<64, AMAJ, false>), dim3((unsigned)t64), dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, Bm, P, ldb, coef, g, C, ldc);
+  const int nsplit = ws ? nce_bwd_split(M, P, Kd) : 1;
+  const bool big = ws || t128 >= min_tiles;
+  const int64_t ksteps = (Kd + BK - 1) / BK;
+  const int64_t k_per_split = ((ksteps + nsplit - 1) / nsplit) * BK;
+  const dim3 grid((unsigned)(big ? t128 : ((M + 63) / 64) * tiles_n), (unsigned)nsplit);
+#define EGNN_NCE_BWD(BM_, V, E) hipLaunchKernelGGL((nce_bwd_kernel<BM_, AMAJ, V, E>), grid, dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, shift, Bm, P, ldb, Im, ldi, coef, g, C, ldc, k_per_split, ws)
+  if (big) {
+    if (vec4) { if (expz) EGNN_NCE_BWD(128, true, true); else EGNN_NCE_BWD(128, true, false); }
+    else { if (expz) EGNN_NCE_BWD(128, false, true); else EGNN_NCE_BWD(128, false, false); }
+  } else {
+    if (vec4) { if (expz) EGNN_NCE_BWD(64, true, true); else EGNN_NCE_BWD(64, true, false); }
+    else { if (expz) EGNN_NCE_BWD(64, false, true); else EGNN_NCE_BWD(64, false, false); }
+  }
+#undef EGNN_NCE_BWD
+  if (nsplit > 1) {
+    const int64_t blocks = (M * P + 255) / 256;
+    const dim3 rgrid((unsigned)(blocks < 4096 ? blocks : 4096));
+    if (expz) hipLaunchKernelGGL((nce_bwd_reduce_kernel<AMAJ, true>), rgrid, dim3(256), 0, st, ws, nsplit, M, P, Kd, diag_off, lse, shift, Im, ldi, coef, g, C, ldc);
+    else hipLaunchKernelGGL((nce_bwd_reduce_kernel<AMAJ, false>), rgrid, dim3(256), 0, st, ws, nsplit, M, P, Kd, diag_off, lse, shift, Im, ldi, coef, g, C, ldc);
   }
 }
 
 }  // namespace
 
 extern "C" size_t egnn_nce_ws_floats(int64_t S) { return (size_t)S * (1 + 2 * kMaxSplit); }
+
+extern "C" size_t egnn_nce_bwd_ws_floats(int64_t Sr, int64_t Sc, int64_t P) {
+  if (Sr <= 0 || Sc <= 0 || P <= 0) return 0;
+  const size_t a = (size_t)nce_bwd_split(Sr, P, Sc) * Sr * P, b = (size_t)nce_bwd_split(Sc, P, Sr) * Sc * P;
+  return a > b ? a : b;
+}
+
+extern "C" int egnn_nce_saves_exp(float tau, int unit_rows) { return tau > 0.f && nce_unit_form(tau, unit_rows) ? 1 : 0; }
 
 extern "C" int egnn_nce_block_fwd_f32(const float* fhat, int64_t ld_f, const float* that, int64_t ld_t, int64_t Sr, int64_t Sc,
                                       int64_t diag_off, int64_t P, float tau, float inv_count, int unit_rows, float* Z,
@@ -254,26 +407,32 @@ extern "C" int egnn_nce_block_fwd_f32(const float* fhat, int64_t ld_f, const flo
   float* ps = pm + Sr * kMaxSplit;
   const bool vec4 = (ld_f % 4 == 0) && (ld_t % 4 == 0) && egnn_aligned16(fhat) && egnn_aligned16(that);
   dim3 grid((unsigned)rb, (unsigned)nsplit);
-  // the bound 1/tau is a usable shift while exp(-2/tau) stays a normal float (tau >= 0.025 leaves ample room)
-  const bool fixed = unit_rows && (2.f / tau) <= 80.f;
-#define EGNN_NCE_FWD(V, F) hipLaunchKernelGGL((nce_fwd_kernel<V, F>), grid, dim3(256), 0, st, fhat, ld_f, that, ld_t, Sr, Sc, diag_off, P, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split)
-  if (vec4) { if (fixed) EGNN_NCE_FWD(true, true); else EGNN_NCE_FWD(true, false); }
-  else { if (fixed) EGNN_NCE_FWD(false, true); else EGNN_NCE_FWD(false, false); }
+  const bool fixed = nce_unit_form(tau, unit_rows);
+  const bool aligned = Z && vec4 && fixed && Sr % FB == 0 && Sc % FB == 0 && P % BK == 0 && Sc < (1LL << 28);
+#define EGNN_NCE_FWD(V, F, A) hipLaunchKernelGGL((nce_fwd_kernel<V, F, A>), grid, dim3(256), 0, st, fhat, ld_f, that, ld_t, Sr, Sc, diag_off, P, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split)
+  if (aligned) EGNN_NCE_FWD(true, true, true);
+  else if (vec4) { if (fixed) EGNN_NCE_FWD(true, true, false); else EGNN_NCE_FWD(true, false, false); }
+  else { if (fixed) EGNN_NCE_FWD(false, true, false); else EGNN_NCE_FWD(false, false, false); }
 #undef EGNN_NCE_FWD
   hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(1024), 0, st, pm, ps, zdiag, Sr, nsplit, inv_count, lse, loss);
   return egnn_launch_status();
 }
 
 extern "C" int egnn_nce_block_bwd_f32(const float* fhat, int64_t ld_f, const float* that, int64_t ld_t, int64_t Sr, int64_t Sc,
-                                      int64_t diag_off, int64_t P, float scale, const float* Z, const float* lse, const float* g,
-                                      float* dfhat, int64_t ld_df, float* dthat, int64_t ld_dt, void* stream) {
-  EGNN_CHECK_ARG(Sr > 0 && Sc > 0 && P > 0 && ld_f >= P && ld_t >= P && fhat && that && Z && lse);
+                                      int64_t diag_off, int64_t P, float tau, float scale, int unit_rows, const float* Z,
+                                      const float* lse, const float* g, float* dfhat, int64_t ld_df, float* dthat, int64_t ld_dt,
+                                      float* ws, size_t ws_floats, void* stream) {
+  EGNN_CHECK_ARG(Sr > 0 && Sc > 0 && P > 0 && ld_f >= P && ld_t >= P && tau > 0.f && fhat && that && Z && lse);
+  if (ws && ws_floats < egnn_nce_bwd_ws_floats(Sr, Sc, P)) return EGNN_EWORKSPACE;
+  EGNN_CHECK_ARG(diag_off >= 0 && diag_off + Sr <= Sc);
   EGNN_CHECK_ARG((dfhat == nullptr || ld_df >= P) && (dthat == nullptr || ld_dt >= P));
   hipStream_t st = (hipStream_t)stream;
   const bool vec4 = (ld_f % 4 == 0) && (ld_t % 4 == 0) && (Sc % 4 == 0) && egnn_aligned16(fhat) && egnn_aligned16(that) && egnn_aligned16(Z);
+  const bool expz = nce_unit_form(tau, unit_rows);   // what the forward stored in Z
+  const float shift = (1.f / tau) * 1.0001f;         // == nce_shift(inv_tau) of the forward
   // dfhat [Sr,P] = scale g (P - I) that ;  dthat [Sc,P] = scale g (P - I)^T fhat
-  if (dfhat) launch_bwd<KMAJOR>(Z, Sc, Sr, Sc, diag_off, lse, that, P, ld_t, scale, g, dfhat, ld_df, vec4, st);
-  if (dthat) launch_bwd<MNMAJOR>(Z, Sc, Sc, Sr, diag_off, lse, fhat, P, ld_f, scale, g, dthat, ld_dt, vec4, st);
+  if (dfhat) launch_bwd<KMAJOR>(Z, Sc, Sr, Sc, diag_off, lse, shift, expz, that, P, ld_t, that, ld_t, scale, g, dfhat, ld_df, vec4, ws, st);
+  if (dthat) launch_bwd<MNMAJOR>(Z, Sc, Sc, Sr, diag_off, lse, shift, expz, fhat, P, ld_f, fhat, ld_f, scale, g, dthat, ld_dt, vec4, ws, st);
   return egnn_launch_status();
 }
 
@@ -282,9 +441,10 @@ extern "C" int egnn_nce_fwd_f32(const float* fhat, const float* that, int64_t S,
   return egnn_nce_block_fwd_f32(fhat, ld, that, ld, S, S, 0, P, tau, S > 0 ? 1.f / (float)S : 0.f, unit_rows, Z, lse, loss, ws, ws_floats, stream);
 }
 
-extern "C" int egnn_nce_bwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,
+extern "C" int egnn_nce_bwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau, int unit_rows,
                                 const float* Z, const float* lse, const float* g, float* dfhat, float* dthat,
-                                void* stream) {
+                                float* ws, size_t ws_floats, void* stream) {
   EGNN_CHECK_ARG(S > 0 && tau > 0.f);
-  return egnn_nce_block_bwd_f32(fhat, ld, that, ld, S, S, 0, P, 1.f / ((float)S * tau), Z, lse, g, dfhat, ld, dthat, ld, stream);
+  return egnn_nce_block_bwd_f32(fhat, ld, that, ld, S, S, 0, P, tau, 1.f / ((float)S * tau), unit_rows, Z, lse, g, dfhat, ld, dthat,
+                                ld, ws, ws_floats, stream);
 }

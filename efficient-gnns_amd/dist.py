@@ -256,7 +256,7 @@ class _DistNCE(torch.autograd.Function):
         df = torch.zeros_like(fhat)
         if Sr > 0:
             Z, lse = saved[2], saved[3]
-            df, dt_all = ops.nce_block_bwd(fhat, t_all, off, 1.0 / (S * tau), Z, lse, g.contiguous().to(torch.float32))
+            df, dt_all = ops.nce_block_bwd(fhat, t_all, off, 1.0 / (S * tau), Z, lse, g.contiguous().to(torch.float32), tau)
         dist.all_reduce(dt_all, group=group)  # every row block contributes to every teacher row
         return df, dt_all[off:off + Sr].contiguous(), None, None, None, None
 

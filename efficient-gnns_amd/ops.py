@@ -330,8 +330,11 @@ class _NCE(torch.autograd.Function):
         g = g.contiguous().to(torch.float32)
         df = torch.empty_like(fhat) if ctx.needs_input_grad[0] else None
         dt = torch.empty_like(that) if ctx.needs_input_grad[1] else None
-        rc = _lib.load().egnn_nce_bwd_f32(_lib.ptr(fhat), _lib.ptr(that), S, P, fhat.stride(0), ctx.tau, _lib.ptr(Z), _lib.ptr(lse),
-                                          _lib.ptr(g), _lib.ptr(df), _lib.ptr(dt), _lib.stream())
+        lib = _lib.load()
+        nws = lib.egnn_nce_bwd_ws_floats(S, S, P)
+        ws = torch.empty(nws, dtype=torch.float32, device=fhat.device)
+        rc = lib.egnn_nce_bwd_f32(_lib.ptr(fhat), _lib.ptr(that), S, P, fhat.stride(0), ctx.tau, 1, _lib.ptr(Z), _lib.ptr(lse),
+                                  _lib.ptr(g), _lib.ptr(df), _lib.ptr(dt), _lib.ptr(ws), nws, _lib.stream())
         _lib.check(rc, "egnn_nce_bwd_f32")
         return df, dt, None
 
@@ -342,7 +345,9 @@ def nce_unit(fhat: Tensor, that: Tensor, tau: float) -> Tensor:
 
 
 def nce_block_fwd(fhat: Tensor, t_all: Tensor, diag_off: int, tau: float, inv_count: float, unit_rows: bool = True):
-    """Row block of the G-CRD loss (egnn_nce_block_fwd_f32): returns (Z [Sr,Sc], lse [Sr], loss_sum*inv_count [1])."""
+    """Row block of the G-CRD loss (egnn_nce_block_fwd_f32): returns (Z [Sr,Sc], lse [Sr], loss_sum*inv_count [1]).
+    Z is the saved score matrix for nce_block_bwd: logits, or exp(logit - 1.0001/tau) in the unit-rows form
+    (egnn_nce_saves_exp); pass the same tau / unit_rows to the backward."""
     _lib.require_gpu(fhat, t_all)
     Sr, P = fhat.shape
     Sc = t_all.shape[0]
@@ -358,14 +363,17 @@ def nce_block_fwd(fhat: Tensor, t_all: Tensor, diag_off: int, tau: float, inv_co
     return Z, lse, loss
 
 
-def nce_block_bwd(fhat: Tensor, t_all: Tensor, diag_off: int, scale: float, Z: Tensor, lse: Tensor, g: Tensor):
+def nce_block_bwd(fhat: Tensor, t_all: Tensor, diag_off: int, scale: float, Z: Tensor, lse: Tensor, g: Tensor, tau: float,
+                  unit_rows: bool = True):
     """(dfhat [Sr,P], this rank's contribution to dthat_all [Sc,P]) via egnn_nce_block_bwd_f32."""
     Sr, P = fhat.shape
     Sc = t_all.shape[0]
     df, dt = torch.empty_like(fhat), torch.empty_like(t_all)
+    nws = _lib.load().egnn_nce_bwd_ws_floats(Sr, Sc, P)
+    ws = torch.empty(nws, dtype=torch.float32, device=fhat.device)
     rc = _lib.load().egnn_nce_block_bwd_f32(_lib.ptr(fhat), fhat.stride(0), _lib.ptr(t_all), t_all.stride(0), Sr, Sc, diag_off, P,
-                                            float(scale), _lib.ptr(Z), _lib.ptr(lse), _lib.ptr(g), _lib.ptr(df), df.stride(0),
-                                            _lib.ptr(dt), dt.stride(0), _lib.stream())
+                                            float(tau), float(scale), int(unit_rows), _lib.ptr(Z), _lib.ptr(lse), _lib.ptr(g), _lib.ptr(df), df.stride(0),
+                                            _lib.ptr(dt), dt.stride(0), _lib.ptr(ws), nws, _lib.stream())
     _lib.check(rc, "egnn_nce_block_bwd_f32")
     return df, dt
 

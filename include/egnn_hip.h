@@ -165,31 +165,40 @@ int egnn_normalize_rows_bwd_f32(const float* xhat, int64_t ldh, const float* dou
 /* G-CRD / InfoNCE, /root/reference/arxiv_pyg/criterion.py:139-145:
  *   Z = fhat that^T / tau  ([S,S]);  loss = mean_i( logsumexp_j Z_ij - Z_ii ).
  * fwd: Z tiles are produced on the fp32 MFMA, the row log-sum-exp is accumulated online per lane and
- *      merged in a fixed order; Z is written to `Z` ([S,S], ld = S) for the backward when Z != NULL.
+ *      merged in a fixed order; the scores are saved in `Z` ([S,S], ld = S) for the backward when Z != NULL.
  *      lse [S] and the scalar loss are outputs.  ws: egnn_nce_ws_floats(S) floats.
  *      unit_rows != 0 asserts ||fhat_i|| = ||that_j|| = 1 (what criterion.py:139-140 guarantees): logits are then
  *      bounded by 1/tau and that bound replaces the running row maximum (one exp per element, half the state);
  *      with unit_rows == 0 (or tau < 0.025) the general online-max form runs.
- * bwd: dfhat = g/(S tau) (P - I) that ; dthat = g/(S tau) (P - I)^T fhat, P = exp(Z - lse); g device scalar.
- *      Requires the Z written by fwd. */
+ *      What `Z` holds: the logits Z_ij in the general form; E_ij = exp(Z_ij - 1.0001/tau) in the unit-rows form
+ *      (egnn_nce_saves_exp(tau, unit_rows) tells which) -- the forward needs E for the row sums anyway, and with
+ *      w_i = exp(1.0001/tau - lse_i) the backward becomes two exp-free GEMMs on E.
+ * bwd: dfhat = g/(S tau) (P - I) that ; dthat = g/(S tau) (P - I)^T fhat, P = exp(Z - lse) = diag(w) E; g device
+ *      scalar.  Requires the `Z` written by fwd and the SAME tau / unit_rows.
+ *      ws (nullable): egnn_nce_bwd_ws_floats(S, S, P) floats.  With it the two GEMMs (reduction length S, only
+ *      S*P outputs) split their reduction over enough workgroups to fill the chip and sum the partials in a fixed
+ *      order; without it they fall back to smaller row tiles. */
 size_t egnn_nce_ws_floats(int64_t S);
+size_t egnn_nce_bwd_ws_floats(int64_t Sr, int64_t Sc, int64_t P);
+int egnn_nce_saves_exp(float tau, int unit_rows);
 int egnn_nce_fwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau, int unit_rows,
                      float* Z, float* lse, float* loss, float* ws, size_t ws_floats, void* stream);
-int egnn_nce_bwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau,
+int egnn_nce_bwd_f32(const float* fhat, const float* that, int64_t S, int64_t P, int64_t ld, float tau, int unit_rows,
                      const float* Z, const float* lse, const float* g,
-                     float* dfhat, float* dthat, void* stream);
+                     float* dfhat, float* dthat, float* ws, size_t ws_floats, void* stream);
 
 /* Row-block form of the two entry points above, for node-range sharding: this rank owns Sr of the
  * S_total sampled rows, `that` holds ALL Sc = S_total teacher rows (all-gathered over RCCL), and the positive of
  * local row i is column i + diag_off.  loss = inv_count * sum_i (lse_i - Z_i,i+off)  (pass 1/S_total and all-reduce);
  * dfhat [Sr,P] is complete, dthat [Sc,P] is this rank's contribution (all-reduce it); scale = 1 / (S_total * tau).
- * Z is [Sr,Sc] (ld = Sc); ws: egnn_nce_ws_floats(Sr). */
+ * Z is [Sr,Sc] (ld = Sc); fwd ws: egnn_nce_ws_floats(Sr); bwd ws (nullable): egnn_nce_bwd_ws_floats(Sr, Sc, P). */
 int egnn_nce_block_fwd_f32(const float* fhat, int64_t ld_f, const float* that, int64_t ld_t, int64_t Sr, int64_t Sc,
                            int64_t diag_off, int64_t P, float tau, float inv_count, int unit_rows, float* Z, float* lse,
                            float* loss, float* ws, size_t ws_floats, void* stream);
 int egnn_nce_block_bwd_f32(const float* fhat, int64_t ld_f, const float* that, int64_t ld_t, int64_t Sr, int64_t Sc,
-                           int64_t diag_off, int64_t P, float scale, const float* Z, const float* lse, const float* g,
-                           float* dfhat, int64_t ld_df, float* dthat, int64_t ld_dt, void* stream);
+                           int64_t diag_off, int64_t P, float tau, float scale, int unit_rows, const float* Z,
+                           const float* lse, const float* g, float* dfhat, int64_t ld_df, float* dthat, int64_t ld_dt,
+                           float* ws, size_t ws_floats, void* stream);
 
 /* GSP all-pairs similarity loss, /root/reference/arxiv_pyg/criterion.py:69-88:
  *   loss = mean_ij (k(xs_i,xs_j) - k(xt_i,xt_j))^2 ; kernel: EGNN_K_COSINE / _POLY (rows must be unit vectors,

@@ -47,7 +47,7 @@ def _patch_ops_with_oracle():
         diag = z[torch.arange(z.shape[0]), torch.arange(z.shape[0]) + off]
         return z, lse, ((lse - diag).sum() * inv_count).reshape(1)
 
-    def nce_block_bwd(fhat, t_all, off, scale, Z, lse, g):
+    def nce_block_bwd(fhat, t_all, off, scale, Z, lse, g, tau=None, unit_rows=True):
         p = torch.exp(Z - lse[:, None])
         p[torch.arange(Z.shape[0]), torch.arange(Z.shape[0]) + off] -= 1.0
         return scale * g * (p @ t_all), scale * g * (p.t() @ fhat)

@@ -13,6 +13,7 @@ import efficient_gnns_amd.data as D
 import efficient_gnns_amd.criterion as PC
 import efficient_gnns_amd.models as PM
 import efficient_gnns_amd.ops as ops
+from efficient_gnns_amd import _lib
 import oracle.criterion as OC
 import oracle.models as OM
 import oracle.nn as ON
@@ -642,9 +643,11 @@ def test_mag_shaped_mean_aggregation_properties():
         close(y[r], ref, rtol=1e-5)
 
 
+@pytest.mark.parametrize("unit_rows", [True, False])
 @pytest.mark.parametrize("Sr,Sc,off,P", [(100, 300, 37, 48), (256, 2048, 1024, 256), (77, 77, 0, 20), (513, 1100, 587, 128)])
-def test_nce_row_block_kernels_vs_torch(Sr, Sc, off, P):
-    """The sharded G-CRD pieces (egnn_nce_block_*): a rank's Sr rows against all Sc teacher rows, positives at i+off."""
+def test_nce_row_block_kernels_vs_torch(Sr, Sc, off, P, unit_rows):
+    """The sharded G-CRD pieces (egnn_nce_block_*): a rank's Sr rows against all Sc teacher rows, positives at i+off.
+    Both forms of the saved score matrix: logits (general) and exp(logit - 1.0001/tau) (unit rows)."""
     g = torch.Generator().manual_seed(Sr + Sc)
     f = torch.nn.functional.normalize(torch.randn(Sr, P, generator=g), dim=-1)
     t = torch.nn.functional.normalize(torch.randn(Sc, P, generator=g) + 0.1, dim=-1)
@@ -654,11 +657,26 @@ def test_nce_row_block_kernels_vs_torch(Sr, Sc, off, P):
     lse = torch.logsumexp(z, dim=1)
     loss_ref = (lse - z[torch.arange(Sr), torch.arange(Sr) + off]).sum() / S_total
     loss_ref.backward()
-    Z, lse_k, loss = ops.nce_block_fwd(f.to(DEV), t.to(DEV), off, tau, 1.0 / S_total)
+    Z, lse_k, loss = ops.nce_block_fwd(f.to(DEV), t.to(DEV), off, tau, 1.0 / S_total, unit_rows=unit_rows)
     close(loss[0], loss_ref, rtol=2e-5, atol_scale=0)
     close(lse_k, lse, rtol=1e-5, atol_scale=1e-6)
-    close(Z, z, rtol=1e-5, atol_scale=1e-6)
+    saves_exp = bool(_lib.load().egnn_nce_saves_exp(tau, int(unit_rows)))
+    assert saves_exp == unit_rows
+    if saves_exp:
+        shift = float(np.float32(np.float32(1.0) / np.float32(tau)) * np.float32(1.0001))
+        close(Z, torch.exp(z - shift), rtol=1e-4, atol_scale=1e-6)
+    else:
+        close(Z, z, rtol=1e-5, atol_scale=1e-6)
     gscale = torch.tensor([0.7], device=DEV)
-    df, dt = ops.nce_block_bwd(f.to(DEV), t.to(DEV), off, 1.0 / (S_total * tau), Z, lse_k, gscale)
+    df, dt = ops.nce_block_bwd(f.to(DEV), t.to(DEV), off, 1.0 / (S_total * tau), Z, lse_k, gscale, tau, unit_rows=unit_rows)
     close(df, 0.7 * fd.grad, rtol=1e-4, atol_scale=2e-5)
     close(dt, 0.7 * td.grad, rtol=1e-4, atol_scale=2e-5)
+    # the same backward without a workspace (no split-K; smaller row tiles) must agree
+    df2, dt2 = torch.empty_like(df), torch.empty_like(dt)
+    fg, tg = f.to(DEV), t.to(DEV)
+    rc = _lib.load().egnn_nce_block_bwd_f32(_lib.ptr(fg), P, _lib.ptr(tg), P, Sr, Sc, off, P, tau, 1.0 / (S_total * tau), int(unit_rows),
+                                            _lib.ptr(Z), _lib.ptr(lse_k), _lib.ptr(gscale), _lib.ptr(df2), P, _lib.ptr(dt2), P,
+                                            None, 0, _lib.stream())
+    assert rc == 0
+    close(df2, df, rtol=1e-5, atol_scale=2e-6)
+    close(dt2, dt, rtol=1e-5, atol_scale=2e-6)
