@@ -3,7 +3,7 @@
 // Block tile BM x BN, 256 threads = 4 waves in a 2 x 2 arrangement, each wave owning
 // (BM/2) x (BN/2) as TM x TN MFMA tiles of 32 x 32.  K is consumed in steps of BK = 16 through two
 // LDS buffers; global loads for step k+1 are issued before the MFMAs of step k and written to the
-// other LDS buffer after them (one barrier per step).  An operand keeps its global orientation in LDS so
+// other LDS buffer a quarter of the way through them (one barrier per step).  An operand keeps its global orientation in LDS so
 // that staging is always a conflict-free ds_write_b128: k-major operands live as [rows][BK+4] and are read
 // with one ds_read_b128 per 4 MFMAs; row-major-in-k operands ([K, rows] in memory) live as [BK][rows+4] and
 // are read with four conflict-free ds_read_b32.  Either way lane l holds k = {4h .. 4h+3}, h = l >> 5, and
@@ -21,6 +21,9 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #ifndef EGNN_BK
 #define EGNN_BK 16
+#endif
+#ifndef EGNN_STORE_AFTER
+#define EGNN_STORE_AFTER 1  // MFMA group (of 4) of the first k-block after which the prefetched tile is written to LDS
 #endif
 constexpr int BK = EGNN_BK;     // k-step per barrier (16 or 32)
 constexpr int LDS_LD = BK + 4;  // floats per LDS row: (BK+4)*4 B keeps every row 16-byte aligned
@@ -141,37 +144,32 @@ __device__ __forceinline__ int acc_col(int wn, int tn, int lane) {
   return wn * TileShape<BM, BN>::WN + tn * 32 + (lane & 31);
 }
 
-// acc += A[m0:m0+BM, kbeg:kend] * B[kbeg:kend, n0:n0+BN]   (all 256 threads must call with equal bounds)
-template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY = false, class XFA, class XFB, int TM_, int TN_>
-__device__ __forceinline__ void mainloop(f32x16 (&acc)[TM_][TN_],
-                                         const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
-                                         const float* __restrict__ B, int64_t ldb, int64_t n0, int64_t N,
-                                         int64_t kbeg, int64_t kend, const XFA& xfa, const XFB& xfb, float* smem) {
+// The software pipeline of one workgroup: operand tiles travel global -> registers (prefetch) -> LDS (commit, inside
+// step) -> MFMA fragments.  mainloop() below drives it for one output tile; kernels that walk several tiles (G-CRD
+// forward) drive it themselves so that the first k-step of the next tile is already in flight during an epilogue.
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY, class XFA, class XFB>
+struct Pipeline {
   using TS = TileShape<BM, BN>;
-  static_assert(TM_ == TS::TM && TN_ == TS::TN, "accumulator shape does not match the block tile");
   // plain offset arithmetic on the __shared__ base keeps the LDS address space visible to the compiler
   // (an array of buffer pointers indexed by `cur` decays to flat loads, which also drain the global prefetch)
-  constexpr int A_BUF = BM * LDS_LD, B_BUF = BN * LDS_LD, B_OFF = 2 * BM * LDS_LD;
+  static constexpr int A_BUF = BM * LDS_LD, B_BUF = BN * LDS_LD, B_OFF = 2 * BM * LDS_LD;
   Stager<BM, AMAJ, VEC4, XFA> sa;
   Stager<BN, BMAJ, VEC4, XFB> sb;
-  const int nk = (int)((kend - kbeg + BK - 1) / BK);
-  if (nk <= 0) return;
-  const int lane = egnn_lane();
-  const int wave = egnn_wave_id();
-  const int wm = wave >> 1, wn = wave & 1;
 
-  sa.template load<FULLONLY>(A, lda, m0, M, kbeg, kend, xfa);
-  sb.template load<FULLONLY>(B, ldb, n0, N, kbeg, kend, xfb);
-  sa.store(smem);
-  sb.store(smem + B_OFF);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) {
-      sa.template load<FULLONLY>(A, lda, m0, M, kbeg + (int64_t)(kt + 1) * BK, kend, xfa);
-      sb.template load<FULLONLY>(B, ldb, n0, N, kbeg + (int64_t)(kt + 1) * BK, kend, xfb);
-    }
+  __device__ __forceinline__ void prefetch(const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
+                                           const float* __restrict__ B, int64_t ldb, int64_t n0, int64_t N, int64_t k0,
+                                           int64_t kend, const XFA& xfa, const XFB& xfb) {
+    sa.template load<FULLONLY>(A, lda, m0, M, k0, kend, xfa);
+    sb.template load<FULLONLY>(B, ldb, n0, N, k0, kend, xfb);
+  }
+  __device__ __forceinline__ void commit(float* smem, int buf) const {
+    sa.store(smem + buf * A_BUF);
+    sb.store(smem + B_OFF + buf * B_BUF);
+  }
+  // one k-step out of LDS buffer `cur`; with `more`, the prefetched registers are committed to buffer cur^1 on the way
+  template <int TM_, int TN_>
+  __device__ __forceinline__ void step(f32x16 (&acc)[TM_][TN_], float* smem, int cur, bool more, int lane, int wm, int wn) const {
+    static_assert(TM_ == TS::TM && TN_ == TS::TN, "accumulator shape does not match the block tile");
 #pragma unroll
     for (int kb = 0; kb < BK / 8; ++kb) {
       f32x4v a[TS::TM], b[TS::TN];
@@ -180,17 +178,41 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM_][TN_],
 #pragma unroll
       for (int tn = 0; tn < TS::TN; ++tn) b[tn] = load_frag<BN, BMAJ>(smem + B_OFF + cur * B_BUF, wn * TS::WN + tn * 32, kb, lane);
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < 4; ++m) {
 #pragma unroll
         for (int tm = 0; tm < TS::TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TS::TN; ++tn)
             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][m], b[tn][m], acc[tm][tn], 0, 0, 0);
+        // The staged tile goes to the other LDS buffer EARLY in the step (after the first quarter of its MFMAs), not
+        // after the last one: the ds_write latency and the barrier that follows are then covered by this wave's own
+        // remaining MFMAs instead of draining the matrix pipe (measured with tools/probes/gemm_abl.hip: +16-20 %).
+        if (kb == 0 && m == EGNN_STORE_AFTER && more) commit(smem, cur ^ 1);
+      }
     }
-    if (more) {
-      sa.store(smem + (cur ^ 1) * A_BUF);
-      sb.store(smem + B_OFF + (cur ^ 1) * B_BUF);
-    }
+  }
+};
+
+// acc += A[m0:m0+BM, kbeg:kend] * B[kbeg:kend, n0:n0+BN]   (all 256 threads must call with equal bounds)
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY = false, class XFA, class XFB, int TM_, int TN_>
+__device__ __forceinline__ void mainloop(f32x16 (&acc)[TM_][TN_],
+                                         const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
+                                         const float* __restrict__ B, int64_t ldb, int64_t n0, int64_t N,
+                                         int64_t kbeg, int64_t kend, const XFA& xfa, const XFB& xfb, float* smem) {
+  Pipeline<BM, BN, AMAJ, BMAJ, VEC4, FULLONLY, XFA, XFB> pipe;
+  const int nk = (int)((kend - kbeg + BK - 1) / BK);
+  if (nk <= 0) return;
+  const int lane = egnn_lane();
+  const int wave = egnn_wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+
+  pipe.prefetch(A, lda, m0, M, B, ldb, n0, N, kbeg, kend, xfa, xfb);
+  pipe.commit(smem, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) pipe.prefetch(A, lda, m0, M, B, ldb, n0, N, kbeg + (int64_t)(kt + 1) * BK, kend, xfa, xfb);
+    pipe.step(acc, smem, kt & 1, more, lane, wm, wn);
     __syncthreads();
   }
 }

@@ -23,6 +23,9 @@ using namespace egnn_gemm;
 
 namespace {
 
+#ifndef EGNN_NCE_FWD_WAVES
+#define EGNN_NCE_FWD_WAVES 2  // waves per SIMD the edge-free forward variant is compiled for
+#endif
 constexpr int kMaxSplit = 8;
 constexpr int FB = 128;  // forward block tile (rows and columns)
 
@@ -31,6 +34,17 @@ __device__ __forceinline__ float nce_shift(float inv_tau) { return inv_tau * 1.0
 // the bound 1/tau is a usable shift while exp(-2/tau) stays a normal float (tau >= 0.025 leaves ample room)
 inline bool nce_unit_form(float tau, int unit_rows) { return unit_rows && (2.f / tau) <= 80.f; }
 
+// exp(x) for -100 < x < 80 (no overflow / denormal handling): the usual two-constant argument reduction in front of
+// v_exp_f32, i.e. libm's expf without its range checks (8 instead of 17 VALU instructions; the epilogue's VALU work
+// competes with other waves' MFMA issue).  Used where the unit-rows bound guarantees the range.
+__device__ __forceinline__ float exp_bounded(float x) {
+  const float kL2eHi = 1.44269502162933349609375f, kL2eLo = 1.925963033500011e-8f;
+  const float n = __builtin_rintf(x * kL2eHi);
+  float f = fmaf(x, kL2eHi, -n);
+  f = fmaf(x, kL2eLo, f);
+  return ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
 __device__ __forceinline__ void lse_merge(float& m, float& s, float om, float os) {
   const float mn = fmaxf(m, om);
   if (mn == -INFINITY) return;  // both empty
@@ -38,12 +52,51 @@ __device__ __forceinline__ void lse_merge(float& m, float& s, float om, float os
   m = mn;
 }
 
+// Epilogue of one interior 128 x 128 tile of the unit-rows form: E = exp(acc / tau - shift) is stored and added to the
+// per-lane row sums.  Wave-uniform row bases + one 32-bit lane offset; nothing per-row is live outside.
+template <class TS, int TM_, int TN_>
+__device__ __forceinline__ void nce_tile_epilogue(const f32x16 (&acc)[TM_][TN_], float (&rs)[TM_][16], float* __restrict__ Z,
+                                                  float* __restrict__ zdiag, int64_t ib, int64_t j0, int64_t sc,
+                                                  int64_t diag_off, float inv_tau, float shift, int lane, int wm, int wn) {
+  float* zb = Z + (ib + wm * TS::WM) * sc + (j0 + wn * TS::WN);
+  const unsigned voff = (unsigned)(4 * (lane >> 5)) * (unsigned)sc + (unsigned)(lane & 31);
+#pragma unroll
+  for (int tm = 0; tm < TM_; ++tm) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float* zr = zb + (int64_t)(tm * 32 + (r & 3) + 8 * (r >> 2)) * sc;
+#pragma unroll
+      for (int tn = 0; tn < TN_; ++tn) {
+        const float e = exp_bounded(fmaf(acc[tm][tn][r], inv_tau, -shift));
+        zr[voff + tn * 32] = e;
+        rs[tm][r] += e;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // one row at a time: keeps the 64 exp chains from being interleaved (registers)
+    }
+  }
+  if (j0 < ib + diag_off + FB && ib + diag_off < j0 + FB) {  // the tile crosses the diagonal of positives
+    // element (lr, lc) of the tile is a positive iff lr - lc == d; split into a lane part and a wave-uniform part
+    // (32-bit: |d| < FB here) so that nothing per-row survives outside this rarely taken branch
+    const int d = (int)(j0 - ib - diag_off);
+    const int lv = 4 * (lane >> 5) - (lane & 31);
+#pragma unroll
+    for (int tm = 0; tm < TM_; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ur = wm * TS::WM + tm * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int tn = 0; tn < TN_; ++tn)
+          if (lv == d - (ur - wn * TS::WN - tn * 32)) zdiag[ib + ur + 4 * (lane >> 5)] = acc[tm][tn][r] * inv_tau;
+      }
+  }
+}
+
 // FIXED: rows are unit vectors, so every logit is <= 1/tau and that bound serves as the soft-max shift: one exp per
 // element and half the per-lane state of the online-max form (which costs a whole wave per SIMD in registers).
 // ALIGNED: Sr and Sc are multiples of the tile, P of the k-step and the operands are float4-addressable (the sampled
 // G-CRD problem: 16384 x 16384 x 256); no edge handling is compiled into that variant.
 template <bool VEC4, bool FIXED, bool ALIGNED>
-__global__ __launch_bounds__(256, ALIGNED ? 3 : 1) void nce_fwd_kernel(const float* __restrict__ fhat, int64_t ldf,
+__global__ __launch_bounds__(256, ALIGNED ? EGNN_NCE_FWD_WAVES : 1) void nce_fwd_kernel(const float* __restrict__ fhat, int64_t ldf,
                                                       const float* __restrict__ that, int64_t ldt, int64_t Sr, int64_t Sc,
                                                       int64_t diag_off, int64_t P, float inv_tau,
                                                       float* __restrict__ Z, float* __restrict__ zdiag,
@@ -72,53 +125,55 @@ __global__ __launch_bounds__(256, ALIGNED ? 3 : 1) void nce_fwd_kernel(const flo
     }
 
   IdentityXf id;
+  if constexpr (ALIGNED) {
+    // One continuous software pipeline over (column tile, k-step): the first k-step of the next tile is fetched and
+    // committed to LDS during the last step of the current one, so an epilogue is followed by MFMAs at once.
+    Pipeline<FB, FB, KMAJOR, KMAJOR, true, true, IdentityXf, IdentityXf> pipe;
+    const int nk = (int)(P / BK);
+    const int64_t total = (cb1 - cb0) * nk;
+    f32x16 acc[TS::TM][TS::TN];
+    zero_acc(acc);
+    if (total > 0) {
+      pipe.prefetch(fhat, ldf, i0, Sr, that, ldt, cb0 * FB, Sc, 0, P, id, id);
+      pipe.commit(smem, 0);
+    }
+    __syncthreads();
+    int kt = 0;
+    int64_t cb = cb0;
+    for (int64_t g = 0; g < total; ++g) {
+      const bool more = g + 1 < total;
+      int kn = kt + 1;
+      int64_t cbn = cb;
+      if (kn == nk) { kn = 0; ++cbn; }
+      if (more) pipe.prefetch(fhat, ldf, i0, Sr, that, ldt, cbn * FB, Sc, (int64_t)kn * BK, P, id, id);
+      pipe.step(acc, smem, (int)(g & 1), more, lane, wm, wn);
+      __syncthreads();
+      if (kn == 0) {
+        // launder the loop-invariant scalars: see the general path below
+        int64_t sc = Sc, ib = i0;
+        asm volatile("" : "+s"(sc), "+s"(ib));
+        nce_tile_epilogue<TS>(acc, rs, Z, zdiag, ib, cb * FB, sc, diag_off, inv_tau, shift, lane, wm, wn);
+        zero_acc(acc);
+      }
+      kt = kn;
+      cb = cbn;
+    }
+  } else
   for (int64_t cb = cb0; cb < cb1; ++cb) {
     const int64_t j0 = cb * FB;
     f32x16 acc[TS::TM][TS::TN];
     zero_acc(acc);
-    mainloop<FB, FB, KMAJOR, KMAJOR, VEC4, ALIGNED>(acc, fhat, ldf, i0, Sr, that, ldt, j0, Sc, 0, P, id, id, smem);
+    mainloop<FB, FB, KMAJOR, KMAJOR, VEC4>(acc, fhat, ldf, i0, Sr, that, ldt, j0, Sc, 0, P, id, id, smem);
     // The epilogue addresses are functions of loop-invariant quantities (i0, Sc); left alone, the compiler hoists one
     // 64-bit pointer per accumulator row out of the column-block loop (~150 registers, one wave per SIMD).  Laundering
     // the two scalars through an empty asm makes it recompute them per tile instead (a few dozen scalar ops).
     int64_t sc = Sc, ib = i0;
     asm volatile("" : "+s"(sc), "+s"(ib));
-    const bool interior = ALIGNED || ((ib + FB <= Sr) && (j0 + FB <= sc));  // block-uniform
-    if (FIXED && interior && (ALIGNED || sc < (1LL << 28))) {
-      // interior tile of the unit-rows form: wave-uniform row bases + one 32-bit lane offset, no per-element guards
-      float* zb = Z ? Z + (ib + wm * TS::WM) * sc + (j0 + wn * TS::WN) : nullptr;
-      const unsigned voff = (unsigned)(4 * (lane >> 5)) * (unsigned)sc + (unsigned)(lane & 31);
-#pragma unroll
-      for (int tm = 0; tm < TS::TM; ++tm) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float* zr = zb + (int64_t)(tm * 32 + (r & 3) + 8 * (r >> 2)) * sc;
-#pragma unroll
-          for (int tn = 0; tn < TS::TN; ++tn) {
-            const float e = expf(acc[tm][tn][r] * inv_tau - shift);
-            if (ALIGNED || Z) zr[voff + tn * 32] = e;  // the aligned variant is only launched with Z != NULL
-            rs[tm][r] += e;
-          }
-          __builtin_amdgcn_sched_barrier(0);  // one row at a time: keeps the 64 exp chains from being interleaved (registers)
-        }
-      }
-      if (j0 < ib + diag_off + FB && ib + diag_off < j0 + FB) {  // the tile crosses the diagonal of positives
-        // element (lr, lc) of the tile is a positive iff lr - lc == d; split into a lane part and a wave-uniform part
-        // (32-bit: |d| < FB here) so that nothing per-row survives outside this rarely taken branch
-        const int d = (int)(j0 - ib - diag_off);
-        const int lv = 4 * (lane >> 5) - (lane & 31);
-#pragma unroll
-        for (int tm = 0; tm < TS::TM; ++tm)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ur = wm * TS::WM + tm * 32 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-            for (int tn = 0; tn < TS::TN; ++tn)
-              if (lv == d - (ur - wn * TS::WN - tn * 32)) zdiag[ib + ur + 4 * (lane >> 5)] = acc[tm][tn][r] * inv_tau;
-          }
-      }
+    const bool interior = (ib + FB <= Sr) && (j0 + FB <= sc);  // block-uniform
+    if (FIXED && Z && interior && sc < (1LL << 28)) {
+      if constexpr (FIXED) nce_tile_epilogue<TS>(acc, rs, Z, zdiag, ib, j0, sc, diag_off, inv_tau, shift, lane, wm, wn);
       continue;
     }
-    if constexpr (!(ALIGNED && FIXED))
 #pragma unroll
     for (int tm = 0; tm < TS::TM; ++tm) {
 #pragma unroll
@@ -132,7 +187,7 @@ __global__ __launch_bounds__(256, ALIGNED ? 3 : 1) void nce_fwd_kernel(const flo
           const float z = acc[tm][tn][r] * inv_tau;
           const bool ok = row < Sr && c < sc;
           if (ok) {
-            if (Z) Z[row * sc + c] = FIXED ? expf(z - shift) : z;
+            if (Z) Z[row * sc + c] = FIXED ? exp_bounded(fmaf(acc[tm][tn][r], inv_tau, -shift)) : z;
             if (row + diag_off == c) zdiag[row] = z;
           }
           zt[tn] = ok ? z : -INFINITY;
@@ -140,7 +195,8 @@ __global__ __launch_bounds__(256, ALIGNED ? 3 : 1) void nce_fwd_kernel(const flo
         }
         if constexpr (FIXED) {
 #pragma unroll
-          for (int tn = 0; tn < TS::TN; ++tn) rs[tm][r] += expf(zt[tn] - shift);  // exp(-inf) == 0 for masked columns
+          for (int tn = 0; tn < TS::TN; ++tn)  // masked columns contribute nothing
+            if (zt[tn] > -INFINITY) rs[tm][r] += exp_bounded(fmaf(acc[tm][tn][r], inv_tau, -shift));
         } else if (mt > -INFINITY) {
           const float mn = fmaxf(rm[tm][r], mt);
           float s = rs[tm][r] * expf(rm[tm][r] - mn);
@@ -396,7 +452,7 @@ extern "C" int egnn_nce_block_fwd_f32(const float* fhat, int64_t ld_f, const flo
   hipStream_t st = (hipStream_t)stream;
   const int64_t rb = (Sr + FB - 1) / FB;
   const int64_t ncb = (Sc + FB - 1) / FB;
-  int nsplit = (int)((512 + rb - 1) / rb);
+  int nsplit = (int)((256 * EGNN_NCE_FWD_WAVES + rb - 1) / rb);  // one resident workgroup per wave slot of every CU
   if (nsplit > kMaxSplit) nsplit = kMaxSplit;
   if (nsplit > ncb) nsplit = (int)ncb;
   if (nsplit < 1) nsplit = 1;
