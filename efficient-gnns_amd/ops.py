@@ -199,11 +199,11 @@ class _MatMul(torch.autograd.Function):
         return gx, gw, gb, None
 
 
-def matmul(x: Tensor, w: Tensor) -> Tensor:
-    """x [M,K] @ w [K,N]."""
+def matmul(x: Tensor, w: Tensor, bias: Tensor | None = None) -> Tensor:
+    """x [M,K] @ w [K,N] (+ bias [N], added in the GEMM's store)."""
     if gemm_backend() == "blas":
-        return x @ w
-    return _MatMul.apply(x, w, None, False)
+        return x @ w if bias is None else torch.addmm(bias, x, w)
+    return _MatMul.apply(x, w, bias, False)
 
 
 def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None) -> Tensor:

@@ -31,7 +31,7 @@ def _patch_ops_with_oracle():
 
     ops.spmm = lambda adj, x, reduce="sum", bias=None: OS.matmul(to_oracle(adj), x, reduce) + (0 if bias is None else bias)
     ops.take_rows = lambda x, idx: x[idx]
-    ops.matmul = lambda x, w: x @ w
+    ops.matmul = lambda x, w, bias=None: x @ w if bias is None else x @ w + bias
     ops.linear = lambda x, w, b=None: F.linear(x, w, b)
     ops.cross_entropy = lambda logits, labels: F.cross_entropy(logits, labels)
 
