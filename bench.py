@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--training", default="nce", choices=["nce", "kd", "gpw", "lpw", "supervised"])
     ap.add_argument("--cpu-epochs", type=int, default=3, help="CPU-oracle epochs timed for cpu_baseline (0 = skip)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the node-range sharded (multi-GPU) code path even with one rank: RCCL init, halo plan, "
+                         "SyncBN, row-block G-CRD -- a 1-GPU check of the path the N>1 runs take")
     return ap.parse_args()
 
 
@@ -151,6 +154,22 @@ def cpu_baseline(args, data, hp):
                        f"(pure-PyTorch CPU oracle; the reference's PyG stack is not installable)")
 
 
+def cap_cpu_threads(local_world: int = 1) -> int:
+    """ATen sizes its OpenMP pool from the visible CPUs (256 on the GPU box) although the container's cgroup grants far
+    fewer (cpu.max = 16 there): the idle workers spin, exhaust the CFS quota and the launching thread is throttled for
+    tens of ms at a time.  Cap the pool at the quota (shared by the ranks of this node)."""
+    limit = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            limit = min(limit, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    n = max(1, min(torch.get_num_threads(), limit // max(1, local_world)))
+    torch.set_num_threads(n)
+    return n
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,6 +177,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    cap_cpu_threads(int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     hp = dict(HP, max_samples=args.max_samples)
@@ -169,7 +189,9 @@ def main():
     import efficient_gnns_amd.models as PM
     import efficient_gnns_amd.ops as ops
 
-    if world > 1:
+    if world > 1 or args.force_sharded:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
         import efficient_gnns_amd.dist as dist_mod
         return dist_mod.bench_main(args, hp, MODEL, rank, world, device)
 
@@ -185,6 +207,11 @@ def main():
 
     for _ in range(args.warmup):
         epoch(PM, model, d, opt, args, hp, sp, tp, edge_index)
+    # keep generation-2 garbage collections (a ~40 ms walk over the ~170k objects the imports leave behind) out of the
+    # training loop: freeze what survived set-up, as a long-running trainer would
+    import gc
+    gc.collect()
+    gc.freeze()
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     train_ms = eval_ms = 0.0

@@ -282,12 +282,12 @@ extern "C" int egnn_bn_act_fwd_f32(const float* x, int64_t ld, int64_t n, int64_
   return egnn_launch_status();
 }
 
-extern "C" int egnn_bn_act_bwd_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
-                                   const float* mean, const float* var, float eps, const float* gamma, const float* beta, int relu,
-                                   float p, uint64_t seed, int batch_stats, float* dgamma, float* dbeta, float* dx, int64_t ld_dx,
-                                   float* ws, size_t ws_floats, void* stream) {
-  EGNN_CHECK_ARG(n > 0 && x && dy && mean && var && dgamma && dbeta && dx && ws && ld >= C && ld_dy >= C && ld_dx >= C);
-  if (!shape_ok(x, ld, C) || !shape_ok(dy, ld_dy, C) || !shape_ok(dx, ld_dx, C)) return EGNN_EALIGN;
+extern "C" int egnn_bn_act_bwd_reduce_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
+                                          const float* mean, const float* var, float eps, const float* gamma, const float* beta,
+                                          int relu, float p, uint64_t seed, float* dgamma, float* dbeta, float* ws,
+                                          size_t ws_floats, void* stream) {
+  EGNN_CHECK_ARG(n > 0 && x && dy && mean && var && dgamma && dbeta && ws && ld >= C && ld_dy >= C);
+  if (!shape_ok(x, ld, C) || !shape_ok(dy, ld_dy, C)) return EGNN_EALIGN;
   if (ws_floats < egnn_bn_ws_floats(C)) return EGNN_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const BnParams q{x, ld, n, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed};
@@ -295,7 +295,29 @@ extern "C" int egnn_bn_act_bwd_f32(const float* x, int64_t ld, const float* dy, 
   const int nb = (int)(want < kStatBlocks ? want : kStatBlocks);
   hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, q, dy, ld_dy, ws);
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, ws, nb, C, dbeta, dgamma);
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(row_blocks(n)), dim3(256), 0, st, q, dy, ld_dy, dbeta, dgamma,
-                     batch_stats ? 1.f / (float)n : 0.f, dx, ld_dx);
   return egnn_launch_status();
+}
+
+extern "C" int egnn_bn_act_bwd_apply_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
+                                         const float* mean, const float* var, float eps, const float* gamma, const float* beta,
+                                         int relu, float p, uint64_t seed, const float* sum_dbeta, const float* sum_dgamma,
+                                         float inv_count, float* dx, int64_t ld_dx, void* stream) {
+  EGNN_CHECK_ARG(n > 0 && x && dy && mean && var && sum_dbeta && sum_dgamma && dx && ld >= C && ld_dy >= C && ld_dx >= C);
+  if (!shape_ok(x, ld, C) || !shape_ok(dy, ld_dy, C) || !shape_ok(dx, ld_dx, C)) return EGNN_EALIGN;
+  const BnParams q{x, ld, n, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed};
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(row_blocks(n)), dim3(256), 0, (hipStream_t)stream, q, dy, ld_dy, sum_dbeta,
+                     sum_dgamma, inv_count, dx, ld_dx);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_bn_act_bwd_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
+                                   const float* mean, const float* var, float eps, const float* gamma, const float* beta, int relu,
+                                   float p, uint64_t seed, int batch_stats, float* dgamma, float* dbeta, float* dx, int64_t ld_dx,
+                                   float* ws, size_t ws_floats, void* stream) {
+  EGNN_CHECK_ARG(dx && ld_dx >= C);
+  const int rc = egnn_bn_act_bwd_reduce_f32(x, ld, dy, ld_dy, n, C, mean, var, eps, gamma, beta, relu, p, seed, dgamma, dbeta, ws,
+                                            ws_floats, stream);
+  if (rc != EGNN_OK) return rc;
+  return egnn_bn_act_bwd_apply_f32(x, ld, dy, ld_dy, n, C, mean, var, eps, gamma, beta, relu, p, seed, dbeta, dgamma,
+                                   batch_stats ? 1.f / (float)n : 0.f, dx, ld_dx, stream);
 }

@@ -201,15 +201,31 @@ class SyncBatchNorm1d(nn.Module):
             self.running_var.fill_(1.0)
             self.num_batches_tracked.zero_()
 
-    def forward(self, x: Tensor) -> Tensor:
-        if not self.training:
-            return (x - self.running_mean) * torch.rsqrt(self.running_var + self.eps) * self.weight + self.bias
-        y, mean, var, n = _SyncBNFn.apply(x, self.weight, self.bias, self.eps, self.group)
+    def _update_running(self, mean, var, n):
         with torch.no_grad():
             m = self.momentum
             self.running_mean.mul_(1 - m).add_(mean.detach(), alpha=m)
             self.running_var.mul_(1 - m).add_(var.detach() * (n / (n - 1).clamp(min=1)), alpha=m)
             self.num_batches_tracked += 1
+
+    def forward(self, x: Tensor) -> Tensor:
+        if not self.training:
+            return (x - self.running_mean) * torch.rsqrt(self.running_var + self.eps) * self.weight + self.bias
+        y, mean, var, n = _SyncBNFn.apply(x, self.weight, self.bias, self.eps, self.group)
+        self._update_running(mean, var, n)
+        return y
+
+    def fused_act(self, x: Tensor, relu: bool, p: float, training: bool) -> Tensor:
+        """dropout(relu(self(x)), p) -- on the GPU through the fused BN + ReLU + dropout kernels (ops.sync_bn_act /
+        ops.bn_act), elsewhere (gloo tests) through the torch operators above."""
+        if not (x.is_cuda and ops.bn_shape_ok(x)):
+            y = self(x)
+            y = torch.relu(y) if relu else y
+            return torch.nn.functional.dropout(y, p, training) if p > 0 else y
+        if not training:   # running statistics: the single-GPU kernel applies as it is
+            return ops._BnAct.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, relu, 0.0, 0, False)
+        y, mean, var, n = ops.sync_bn_act(x, self, relu, p, training, self.group)
+        self._update_running(mean, var, n)
         return y
 
 
@@ -440,6 +456,12 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
 
     for _ in range(args.warmup):
         epoch()
+    # The interpreter holds ~170k long-lived objects after the torch / RCCL imports; a full (generation-2) collection
+    # walks all of them (~40 ms) and the per-step autograd / collective bookkeeping triggers one every few steps.
+    # Freezing the survivors of set-up keeps later collections proportional to the per-step garbage.
+    import gc
+    gc.collect()
+    gc.freeze()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):

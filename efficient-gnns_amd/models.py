@@ -36,7 +36,9 @@ class _Student(nn.Module):
             x = conv(x, adj_t)
             if isinstance(bn, nn.BatchNorm1d) and x.is_cuda:   # fused BN + ReLU + dropout kernels (gnn.py:48-50)
                 x = ops.bn_act(x, bn, relu=True, p=self.dropout, training=self.training)
-            else:                                               # SyncBatchNorm1d on sharded runs
+            elif hasattr(bn, "fused_act"):                      # dist.SyncBatchNorm1d on sharded runs (all-rank statistics)
+                x = bn.fused_act(x, True, self.dropout, self.training)
+            else:
                 x = F.dropout(F.relu(bn(x)), p=self.dropout, training=self.training)
             self.out_feat = x
         return self.convs[-1](x, adj_t)
@@ -74,6 +76,8 @@ class ProjectionHead(nn.Sequential):
 
     def forward(self, x):
         lin, bn = self[0], self[1]
+        if x.is_cuda and hasattr(bn, "fused_act"):              # dist.SyncBatchNorm1d
+            return bn.fused_act(ops.linear(x, lin.weight, lin.bias), True, 0.0, self.training)
         if not x.is_cuda or not isinstance(bn, nn.BatchNorm1d):
             return super().forward(x)
         return ops.bn_act(ops.linear(x, lin.weight, lin.bias), bn, relu=True, p=0.0, training=self.training)

@@ -448,3 +448,80 @@ def bn_act(x: Tensor, bn: "torch.nn.BatchNorm1d", relu: bool = True, p: float = 
     drop = p if (training and p > 0) else 0.0
     seed = int(torch.empty((), dtype=torch.int64).random_()) if drop > 0 else 0  # host generator: torch.manual_seed reproducible
     return _BnAct.apply(x, bn.weight, bn.bias, mean, var, bn.eps, relu, drop, seed & 0x7FFFFFFFFFFFFFFF, use_batch)
+
+
+# ------------------------------------------------------------------------------------------------
+# the same fused BatchNorm + ReLU + dropout with batch statistics that span all ranks (node-range shards)
+# ------------------------------------------------------------------------------------------------
+class _SyncBnAct(torch.autograd.Function):
+    """Two small collectives per direction: the per-shard (n, mean, var) triples are all-gathered and merged in rank
+    order (Chan's parallel-variance formula, identical on every rank); the backward all-reduces [sum d, sum d*xhat]."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu, p, seed, group):
+        import torch.distributed as dist
+        x = _rowmajor(x)
+        n, C = x.shape
+        lib, dev = _lib.load(), x.device
+        world = dist.get_world_size(group)
+        stats = torch.zeros(2 * C + 1, dtype=torch.float32, device=dev)  # [mean | var | n]; an empty shard contributes n = 0
+        if n > 0:
+            nws = lib.egnn_bn_ws_floats(C)
+            ws = torch.empty(nws, dtype=torch.float32, device=dev)
+            _lib.check(lib.egnn_bn_stats_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(stats), _lib.ptr(stats[C:]), _lib.ptr(ws), nws,
+                                             _lib.stream()), "egnn_bn_stats_f32")
+            stats[2 * C] = float(n)
+        allst = torch.empty(world, 2 * C + 1, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(allst, stats, group=group)
+        cnt = allst[:, 2 * C:]                                   # [world, 1]
+        total = cnt.sum()
+        mean = (allst[:, :C] * cnt).sum(0) / total
+        var = ((allst[:, C:2 * C] + (allst[:, :C] - mean) ** 2) * cnt).sum(0) / total
+        y = torch.empty(n, C, dtype=torch.float32, device=dev)
+        if n > 0:
+            rc = lib.egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
+                                         _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(y), y.stride(0), _lib.stream())
+            _lib.check(rc, "egnn_bn_act_fwd_f32")
+        ctx.save_for_backward(x, gamma, beta, mean, var, total)
+        ctx.cfg = (float(eps), int(relu), float(p), int(seed), group)
+        ctx.mark_non_differentiable(mean, var, total)
+        return y, mean, var, total
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv, _gt):
+        import torch.distributed as dist
+        x, gamma, beta, mean, var, total = ctx.saved_tensors
+        eps, relu, p, seed, group = ctx.cfg
+        gy = _rowmajor(gy)
+        n, C = x.shape
+        lib, dev = _lib.load(), x.device
+        sums = torch.zeros(2 * C, dtype=torch.float32, device=dev)   # [dbeta | dgamma] of this shard
+        if n > 0:
+            nws = lib.egnn_bn_ws_floats(C)
+            ws = torch.empty(nws, dtype=torch.float32, device=dev)
+            rc = lib.egnn_bn_act_bwd_reduce_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var),
+                                                eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(sums[C:]), _lib.ptr(sums),
+                                                _lib.ptr(ws), nws, _lib.stream())
+            _lib.check(rc, "egnn_bn_act_bwd_reduce_f32")
+        local = sums.clone()                                          # parameter grads stay local (the flat all-reduce sums them)
+        dist.all_reduce(sums, group=group)
+        sums = sums / total                                          # scaled on the device (no host read of the row count)
+        dx = torch.empty_like(x)
+        if n > 0:
+            rc = lib.egnn_bn_act_bwd_apply_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var),
+                                               eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(sums), _lib.ptr(sums[C:]),
+                                               1.0, _lib.ptr(dx), dx.stride(0), _lib.stream())
+            _lib.check(rc, "egnn_bn_act_bwd_apply_f32")
+        return dx, local[C:], local[:C], None, None, None, None, None
+
+
+def sync_bn_act(x: Tensor, bn, relu: bool, p: float, training: bool, group=None):
+    """Training-mode dropout(relu(bn(x))) with all-rank statistics; returns (y, mean, biased var, total rows) so that the
+    module can update its running statistics.  ``bn`` needs weight / bias / eps (dist.SyncBatchNorm1d)."""
+    drop = p if (training and p > 0) else 0.0
+    seed = int(torch.empty((), dtype=torch.int64).random_()) if drop > 0 else 0
+    return _SyncBnAct.apply(x, bn.weight, bn.bias, bn.eps, relu, drop, seed & 0x7FFFFFFFFFFFFFFF, group)
+
+
+def bn_shape_ok(x: Tensor) -> bool:
+    return _bn_shape_ok(_rowmajor(x))

@@ -258,6 +258,10 @@ int egnn_segment_sum_f32(const int64_t* seg_ptr, const float* x, int64_t n_seg, 
  *   egnn_bn_act_bwd_f32   recomputes xhat / ReLU sign / mask from x and seed; dgamma, dbeta [C]; dx [n,C];
  *                         batch_stats != 0: mean/var are this batch's statistics (training backward, the
  *                         -(sum d + xhat sum d xhat)/n terms apply); 0: running statistics (eval-mode graph)
+ *   egnn_bn_act_bwd_reduce_f32 / _apply_f32   the two halves of the backward, for batch statistics that span several
+ *                         GPUs (node-range shards): reduce writes this shard's dbeta = sum d and
+ *                         dgamma = sum d*xhat; the caller all-reduces them over RCCL and passes the totals plus
+ *                         inv_count = 1 / (rows of ALL shards) to apply (inv_count = 0: running statistics)
  * ws: egnn_bn_ws_floats(C) floats. */
 size_t egnn_bn_ws_floats(int64_t C);
 int egnn_bn_stats_f32(const float* x, int64_t ld, int64_t n, int64_t C, float* mean, float* var, float* ws, size_t ws_floats,
@@ -269,6 +273,14 @@ int egnn_bn_act_bwd_f32(const float* x, int64_t ld, const float* dy, int64_t ld_
                         const float* var, float eps, const float* gamma, const float* beta, int relu, float p, uint64_t seed,
                         int batch_stats, float* dgamma, float* dbeta, float* dx, int64_t ld_dx, float* ws, size_t ws_floats,
                         void* stream);
+
+int egnn_bn_act_bwd_reduce_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
+                               const float* mean, const float* var, float eps, const float* gamma, const float* beta, int relu,
+                               float p, uint64_t seed, float* dgamma, float* dbeta, float* ws, size_t ws_floats, void* stream);
+int egnn_bn_act_bwd_apply_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
+                              const float* mean, const float* var, float eps, const float* gamma, const float* beta, int relu,
+                              float p, uint64_t seed, const float* sum_dbeta, const float* sum_dgamma, float inv_count,
+                              float* dx, int64_t ld_dx, void* stream);
 
 #ifdef __cplusplus
 }

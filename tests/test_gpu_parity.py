@@ -680,3 +680,54 @@ def test_nce_row_block_kernels_vs_torch(Sr, Sc, off, P, unit_rows):
     assert rc == 0
     close(df2, df, rtol=1e-5, atol_scale=2e-6)
     close(dt2, dt, rtol=1e-5, atol_scale=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gnn,mode", [("gcn", "nce"), ("sage", "kd")])
+def test_sharded_path_with_one_rank_over_rccl_matches_single_gpu_path(gnn, mode):
+    """The node-range sharded code (dist.py: halo plan, SyncBN, row-block G-CRD, flat gradient all-reduce) on the real
+    RCCL backend with world_size 1 must reproduce the single-GPU step; the N = 2 logic is covered on gloo."""
+    import torch.distributed as dist
+    import efficient_gnns_amd.dist as DD
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29577", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        hp = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=256, kernel="rbf")
+        d = D.arxiv_like(scale=0.02, seed=5)
+
+        def build():
+            torch.manual_seed(0)
+            np.random.seed(0)
+            model = (PM.GCN if gnn == "gcn" else PM.SAGE)(d.num_features, 64, d.num_classes, 3, 0.0).to(DEV)
+            sp = tp = None
+            groups = [{"params": model.parameters(), "lr": 0.01}]
+            if mode == "nce":
+                sp, tp = PM.make_projection(64, 32).to(DEV), PM.make_projection(750, 32).to(DEV)
+                groups += [{"params": sp.parameters(), "lr": 0.01}, {"params": tp.parameters(), "lr": 0.01}]
+            return model, sp, tp, groups
+
+        model, sp, tp, groups = build()
+        opt = torch.optim.Adam(groups)
+        adj = d.adj_t.to(DEV)
+        x, y = d.x.to(DEV), d.y.to(DEV)
+        split = {k: v.to(DEV) for k, v in d.split_idx.items()}
+        ref_logits, ref_accs = PM.evaluate(model, x, adj, y, split)
+        ref = [PM.train_step(model, x, adj, y, split["train"], opt, mode, hp, d.teacher_out_feat.to(DEV), d.teacher_logits.to(DEV),
+                             sp, tp) for _ in range(3)]
+
+        model, sp, tp, groups = build()
+        for m in (model, sp, tp):
+            if m is not None:
+                DD.swap_batchnorm(m)
+        opt = torch.optim.Adam(groups)
+        prob = DD.ShardedProblem(d, 1, 0, DEV, None, need_gcn=(gnn == "gcn"))
+        out, accs = DD.sharded_evaluate(model, prob)
+        got = [DD.sharded_train_step(model, prob, opt, mode, hp, sp, tp) for _ in range(3)]
+        close(out, ref_logits, rtol=1e-4, atol_scale=1e-5)
+        np.testing.assert_allclose(accs, ref_accs, atol=1e-9)
+        np.testing.assert_allclose(np.array(got), np.array(ref), rtol=2e-4, atol=1e-6)
+    finally:
+        if created:
+            dist.destroy_process_group()
