@@ -187,7 +187,10 @@ struct Pipeline {
         // The staged tile goes to the other LDS buffer EARLY in the step (after the first quarter of its MFMAs), not
         // after the last one: the ds_write latency and the barrier that follows are then covered by this wave's own
         // remaining MFMAs instead of draining the matrix pipe (measured with tools/probes/gemm_abl.hip: +16-20 %).
-        if (kb == 0 && m == EGNN_STORE_AFTER && more) commit(smem, cur ^ 1);
+        // (when BOTH operands are [K,rows] the fragments cost 4x the LDS instructions and the early commit gets in
+        // their way: dW = X^T dY measured 277 us early vs 247 us late, so that layout commits after the last MFMA)
+        constexpr bool kLate = (AMAJ == MNMAJOR && BMAJ == MNMAJOR);
+        if (more && (kLate ? (kb == BK / 8 - 1 && m == 3) : (kb == 0 && m == EGNN_STORE_AFTER))) commit(smem, cur ^ 1);
       }
     }
   }

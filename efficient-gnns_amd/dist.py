@@ -348,7 +348,8 @@ def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: di
         if p is not None:
             p.train()
     group = prob.group
-    out = model(prob.x, prob.adj)[prob.train_local]
+    take = ops.take_rows if prob.x.is_cuda else (lambda t, i: t[i])   # train ids are unique: gather / scatter without a sort
+    out = take(model(prob.x, prob.adj), prob.train_local)
     labels = prob.y.squeeze(1)[prob.train_local]
     frac = out.shape[0] / prob.n_train_global               # local mean -> contribution to the global mean
     dev = out.device
@@ -366,8 +367,8 @@ def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: di
         loss = loss_aux * (hp["alpha"] * hp["kd_T"] ** 2) + loss_cls * (1 - hp["alpha"])
     elif mode == "nce":
         loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else zero
-        f = student_proj(model.out_feat[prob.train_local])
-        t = teacher_proj(prob.teacher_out_feat[prob.train_local])
+        f = student_proj(take(model.out_feat, prob.train_local))
+        t = teacher_proj(take(prob.teacher_out_feat, prob.train_local))
         S = hp["max_samples"]
         ntr = prob.n_train_global
         pick = np.random.choice(ntr, S, replace=False) if S < ntr else np.arange(ntr)   # same draw on every rank
