@@ -87,7 +87,8 @@ def to_device(data, device):
     d.x, d.y = data.x.to(device), data.y.to(device)
     d.adj_t = data.adj_t.to(device)
     d.split_idx = {k: v.to(device) for k, v in data.split_idx.items()}
-    d.teacher_out_feat = data.teacher_out_feat.to(device)
+    import efficient_gnns_amd.ops as _ops
+    d.teacher_out_feat = _ops.pad_pitch(data.teacher_out_feat.to(device))   # same values, rows 16-byte aligned (750 -> pitch 752)
     d.teacher_logits = data.teacher_logits.to(device)
     return d
 

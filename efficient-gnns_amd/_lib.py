@@ -28,6 +28,7 @@ SIGNATURES = {
     "egnn_gcn_norm_fill_i64": (_i32, [_p, _p, _i64, _p, _p, _p, _p]),
     "egnn_gcn_norm_values_i64": (_i32, [_p, _p, _i64, _p, _p, _p]),
     "egnn_gemm_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _p]),
+    "egnn_gemm_rows_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _p, _i64, _p, _p, _p, _i64, _i32, _p, _sz, _p]),
     "egnn_ce_kd_ws_floats": (_sz, [_i64]),
     "egnn_ce_kd_fwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _f32, _p, _p, _p]),
     "egnn_ce_kd_bwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _f32, _p, _p, _p, _i64, _p]),

@@ -18,9 +18,10 @@ struct GemmArgs {
   int split_k;
   int64_t k_per_split;     // multiple of BK
   float* ws;               // [split_k, M, N] when split_k > 1
+  const int64_t* rows;     // GATHER 1: storage rows of A ([M,K]) ; GATHER 2: storage rows of B ([K,N]); else unused
 };
 
-template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4>
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   using TS = TileShape<BM, BN>;
   __shared__ __attribute__((aligned(16))) float smem[TS::SMEM_FLOATS];
@@ -35,7 +36,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   f32x16 acc[TS::TM][TS::TN];
   zero_acc(acc);
   IdentityXf id;
-  mainloop<BM, BN, AMAJ, BMAJ, VEC4>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kend, id, id, smem);
+  mainloop<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kend, id, id,
+                                                                        smem, g.rows, g.rows);
 
   const int lane = egnn_lane();
   const int wave = egnn_wave_id();
@@ -71,32 +73,34 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
   }
 }
 
-template <int BM, int BN, int AMAJ, int BMAJ>
+template <int BM, int BN, int AMAJ, int BMAJ, int GATHER = 0>
 int launch_tile(const GemmArgs& g, bool vec4, hipStream_t st) {
   const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   if (tiles > 0x7fffffffLL) return EGNN_EINVAL;
   dim3 grid((unsigned)tiles, (unsigned)g.split_k);
-  if (vec4) hipLaunchKernelGGL((gemm_kernel<BM, BN, AMAJ, BMAJ, true>), grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((gemm_kernel<BM, BN, AMAJ, BMAJ, false>), grid, dim3(256), 0, st, g);
+  if (vec4) hipLaunchKernelGGL((gemm_kernel<BM, BN, AMAJ, BMAJ, true, GATHER>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gemm_kernel<BM, BN, AMAJ, BMAJ, false, GATHER>), grid, dim3(256), 0, st, g);
   return EGNN_OK;
 }
 
-template <int AMAJ, int BMAJ>
+template <int AMAJ, int BMAJ, int GATHER = 0>
 int launch_major(const GemmArgs& g, bool vec4, hipStream_t st) {
   // narrow outputs (N <= 64, e.g. the 40-class layer) take the 128x64 tile
-  if (g.N <= 64) return launch_tile<128, 64, AMAJ, BMAJ>(g, vec4, st);
-  return launch_tile<128, 128, AMAJ, BMAJ>(g, vec4, st);
+  if (g.N <= 64) return launch_tile<128, 64, AMAJ, BMAJ, GATHER>(g, vec4, st);
+  return launch_tile<128, 128, AMAJ, BMAJ, GATHER>(g, vec4, st);
 }
 
 }  // namespace
 
-extern "C" int egnn_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
-                             int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
-                             int split_k, float* ws, size_t ws_bytes, void* stream) {
+static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                     const int64_t* a_rows, const float* B, int64_t ldb, const int64_t* b_rows, const float* bias, float* C,
+                     int64_t ldc, int split_k, float* ws, size_t ws_bytes, void* stream) {
   EGNN_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
   if (M == 0 || N == 0) return EGNN_OK;
   EGNN_CHECK_ARG(A && B && C && ldc >= N);
   EGNN_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N));
+  // fused row gathers: rows of an [M,K]-stored A (the operand of x[idx] @ W^T) or of a [K,N]-stored B (dW = dY^T x[idx])
+  EGNN_CHECK_ARG(!(a_rows && b_rows) && !(a_rows && trans_a) && !(b_rows && trans_b));
   if (split_k < 1) split_k = 1;
   int64_t ksteps = (K + BK - 1) / BK;
   if (split_k > ksteps) split_k = (int)(ksteps > 0 ? ksteps : 1);
@@ -104,13 +108,17 @@ extern "C" int egnn_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int
     if (!ws || ws_bytes < (size_t)split_k * M * N * sizeof(float)) return EGNN_EWORKSPACE;
   }
   GemmArgs g{M, N, K, A, lda, B, ldb, bias, C, ldc, alpha, nullptr, split_k,
-             ((ksteps + split_k - 1) / split_k) * BK, ws};
+             ((ksteps + split_k - 1) / split_k) * BK, ws, a_rows ? a_rows : b_rows};
   hipStream_t st = (hipStream_t)stream;
   const bool vec4 = (lda % 4 == 0) && (ldb % 4 == 0) && egnn_aligned16(A) && egnn_aligned16(B);
   const int amaj = trans_a ? MNMAJOR : KMAJOR;   // A stored [K,M] when transposed
   const int bmaj = trans_b ? KMAJOR : MNMAJOR;   // B stored [N,K] when transposed, else [K,N]
   int rc;
-  if (amaj == KMAJOR && bmaj == KMAJOR) rc = launch_major<KMAJOR, KMAJOR>(g, vec4, st);
+  if (a_rows) {
+    rc = bmaj == KMAJOR ? launch_major<KMAJOR, KMAJOR, 1>(g, vec4, st) : launch_major<KMAJOR, MNMAJOR, 1>(g, vec4, st);
+  } else if (b_rows) {
+    rc = amaj == KMAJOR ? launch_major<KMAJOR, MNMAJOR, 2>(g, vec4, st) : launch_major<MNMAJOR, MNMAJOR, 2>(g, vec4, st);
+  } else if (amaj == KMAJOR && bmaj == KMAJOR) rc = launch_major<KMAJOR, KMAJOR>(g, vec4, st);
   else if (amaj == KMAJOR) rc = launch_major<KMAJOR, MNMAJOR>(g, vec4, st);
   else if (bmaj == KMAJOR) rc = launch_major<MNMAJOR, KMAJOR>(g, vec4, st);
   else rc = launch_major<MNMAJOR, MNMAJOR>(g, vec4, st);
@@ -120,4 +128,17 @@ extern "C" int egnn_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, g);
   }
   return egnn_launch_status();
+}
+
+extern "C" int egnn_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                             int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
+                             int split_k, float* ws, size_t ws_bytes, void* stream) {
+  return gemm_impl(trans_a, trans_b, M, N, K, alpha, A, lda, nullptr, B, ldb, nullptr, bias, C, ldc, split_k, ws, ws_bytes, stream);
+}
+
+extern "C" int egnn_gemm_rows_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A,
+                                  int64_t lda, const int64_t* a_rows, const float* B, int64_t ldb, const int64_t* b_rows,
+                                  const float* bias, float* C, int64_t ldc, int split_k, float* ws, size_t ws_bytes,
+                                  void* stream) {
+  return gemm_impl(trans_a, trans_b, M, N, K, alpha, A, lda, a_rows, B, ldb, b_rows, bias, C, ldc, split_k, ws, ws_bytes, stream);
 }

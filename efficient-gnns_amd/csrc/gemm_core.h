@@ -38,7 +38,9 @@ struct IdentityXf {
 
 // Stages one operand tile of R rows x BK through registers into LDS.  XF transforms in-range elements
 // (value, global row, global k) on the way; out-of-range elements are exact zeros.
-template <int R, int MAJOR, bool VEC4, class XF>
+// GATHER: storage row i of the operand is row ridx[i] of the matrix at p (a row gather fused into the load: k-major
+// operands gather their `rows`, [K,rows] operands gather along k).
+template <int R, int MAJOR, bool VEC4, class XF, bool GATHER = false>
 struct Stager {
   static constexpr int NV = R * BK / 1024;  // float4 per thread per k-step
   static constexpr int RPP = 256 / KQ;        // k-major: rows covered per pass of the 256 threads
@@ -47,14 +49,16 @@ struct Stager {
   // FULL: the whole R x BK tile is in range (block-uniform) -> straight-line vector loads, no per-element guards
   template <bool FULL>
   __device__ __forceinline__ void load_impl(const float* __restrict__ p, int64_t ld, int64_t r0, int64_t rmax, int64_t k0,
-                                            int64_t kmax, const XF& xf) {
+                                            int64_t kmax, const XF& xf, const int64_t* __restrict__ ridx) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       if constexpr (MAJOR == KMAJOR) {
         const int64_t r = r0 + t / KQ + RPP * i;
         const int64_t k = k0 + (t % KQ) * 4;
-        const float* q = p + r * ld + k;
+        int64_t rs = r;
+        if constexpr (GATHER) rs = (FULL || r < rmax) ? ridx[r] : 0;
+        const float* q = p + rs * ld + k;
         if constexpr (FULL) {
           float x0, x1, x2, x3;
           if constexpr (VEC4) { const float4 x = *reinterpret_cast<const float4*>(q); x0 = x.x; x1 = x.y; x2 = x.z; x3 = x.w; }
@@ -69,7 +73,9 @@ struct Stager {
         constexpr int KPP = 256 / TPR;      // k-rows per pass
         const int64_t k = k0 + t / TPR + KPP * i;
         const int64_t r = r0 + (t % TPR) * 4;
-        const float* q = p + k * ld + r;
+        int64_t ks = k;
+        if constexpr (GATHER) ks = (FULL || k < kmax) ? ridx[k] : 0;
+        const float* q = p + ks * ld + r;
         if constexpr (FULL) {
           float x0, x1, x2, x3;
           if constexpr (VEC4) { const float4 x = *reinterpret_cast<const float4*>(q); x0 = x.x; x1 = x.y; x2 = x.z; x3 = x.w; }
@@ -87,13 +93,13 @@ struct Stager {
   // masks and addresses otherwise get hoisted into the caller's loops and cost ~100 registers)
   template <bool FULLONLY = false>
   __device__ __forceinline__ void load(const float* __restrict__ p, int64_t ld, int64_t r0, int64_t rmax, int64_t k0,
-                                       int64_t kmax, const XF& xf) {
+                                       int64_t kmax, const XF& xf, const int64_t* __restrict__ ridx = nullptr) {
     if constexpr (FULLONLY) {
-      load_impl<true>(p, ld, r0, rmax, k0, kmax, xf);
+      load_impl<true>(p, ld, r0, rmax, k0, kmax, xf, ridx);
     } else {
       const bool full = (r0 + R <= rmax) && (k0 + BK <= kmax);  // block-uniform
-      if (full) load_impl<true>(p, ld, r0, rmax, k0, kmax, xf);
-      else load_impl<false>(p, ld, r0, rmax, k0, kmax, xf);
+      if (full) load_impl<true>(p, ld, r0, rmax, k0, kmax, xf, ridx);
+      else load_impl<false>(p, ld, r0, rmax, k0, kmax, xf, ridx);
     }
   }
 
@@ -147,20 +153,22 @@ __device__ __forceinline__ int acc_col(int wn, int tn, int lane) {
 // The software pipeline of one workgroup: operand tiles travel global -> registers (prefetch) -> LDS (commit, inside
 // step) -> MFMA fragments.  mainloop() below drives it for one output tile; kernels that walk several tiles (G-CRD
 // forward) drive it themselves so that the first k-step of the next tile is already in flight during an epilogue.
-template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY, class XFA, class XFB>
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY, class XFA, class XFB, bool GA = false, bool GB = false>
 struct Pipeline {
   using TS = TileShape<BM, BN>;
   // plain offset arithmetic on the __shared__ base keeps the LDS address space visible to the compiler
   // (an array of buffer pointers indexed by `cur` decays to flat loads, which also drain the global prefetch)
   static constexpr int A_BUF = BM * LDS_LD, B_BUF = BN * LDS_LD, B_OFF = 2 * BM * LDS_LD;
-  Stager<BM, AMAJ, VEC4, XFA> sa;
-  Stager<BN, BMAJ, VEC4, XFB> sb;
+  Stager<BM, AMAJ, VEC4, XFA, GA> sa;
+  Stager<BN, BMAJ, VEC4, XFB, GB> sb;
+  const int64_t* arows = nullptr;  // GA / GB: storage-row indirection of A / B (see Stager)
+  const int64_t* brows = nullptr;
 
   __device__ __forceinline__ void prefetch(const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
                                            const float* __restrict__ B, int64_t ldb, int64_t n0, int64_t N, int64_t k0,
                                            int64_t kend, const XFA& xfa, const XFB& xfb) {
-    sa.template load<FULLONLY>(A, lda, m0, M, k0, kend, xfa);
-    sb.template load<FULLONLY>(B, ldb, n0, N, k0, kend, xfb);
+    sa.template load<FULLONLY>(A, lda, m0, M, k0, kend, xfa, arows);
+    sb.template load<FULLONLY>(B, ldb, n0, N, k0, kend, xfb, brows);
   }
   __device__ __forceinline__ void commit(float* smem, int buf) const {
     sa.store(smem + buf * A_BUF);
@@ -197,12 +205,16 @@ struct Pipeline {
 };
 
 // acc += A[m0:m0+BM, kbeg:kend] * B[kbeg:kend, n0:n0+BN]   (all 256 threads must call with equal bounds)
-template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY = false, class XFA, class XFB, int TM_, int TN_>
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY = false, bool GA = false, bool GB = false, class XFA, class XFB,
+          int TM_, int TN_>
 __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM_][TN_],
                                          const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
                                          const float* __restrict__ B, int64_t ldb, int64_t n0, int64_t N,
-                                         int64_t kbeg, int64_t kend, const XFA& xfa, const XFB& xfb, float* smem) {
-  Pipeline<BM, BN, AMAJ, BMAJ, VEC4, FULLONLY, XFA, XFB> pipe;
+                                         int64_t kbeg, int64_t kend, const XFA& xfa, const XFB& xfb, float* smem,
+                                         const int64_t* arows = nullptr, const int64_t* brows = nullptr) {
+  Pipeline<BM, BN, AMAJ, BMAJ, VEC4, FULLONLY, XFA, XFB, GA, GB> pipe;
+  pipe.arows = arows;
+  pipe.brows = brows;
   const int nk = (int)((kend - kbeg + BK - 1) / BK);
   if (nk <= 0) return;
   const int lane = egnn_lane();

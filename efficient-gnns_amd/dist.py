@@ -308,6 +308,8 @@ class ShardedProblem:
         self.x = data.x[lo:hi].to(device)
         self.y = data.y[lo:hi].to(device)
         self.teacher_out_feat = data.teacher_out_feat[lo:hi].to(device) if getattr(data, "teacher_out_feat", None) is not None else None
+        if self.teacher_out_feat is not None and self.teacher_out_feat.is_cuda:
+            self.teacher_out_feat = ops.pad_pitch(self.teacher_out_feat)   # 750 floats per row -> 16-byte aligned rows
         self.teacher_logits = data.teacher_logits[lo:hi].to(device) if getattr(data, "teacher_logits", None) is not None else None
         # global train order (gnn.py:243-244) restricted to my range; positions keep the global order
         tr = data.split_idx["train"]
@@ -367,8 +369,12 @@ def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: di
         loss = loss_aux * (hp["alpha"] * hp["kd_T"] ** 2) + loss_cls * (1 - hp["alpha"])
     elif mode == "nce":
         loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else zero
-        f = student_proj(take(model.out_feat, prob.train_local))
-        t = teacher_proj(take(prob.teacher_out_feat, prob.train_local))
+        if hasattr(student_proj, "forward_rows") and prob.x.is_cuda:
+            f = student_proj.forward_rows(model.out_feat, prob.train_local)
+            t = teacher_proj.forward_rows(prob.teacher_out_feat, prob.train_local)
+        else:
+            f = student_proj(take(model.out_feat, prob.train_local))
+            t = teacher_proj(take(prob.teacher_out_feat, prob.train_local))
         S = hp["max_samples"]
         ntr = prob.n_train_global
         pick = np.random.choice(ntr, S, replace=False) if S < ntr else np.arange(ntr)   # same draw on every rank

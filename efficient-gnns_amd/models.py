@@ -82,6 +82,18 @@ class ProjectionHead(nn.Sequential):
             return super().forward(x)
         return ops.bn_act(ops.linear(x, lin.weight, lin.bias), bn, relu=True, p=0.0, training=self.training)
 
+    def forward_rows(self, x, idx):
+        """``self(x[idx])`` for unique row ids: the gather is fused into the GEMM's operand load (gnn.py:150-156)."""
+        lin, bn = self[0], self[1]
+        if not x.is_cuda:
+            return self(x[idx])
+        y = ops.linear_rows(x, idx, lin.weight, lin.bias)
+        if hasattr(bn, "fused_act"):                            # dist.SyncBatchNorm1d
+            return bn.fused_act(y, True, 0.0, self.training)
+        if not isinstance(bn, nn.BatchNorm1d):
+            return self[2](bn(y))
+        return ops.bn_act(y, bn, relu=True, p=0.0, training=self.training)
+
 
 def make_projection(in_dim, proj_dim):
     return ProjectionHead(in_dim, proj_dim)
@@ -113,8 +125,12 @@ def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_
     if mode == "kd":
         return C.kd_criterion(out, labels, _const_rows(teacher_logits, train_idx), hp["alpha"], hp["kd_T"])
     if mode in ("fitnet", "gpw", "nce"):
-        f = student_proj(ops.take_rows(model.out_feat, train_idx))
-        t = teacher_proj(_const_rows(teacher_out_feat, train_idx))
+        if hasattr(student_proj, "forward_rows") and hasattr(teacher_proj, "forward_rows") and not _CACHE_CONST_ROWS:
+            f = student_proj.forward_rows(model.out_feat, train_idx)       # proj(feat[train_idx]) without the copies
+            t = teacher_proj.forward_rows(teacher_out_feat, train_idx)
+        else:
+            f = student_proj(ops.take_rows(model.out_feat, train_idx))
+            t = teacher_proj(_const_rows(teacher_out_feat, train_idx))
     elif mode in ("at", "lpw"):
         f, t = ops.take_rows(model.out_feat, train_idx), _const_rows(teacher_out_feat, train_idx)
     elif mode == "gcd":

@@ -152,13 +152,45 @@ def gemm_backend() -> str:
     return os.environ.get("EGNN_GEMM", "hip")
 
 
+def _pitch_ok(t: Tensor) -> bool:
+    """2-D, unit column stride, rows 16-byte aligned: the kernels' float4 path takes it as it is."""
+    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+
+
+def _gemm_operand(t: Tensor) -> Tensor:
+    """A row-major view the kernels can address: kept as it is when only its row pitch is padded (see pad_pitch)."""
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1]:
+        return t
+    return _rowmajor(t)
+
+
+def pad_pitch(t: Tensor) -> Tensor:
+    """The same [n, C] values behind a row pitch that is a multiple of 4 floats (a view of an [n, C+pad] buffer), so
+    that rows start 16-byte aligned and the GEMM / gather kernels can use float4 loads (C = 750 teacher features)."""
+    n, C = t.shape
+    if C % 4 == 0 and _pitch_ok(t):
+        return t
+    buf = torch.zeros(n, (C + 3) // 4 * 4, dtype=t.dtype, device=t.device)
+    buf[:, :C] = t
+    return buf[:, :C]
+
+
 def gemm_raw(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False, bias: Tensor | None = None,
-             alpha: float = 1.0, split_k: int | None = None) -> Tensor:
-    """C = alpha * op(a) @ op(b) (+ bias) via egnn_gemm_f32."""
+             alpha: float = 1.0, split_k: int | None = None, a_rows: Tensor | None = None, b_rows: Tensor | None = None) -> Tensor:
+    """C = alpha * op(a) @ op(b) (+ bias) via egnn_gemm_f32 / egnn_gemm_rows_f32.
+
+    a_rows [M] (trans_a False): op(a) = a[a_rows];  b_rows [K] (trans_b False): b = b[b_rows] -- the gather is fused
+    into the operand load."""
     _lib.require_gpu(a, b)
-    a, b = _rowmajor(a), _rowmajor(b)
-    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
-    Kb, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    a, b = _gemm_operand(a), _gemm_operand(b)
+    if a_rows is not None:
+        M, K = a_rows.numel(), a.shape[1]
+    else:
+        M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    if b_rows is not None:
+        Kb, N = b_rows.numel(), b.shape[1]
+    else:
+        Kb, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
     if K != Kb:
         raise ValueError(f"gemm: inner dimensions differ ({K} vs {Kb})")
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
@@ -169,10 +201,18 @@ def gemm_raw(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False,
     ws = None
     if split_k > 1:
         ws = torch.empty(split_k * M * N, dtype=torch.float32, device=a.device)
-    rc = _lib.load().egnn_gemm_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.ptr(a), a.stride(0), _lib.ptr(b),
-                                   b.stride(0), _lib.ptr(bias), _lib.ptr(c), c.stride(0), split_k, _lib.ptr(ws),
-                                   0 if ws is None else ws.numel() * 4, _lib.stream())
-    _lib.check(rc, "egnn_gemm_f32")
+    lib = _lib.load()
+    if a_rows is None and b_rows is None:
+        rc = lib.egnn_gemm_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.ptr(a), a.stride(0), _lib.ptr(b),
+                               b.stride(0), _lib.ptr(bias), _lib.ptr(c), c.stride(0), split_k, _lib.ptr(ws),
+                               0 if ws is None else ws.numel() * 4, _lib.stream())
+        _lib.check(rc, "egnn_gemm_f32")
+    else:
+        _lib.require_gpu(*(t for t in (a_rows, b_rows) if t is not None))
+        rc = lib.egnn_gemm_rows_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.ptr(a), a.stride(0), _lib.ptr(a_rows),
+                                    _lib.ptr(b), b.stride(0), _lib.ptr(b_rows), _lib.ptr(bias), _lib.ptr(c), c.stride(0), split_k,
+                                    _lib.ptr(ws), 0 if ws is None else ws.numel() * 4, _lib.stream())
+        _lib.check(rc, "egnn_gemm_rows_f32")
     return c
 
 
@@ -204,6 +244,39 @@ def matmul(x: Tensor, w: Tensor, bias: Tensor | None = None) -> Tensor:
     if gemm_backend() == "blas":
         return x @ w if bias is None else torch.addmm(bias, x, w)
     return _MatMul.apply(x, w, bias, False)
+
+
+class _LinearRows(torch.autograd.Function):
+    """y = x[idx] @ weight^T + bias for UNIQUE row ids, without materialising x[idx] (egnn_gemm_rows_f32): the forward
+    gathers in the A-operand load, dW = dY^T x[idx] in the B-operand load, dx scatters the rows of dY W."""
+
+    @staticmethod
+    def forward(ctx, x, idx, weight, bias):
+        w = pad_pitch(weight) if not _pitch_ok(weight) else weight   # 0.8 MB at 256 x 750: rows 16-byte aligned
+        ctx.save_for_backward(x, idx, w)
+        ctx.has_bias = bias is not None
+        return gemm_raw(x, w, False, True, bias, a_rows=idx)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, idx, w = ctx.saved_tensors
+        gy = _rowmajor(gy)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.zeros(x.shape, dtype=gy.dtype, device=gy.device)
+            gx.index_copy_(0, idx, gemm_raw(gy, w, False, False))
+        if ctx.needs_input_grad[2]:
+            gw = gemm_raw(gy, x, True, False, b_rows=idx)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            gb = gy.sum(0)
+        return gx, None, gw, gb
+
+
+def linear_rows(x: Tensor, idx: Tensor, weight: Tensor, bias: Tensor | None = None) -> Tensor:
+    """``F.linear(x[idx], weight, bias)`` with the row gather fused into the GEMM (unique ``idx``)."""
+    if gemm_backend() == "blas" or not x.is_cuda:
+        return torch.nn.functional.linear(take_rows(x, idx), weight, bias)
+    return _LinearRows.apply(x, idx, weight, bias)
 
 
 def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None) -> Tensor:

@@ -129,6 +129,16 @@ int egnn_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, flo
                   const float* A, int64_t lda, const float* B, int64_t ldb,
                   const float* bias, float* C, int64_t ldc,
                   int split_k, float* ws, size_t ws_bytes, void* stream);
+/* The same GEMM with a row gather fused into one operand's load, for the `feat[train_idx]` gathers in front of the
+ * projection heads (/root/reference/arxiv_pyg/gnn.py:150-156: `out_feat[train_idx]`, `teacher_out_feat[train_idx]`,
+ * the latter 273 MB read + written per step in the reference):
+ *   a_rows [M] (requires trans_a == 0): row m of op(A) is row a_rows[m] of the matrix at A        (y = x[idx] W^T)
+ *   b_rows [K] (requires trans_b == 0): row k of B      is row b_rows[k] of the matrix at B        (dW = dY^T x[idx])
+ * At most one of them; both NULL = egnn_gemm_f32.  Ids must be valid row numbers (not checked on the device). */
+int egnn_gemm_rows_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha,
+                       const float* A, int64_t lda, const int64_t* a_rows, const float* B, int64_t ldb, const int64_t* b_rows,
+                       const float* bias, float* C, int64_t ldc,
+                       int split_k, float* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused losses (K5-K7).  Every loss entry point comes as fwd (scalars out) + bwd (input grads out);
