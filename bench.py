@@ -77,7 +77,9 @@ def build_problem(M, data, device, args, hp):
         sp = M.make_projection(MODEL["hidden"], hp["proj_dim"]).to(device)
         tp = M.make_projection(data.teacher_out_feat.shape[1], hp["proj_dim"]).to(device)
         groups += [{"params": sp.parameters(), "lr": MODEL["lr"]}, {"params": tp.parameters(), "lr": MODEL["lr"]}]
-    opt = torch.optim.Adam(groups)
+    # the single-kernel (fused) implementation of the same torch.optim.Adam update (gnn.py:308-312); EGNN_ADAM=foreach
+    # selects PyTorch's default multi-kernel path
+    opt = torch.optim.Adam(groups, fused=(os.environ.get("EGNN_ADAM", "fused") == "fused"))
     return model, sp, tp, opt
 
 

@@ -21,6 +21,30 @@ struct GemmArgs {
   const int64_t* rows;     // GATHER 1: storage rows of A ([M,K]) ; GATHER 2: storage rows of B ([K,N]); else unused
 };
 
+// epilogue of one output tile (or of one split-K partial)
+template <int BM, int BN, int TM_, int TN_>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[TM_][TN_], const GemmArgs& g, int64_t m0, int64_t n0, int split,
+                                           int lane, int wm, int wn) {
+  const bool partial = g.split_k > 1;
+  const float alpha = partial ? 1.f : g.alpha * (g.alpha_dev ? g.alpha_dev[0] : 1.f);
+  float* out = partial ? g.ws + (int64_t)split * g.M * g.N : g.C;
+  const int64_t ldo = partial ? g.N : g.ldc;
+#pragma unroll
+  for (int tn = 0; tn < TN_; ++tn) {
+    const int64_t c = n0 + acc_col<BM, BN>(wn, tn, lane);
+    if (c >= g.N) continue;
+    const float bv = (!partial && g.bias) ? g.bias[c] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM_; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + acc_row<BM, BN>(wm, tm, r, lane);
+        if (row < g.M) out[row * ldo + c] = alpha * acc[tm][tn][r] + bv;
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   using TS = TileShape<BM, BN>;
@@ -38,28 +62,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   IdentityXf id;
   mainloop<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kend, id, id,
                                                                         smem, g.rows, g.rows);
-
-  const int lane = egnn_lane();
   const int wave = egnn_wave_id();
-  const int wm = wave >> 1, wn = wave & 1;
-  const bool partial = g.split_k > 1;
-  const float alpha = partial ? 1.f : g.alpha * (g.alpha_dev ? g.alpha_dev[0] : 1.f);
-  float* out = partial ? g.ws + (int64_t)split * g.M * g.N : g.C;
-  const int64_t ldo = partial ? g.N : g.ldc;
-#pragma unroll
-  for (int tn = 0; tn < TS::TN; ++tn) {
-    const int64_t c = n0 + acc_col<BM, BN>(wn, tn, lane);
-    if (c >= g.N) continue;
-    const float bv = (!partial && g.bias) ? g.bias[c] : 0.f;
-#pragma unroll
-    for (int tm = 0; tm < TS::TM; ++tm) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + acc_row<BM, BN>(wm, tm, r, lane);
-        if (row < g.M) out[row * ldo + c] = alpha * acc[tm][tn][r] + bv;
-      }
-    }
-  }
+  store_tile<BM, BN>(acc, g, m0, n0, split, egnn_lane(), wave >> 1, wave & 1);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {

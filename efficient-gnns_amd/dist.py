@@ -453,7 +453,8 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
         sp = swap_batchnorm(PM.make_projection(model_cfg["hidden"], hp["proj_dim"]).to(device))
         tp = swap_batchnorm(PM.make_projection(data.teacher_out_feat.shape[1], hp["proj_dim"]).to(device))
         groups += [{"params": sp.parameters(), "lr": model_cfg["lr"]}, {"params": tp.parameters(), "lr": model_cfg["lr"]}]
-    opt = torch.optim.Adam(groups)
+    import os
+    opt = torch.optim.Adam(groups, fused=(on_gpu and os.environ.get("EGNN_ADAM", "fused") == "fused"))
     torch.manual_seed(args.seed + 1000 + rank)               # dropout masks differ per shard
 
     def epoch():
