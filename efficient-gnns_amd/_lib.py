@@ -20,6 +20,7 @@ SIGNATURES = {
     "egnn_error_string": (C.c_char_p, [_i32]),
     "egnn_build_info": (_i32, [C.c_char_p, _sz]),
     "egnn_spmm_csr_f32": (_i32, [_i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p, _i64, _p, _i64, _p, _i64, _p]),
+    "egnn_spmm_csr_seg_f32": (_i32, [_i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p]),
     "egnn_spmm_csr_max_bwd_f32": (_i32, [_i64, _i64, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p]),
     "egnn_spmm_algorithmic_bytes": (_i64, [_i64, _i64, _i64, _i64, _i32, _i32]),
     "egnn_rowptr_from_sorted_rows_i64": (_i32, [_p, _i64, _i64, _p, _p]),

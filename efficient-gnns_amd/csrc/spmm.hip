@@ -35,6 +35,8 @@ struct SpmmArgs {
   int64_t* argmax;
   const int64_t* rows;  // row list walked by the launch (nullptr: rows 0..n_list-1)
   int64_t n_list;
+  const int64_t* seg;   // segment schedule (short-row kernel only): [n_list,3] = (first entry, end entry, destination)
+  float* P;             // partial sums of the rows that were cut into several segments: [slots, K], ld = K
   int logG;      // lanes per neighbour = 1 << logG
   int NS;        // number of column slices
   int map_mode;  // 0: slice = b % NS ; 1: NS divides 8 ; 2: NS multiple of 8
@@ -304,9 +306,15 @@ __global__ __launch_bounds__(256) void spmm_short_rows_kernel(const SpmmArgs<Idx
       const bool live = sg < a.n_list;
       int64_t row = 0, start = 0, end = 0;
       if (live) {
-        row = a.rows ? a.rows[sg] : sg;
-        start = (int64_t)a.rowptr[row];
-        end = (int64_t)a.rowptr[row + 1];
+        if (a.seg) {  // explicit entry range; destination < n_rows: that row of Y, else a slot of the partial buffer
+          start = a.seg[3 * sg];
+          end = a.seg[3 * sg + 1];
+          row = a.seg[3 * sg + 2];
+        } else {
+          row = a.rows ? a.rows[sg] : sg;
+          start = (int64_t)a.rowptr[row];
+          end = (int64_t)a.rowptr[row + 1];
+        }
       }
       float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
       for (int64_t e = start; e < end; e += G) {
@@ -341,14 +349,72 @@ __global__ __launch_bounds__(256) void spmm_short_rows_kernel(const SpmmArgs<Idx
         }
       }
       if (live && colok) {
-        const int64_t cnt = end - start;
-        const float inv = a.mean ? 1.f / (float)(cnt > 0 ? cnt : 1) : 1.f;
-        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + col0);
-        *reinterpret_cast<float4*>(a.Y + row * a.ldy + col0) =
-            make_float4(acc0 * inv + b.x, acc1 * inv + b.y, acc2 * inv + b.z, acc3 * inv + b.w);
+        if (row >= a.n_rows) {  // one segment of a long row: raw partial sum, finished by spmm_combine_kernel
+          *reinterpret_cast<float4*>(a.P + (row - a.n_rows) * a.K + col0) = make_float4(acc0, acc1, acc2, acc3);
+        } else {
+          const int64_t cnt = end - start;
+          const float inv = a.mean ? 1.f / (float)(cnt > 0 ? cnt : 1) : 1.f;
+          float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + col0);
+          *reinterpret_cast<float4*>(a.Y + row * a.ldy + col0) =
+              make_float4(acc0 * inv + b.x, acc1 * inv + b.y, acc2 * inv + b.z, acc3 * inv + b.w);
+        }
       }
     }
+  }
+}
+
+// Y[row] = (sum of the row's segment partials) * inv + bias, for the rows cut into several segments.  One workgroup per
+// row: 256 / kvp slot lanes per float4 column (kvp = columns rounded up to a power of two) each add every (256/kvp)-th
+// slot with four loads in flight, then the lanes of a column are added in lane order -- a fixed order, so bit-stable;
+// a hub of 12 505 entries has 196 slots, which one thread per column would walk as 196 dependent-latency steps.
+template <typename IdxT>
+__global__ __launch_bounds__(256) void spmm_combine_kernel(const SpmmArgs<IdxT> a, const int64_t* __restrict__ crow,
+                                                           const int64_t* __restrict__ cptr, int kvp_log) {
+  __shared__ float4 red[256];
+  const int64_t kv = a.K >> 2;
+  const int kvp = 1 << kvp_log;
+  const int nsl = 256 >> kvp_log;
+  const int t = threadIdx.x;
+  const int sl = t >> kvp_log;
+  const int64_t row = crow[blockIdx.x];
+  const int64_t p0 = cptr[blockIdx.x], p1 = cptr[blockIdx.x + 1];
+  for (int64_t cb = 0; cb < kv; cb += kvp) {   // one pass unless K > 1024
+    const int64_t cv = cb + (t & (kvp - 1));
+    const bool ok = cv < kv;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) {
+      const float* base = a.P + cv * 4;
+      int64_t p = p0 + sl;
+      for (; p + 3 * nsl < p1; p += 4 * nsl) {
+        const float4 v0 = *reinterpret_cast<const float4*>(base + p * a.K);
+        const float4 v1 = *reinterpret_cast<const float4*>(base + (p + nsl) * a.K);
+        const float4 v2 = *reinterpret_cast<const float4*>(base + (p + 2 * nsl) * a.K);
+        const float4 v3 = *reinterpret_cast<const float4*>(base + (p + 3 * nsl) * a.K);
+        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+        s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+        s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+        s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+      }
+      for (; p < p1; p += nsl) {
+        const float4 v = *reinterpret_cast<const float4*>(base + p * a.K);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    red[t] = s;
+    __syncthreads();
+    if (sl == 0 && ok) {
+      for (int l = 1; l < nsl; ++l) {
+        const float4 v = red[(l << kvp_log) + t];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      const int64_t cnt = (int64_t)a.rowptr[row + 1] - (int64_t)a.rowptr[row];
+      const float inv = a.mean ? 1.f / (float)(cnt > 0 ? cnt : 1) : 1.f;
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + cv * 4);
+      *reinterpret_cast<float4*>(a.Y + row * a.ldy + cv * 4) = make_float4(s.x * inv + b.x, s.y * inv + b.y, s.z * inv + b.z, s.w * inv + b.w);
+    }
+    __syncthreads();
   }
 }
 
@@ -439,6 +505,43 @@ int dispatch(SpmmArgs<IdxT> a, int reduce, const RowPlan& plan, hipStream_t st) 
   return vec4 ? launch<IdxT, 4, false>(a, plan, st) : launch<IdxT, 1, false>(a, plan, st);
 }
 
+// segment schedule: every row is one or more entry ranges of at most ~64 entries, all of them walked by the
+// sub-group-per-row kernel; rows with several ranges are finished by spmm_combine_kernel
+template <typename IdxT>
+int launch_segments(SpmmArgs<IdxT> a, const int64_t* seg, int64_t n_seg, const int64_t* crow, const int64_t* cptr, int64_t n_comb,
+                    float* partial, hipStream_t st) {
+  const int64_t kv = a.K / 4;
+  if (kv % 8 == 0) {
+    a.logG = 3;
+    a.NS = (int)(kv / 8);
+  } else {
+    a.logG = ilog2_ceil(kv < 64 ? kv : 64);
+    a.NS = (int)((kv + (1 << a.logG) - 1) >> a.logG);
+  }
+  if (a.logG != 3 && a.logG != 4) return EGNN_EALIGN;
+  a.map_mode = (a.NS <= 8 && 8 % a.NS == 0) ? 1 : (a.NS % 8 == 0 ? 2 : 0);
+  a.seg = seg;
+  a.P = partial;
+  a.rows = nullptr;
+  a.n_list = n_seg;
+  const int npw = 64 >> a.logG;
+  const int64_t n_groups = (n_seg + npw - 1) / npw;
+  const int teams = a.map_mode == 1 ? a.NS : (a.map_mode == 2 ? 8 : 1);
+  int64_t blocks = (n_groups + 3) / 4 * teams;
+  blocks = (blocks + 7) / 8 * 8;
+  if (blocks > 0x7ffffff8LL) return EGNN_EINVAL;
+  if (n_seg > 0) {
+    if (a.logG == 3) hipLaunchKernelGGL((spmm_short_rows_kernel<IdxT, 3>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((spmm_short_rows_kernel<IdxT, 4>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+  }
+  if (n_comb > 0) {
+    if (n_comb > 0x7fffffffLL) return EGNN_EINVAL;
+    int kvp_log = ilog2_ceil(kv < 256 ? kv : 256);
+    hipLaunchKernelGGL((spmm_combine_kernel<IdxT>), dim3((unsigned)n_comb), dim3(256), 0, st, a, crow, cptr, kvp_log);
+  }
+  return egnn_launch_status();
+}
+
 template <typename IdxT>
 __global__ void spmm_max_bwd_kernel(int64_t total, int64_t K, const IdxT* col, const float* val, const int64_t* argmax,
                                     const float* dY, int64_t ldy, float* dX, int64_t ldx) {
@@ -474,12 +577,36 @@ extern "C" int egnn_spmm_csr_f32(int64_t n_rows, int64_t n_src, int64_t K, const
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (index_bits == 32) {
     SpmmArgs<int32_t> a{n_rows, K, (const int32_t*)rowptr, (const int32_t*)col, val, src_scale, bias, X, ldx, Y, ldy,
-                        reduce == EGNN_MEAN, argmax, nullptr, 0, 0, 0, 0};
+                        reduce == EGNN_MEAN, argmax, nullptr, 0, nullptr, nullptr, 0, 0, 0};
     return dispatch(a, reduce, plan, st);
   }
   SpmmArgs<int64_t> a{n_rows, K, (const int64_t*)rowptr, (const int64_t*)col, val, src_scale, bias, X, ldx, Y, ldy,
-                      reduce == EGNN_MEAN, argmax, nullptr, 0, 0, 0, 0};
+                      reduce == EGNN_MEAN, argmax, nullptr, 0, nullptr, nullptr, 0, 0, 0};
   return dispatch(a, reduce, plan, st);
+}
+
+extern "C" int egnn_spmm_csr_seg_f32(int64_t n_rows, int64_t n_src, int64_t K, const void* rowptr, const void* col, int index_bits,
+                                     const float* val, const float* src_scale, const float* bias, const float* X, int64_t ldx,
+                                     float* Y, int64_t ldy, int reduce, const int64_t* seg, int64_t n_seg, const int64_t* comb_rows,
+                                     const int64_t* comb_ptr, int64_t n_comb, float* partial, int64_t partial_slots, void* stream) {
+  EGNN_CHECK_ARG(n_rows >= 0 && n_src >= 0 && K >= 0 && ldx >= K && ldy >= K);
+  EGNN_CHECK_ARG(index_bits == 32 || index_bits == 64);
+  EGNN_CHECK_ARG(reduce == EGNN_SUM || reduce == EGNN_MEAN);
+  if (n_rows == 0 || K == 0) return EGNN_OK;
+  EGNN_CHECK_ARG(rowptr && col && X && Y && n_seg >= 0 && n_comb >= 0 && partial_slots >= 0);
+  EGNN_CHECK_ARG((n_seg == 0 || seg) && (n_comb == 0 || (comb_rows && comb_ptr && partial)));
+  if (K % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || !egnn_aligned16(X) || !egnn_aligned16(Y) || (bias && !egnn_aligned16(bias)) ||
+      (partial && !egnn_aligned16(partial)))
+    return EGNN_EALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (index_bits == 32) {
+    SpmmArgs<int32_t> a{n_rows, K, (const int32_t*)rowptr, (const int32_t*)col, val, src_scale, bias, X, ldx, Y, ldy,
+                        reduce == EGNN_MEAN, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0};
+    return launch_segments(a, seg, n_seg, comb_rows, comb_ptr, n_comb, partial, st);
+  }
+  SpmmArgs<int64_t> a{n_rows, K, (const int64_t*)rowptr, (const int64_t*)col, val, src_scale, bias, X, ldx, Y, ldy,
+                      reduce == EGNN_MEAN, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0};
+  return launch_segments(a, seg, n_seg, comb_rows, comb_ptr, n_comb, partial, st);
 }
 
 extern "C" int egnn_spmm_csr_max_bwd_f32(int64_t n_rows, int64_t K, const void* col, int index_bits, const float* val,

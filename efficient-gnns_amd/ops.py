@@ -35,6 +35,10 @@ def _rowmajor(x: Tensor) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 # SpMM
 # ------------------------------------------------------------------------------------------------
+# 'segments' (default): egnn_spmm_csr_seg_f32; 'classes': short / mid / long row classes of egnn_spmm_csr_f32
+_SPMM_SCHEDULE = os.environ.get("EGNN_SPMM_SCHEDULE", "segments")
+
+
 def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = None, use_plan: bool = True,
              bias: Tensor | None = None):
     """Y = REDUCE(adj, X) on the GPU (egnn_spmm_csr_f32).  Returns (Y, argmax | None)."""
@@ -48,8 +52,20 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
     y = torch.empty(n_rows, K, dtype=torch.float32, device=x.device)
     arg = torch.empty(n_rows, K, dtype=torch.int64, device=x.device) if red == 2 else None
     rowptr, col, bits = adj._index_arrays()
-    short, mid, long_ = adj._row_plan() if use_plan else (None, None, None)
     lib = _lib.load()
+    if (use_plan and _SPMM_SCHEDULE == "segments" and red != 2 and K % 4 == 0 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and (bias is None or bias.data_ptr() % 16 == 0)):
+        # every row as ranges of <= 64 entries through the sub-group-per-row kernel (hub rows get the bulk's parallelism)
+        seg, crow, cptr, slots = adj._seg_plan()
+        partial = torch.empty(max(slots, 1), K, dtype=torch.float32, device=x.device)
+        rc = lib.egnn_spmm_csr_seg_f32(n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), bits, _lib.ptr(adj._value), _lib.ptr(src_scale),
+                                       _lib.ptr(bias), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), red, _lib.ptr(seg),
+                                       seg.shape[0], _lib.ptr(crow), _lib.ptr(cptr), crow.numel(), _lib.ptr(partial), slots, _lib.stream())
+        if rc == 0:
+            return y, None
+        if rc != -4:   # EGNN_EALIGN: shape outside the segment kernel's float4 forms -> classic schedule below
+            _lib.check(rc, "egnn_spmm_csr_seg_f32")
+    short, mid, long_ = adj._row_plan() if use_plan else (None, None, None)
 
     def lst(t):
         return (None, 0) if t is None or t.numel() == 0 else (_lib.ptr(t), t.numel())

@@ -23,6 +23,7 @@ import os
 
 SHORT_ROW_MAX = int(os.environ.get("EGNN_SHORT_ROW_MAX", "64"))    # rows up to this length share a wavefront
 LONG_ROW_THRESHOLD = int(os.environ.get("EGNN_LONG_ROW_MIN", "512"))  # rows above it get a 16-wave workgroup
+SEG_MAX = int(os.environ.get("EGNN_SPMM_SEG_MAX", "64"))   # entries per range of the segment schedule
 PLAN_CHUNK = int(os.environ.get("EGNN_PLAN_CHUNK", "1"))  # >1: length-sort short rows inside chunks of this many rows (measured slower: locality wins)
 
 
@@ -224,6 +225,39 @@ class SparseTensor:
                 short = ids[ids >= 0].contiguous()
             self._struct["plan"] = (short, mid, long_)
         return self._struct["plan"]
+
+    def _seg_plan(self):
+        """Segment schedule for egnn_spmm_csr_seg_f32 (cached per structure): (seg [n_seg,3], comb_rows, comb_ptr, slots).
+
+        Rows with at most SEG_MAX entries are one direct range each, in natural row order (index arrays stay
+        L2-local).  Longer rows are cut into equal ranges of at most SEG_MAX entries that write partial slots; their
+        ranges come first in the list so that the heaviest work is dispatched first."""
+        if "segplan" not in self._struct:
+            rp = self._rowptr
+            dev = rp.device
+            cnt = rp[1:] - rp[:-1]
+            n = cnt.numel()
+            multi = torch.nonzero(cnt > SEG_MAX).view(-1)
+            single = torch.nonzero(cnt <= SEG_MAX).view(-1)
+            direct = torch.stack([rp[single], rp[single + 1], single], dim=1)
+            if multi.numel() > 0:
+                c = cnt[multi]
+                nseg = (c + SEG_MAX - 1) // SEG_MAX
+                cptr = torch.zeros(multi.numel() + 1, dtype=torch.int64, device=dev)
+                torch.cumsum(nseg, 0, out=cptr[1:])
+                slots = int(cptr[-1])
+                owner = torch.repeat_interleave(torch.arange(multi.numel(), device=dev), nseg)   # which multi row a slot belongs to
+                k = torch.arange(slots, device=dev) - cptr[owner]                                  # segment number inside its row
+                # equal split: segment k of a row with c entries and s segments covers [k*c//s, (k+1)*c//s)
+                cs, ss, base = c[owner], nseg[owner], rp[multi][owner]
+                parts = torch.stack([base + (k * cs) // ss, base + ((k + 1) * cs) // ss, n + torch.arange(slots, device=dev)], dim=1)
+                seg = torch.cat([parts, direct], dim=0).contiguous()
+            else:
+                cptr = torch.zeros(1, dtype=torch.int64, device=dev)
+                slots = 0
+                seg = direct.contiguous()
+            self._struct["segplan"] = (seg, multi.contiguous(), cptr.contiguous(), slots)
+        return self._struct["segplan"]
 
     def _inv_rowcount(self) -> Tensor:
         if "invcnt" not in self._struct:
