@@ -249,7 +249,10 @@ def main():
                 traffic = json.load(open(tj)).get("hbm_bytes_per_call")
             except Exception:  # noqa: BLE001
                 traffic = None
-        roofline = dict(bound="hbm", kernel=f"spmm_rows_kernel (egnn_spmm_csr_f32, K={K}, reduce=sum)",
+        sched = getattr(ops, "_SPMM_SCHEDULE", "classes")
+        kern = ("spmm_short_rows_kernel + spmm_combine_kernel (egnn_spmm_csr_seg_f32" if sched == "segments"
+                else "spmm_{short_rows,rows,long_rows}_kernel (egnn_spmm_csr_f32")
+        roofline = dict(bound="hbm", kernel=f"{kern}, K={K}, reduce=sum)",
                         achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                         frac_of_measured_copy_peak=round(gbs / 6290.0, 4),
                         algorithmic_bytes_per_launch=roof["bytes"], avg_launch_us=round(roof["avg_s"] * 1e6, 2),
@@ -268,6 +271,9 @@ def main():
                     gnn=args.gnn, training=args.training, hidden=MODEL["hidden"], layers=MODEL["layers"],
                     max_samples=hp["max_samples"], proj_dim=hp["proj_dim"], nce_T=hp["nce_T"], beta=hp["beta"],
                     gemm_backend=ops.gemm_backend(), partitioning="single GPU",
+                    spmm_schedule=getattr(ops, "_SPMM_SCHEDULE", "classes"),
+                    gcn_operand_order="aggregate on the narrower side of W (layer 1: (A x) W; same product as A (x W))",
+                    adam=os.environ.get("EGNN_ADAM", "fused"),
                     memoise_first_layer_aggregation=os.environ.get("EGNN_GCN_MEMOISE_AX", "0") == "1",
                     cache_constant_row_gathers=os.environ.get("EGNN_CACHE_CONST_ROWS", "0") == "1"),
         roofline=roofline, cpu_baseline=cpu,

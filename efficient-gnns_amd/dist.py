@@ -494,6 +494,16 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
                         mean_halo_rows_per_rank=int(float(halo) / world)),
             roofline=None, cpu_baseline=None,
             last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs])
-        emit(json.dumps(out))
     dist.barrier()
     dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; flush that first so that the JSON line is the LAST line of stdout
+        import ctypes
+        import sys
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        emit(json.dumps(out))
+        sys.stdout.flush()
