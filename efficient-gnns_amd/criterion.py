@@ -18,7 +18,9 @@ __all__ = ["kd_criterion", "fitnet_criterion", "at_criterion", "gpw_criterion", 
 
 
 def _sample_rows(n: int, max_samples: int, device):
-    """criterion.py:62-65,134-137: host NumPy global RNG, exactly one draw; None = keep every row."""
+    """criterion.py:62-65,134-137: host NumPy global RNG, exactly one draw; None = keep every row.
+    (Making the draw earlier in the step -- before the forward, or at the end of the previous step -- was measured:
+    no gain, the step is GPU-bound around it.)"""
     if max_samples < n:
         pick = np.random.choice(n, max_samples, replace=False)
         return torch.from_numpy(pick).to(device=device, dtype=torch.int64, non_blocking=True)

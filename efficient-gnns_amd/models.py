@@ -182,5 +182,9 @@ def evaluate(model, x, adj_t, y, split_idx):
     model.eval()
     out = model(x, adj_t)
     y_pred = out.argmax(dim=-1, keepdim=True)
-    accs = tuple(accuracy(y[split_idx[k]], y_pred[split_idx[k]]) for k in ("train", "valid", "test"))
+    if out.is_cuda:   # the three Evaluator accuracies with ONE device->host read instead of three
+        hit = (y_pred == y).view(-1).to(torch.float32)
+        accs = tuple(torch.stack([hit[split_idx[k]].mean() for k in ("train", "valid", "test")]).tolist())
+    else:
+        accs = tuple(accuracy(y[split_idx[k]], y_pred[split_idx[k]]) for k in ("train", "valid", "test"))
     return out, accs
