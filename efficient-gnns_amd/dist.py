@@ -89,10 +89,13 @@ class _HaloExchange(torch.autograd.Function):
         plan, group = sadj.plan, sadj.group
         K = x_local.shape[1]
         send_buf = x_local.index_select(0, sadj.send_idx_dev).contiguous()
-        recv_buf = torch.empty(plan.n_halo, K, dtype=x_local.dtype, device=x_local.device)
-        dist.all_to_all_single(recv_buf, send_buf, plan.recv_counts, plan.send_counts, group=group)
+        # the halo rows are received straight into the tail of the extended matrix (no concatenation copy of the halo,
+        # which is 7/8 of the matrix at 8 ranks on a graph without locality)
+        x_ext = torch.empty(plan.n_local + plan.n_halo, K, dtype=x_local.dtype, device=x_local.device)
+        x_ext[:plan.n_local].copy_(x_local)
+        dist.all_to_all_single(x_ext[plan.n_local:], send_buf, plan.recv_counts, plan.send_counts, group=group)
         ctx.sadj = sadj
-        return torch.cat([x_local, recv_buf], dim=0)
+        return x_ext
 
     @staticmethod
     def backward(ctx, g_ext):

@@ -10,6 +10,7 @@ import torch
 
 import efficient_gnns_amd as E
 import efficient_gnns_amd.data as D
+from efficient_gnns_amd import _lib
 import oracle.sparse as OS
 import oracle.utils as OU
 from conftest import ROOT
@@ -144,3 +145,64 @@ def test_conv_parameter_layouts_match_pyg_1_7():
     assert n(PM.GCN(128, 256, 40, 2, 0.5)) == 43816 and n(PM.SAGE(128, 256, 40, 2, 0.5)) == 86824
     assert n(PM.GCN(128, 256, 40, 3, 0.5)) == 110120
     assert sorted(PM.make_projection(256, 128).state_dict())[:2] == ["0.bias", "0.weight"]
+
+
+def test_c_abi_argument_errors_are_reported_before_any_launch():
+    """Every entry point validates its arguments on the host and returns a negative EGNN_E* code without enqueueing
+    anything (include/egnn_hip.h conventions) -- callable without a GPU."""
+    lib = _lib.load()
+    EINVAL, EWORKSPACE = -1, None
+    import ctypes
+    buf = (ctypes.c_float * 64)()
+    ibuf = (ctypes.c_int64 * 16)()
+    p, ip = ctypes.addressof(buf), ctypes.addressof(ibuf)
+    # segment SpMM: max is not offered; missing combine arrays; negative sizes
+    assert lib.egnn_spmm_csr_seg_f32(4, 4, 4, ip, ip, 64, None, None, None, p, 4, p, 4, 2, ip, 1, None, None, 0, None, 0, None) < 0
+    assert lib.egnn_spmm_csr_seg_f32(4, 4, 4, ip, ip, 64, None, None, None, p, 4, p, 4, 0, ip, 1, None, None, 2, None, 0, None) < 0
+    assert lib.egnn_spmm_csr_seg_f32(4, 4, 4, ip, ip, 16, None, None, None, p, 4, p, 4, 0, ip, 1, None, None, 0, None, 0, None) < 0
+    assert lib.egnn_spmm_csr_seg_f32(0, 0, 4, None, None, 64, None, None, None, None, 4, None, 4, 0, None, 0, None, None, 0, None, 0, None) == 0
+    # unaligned leading dimension -> EGNN_EALIGN (-4): the host falls back to egnn_spmm_csr_f32
+    assert lib.egnn_spmm_csr_seg_f32(4, 4, 4, ip, ip, 64, None, None, None, p, 5, p, 5, 0, ip, 1, None, None, 0, None, 0, None) == -4
+    # fused-gather GEMM: at most one gather, and only on an untransposed operand
+    assert lib.egnn_gemm_rows_f32(0, 1, 4, 4, 4, 1.0, p, 4, ip, p, 4, ip, None, p, 4, 1, None, 0, None) < 0
+    assert lib.egnn_gemm_rows_f32(1, 1, 4, 4, 4, 1.0, p, 4, ip, p, 4, None, None, p, 4, 1, None, 0, None) < 0
+    assert lib.egnn_gemm_rows_f32(0, 0, 4, 4, 4, 1.0, p, 4, None, p, 4, ip, None, p, 2, 1, None, 0, None) < 0       # ldc < N
+    assert lib.egnn_gemm_f32(0, 0, 4, 4, 64, 1.0, p, 64, p, 4, None, p, 4, 2, None, 0, None) < 0                      # split-K without a workspace
+    # G-CRD: tau must be positive; the backward workspace, when given, must be large enough
+    assert lib.egnn_nce_fwd_f32(p, p, 4, 4, 4, 0.0, 1, p, p, p, p, 1 << 20, None) < 0
+    assert lib.egnn_nce_bwd_f32(p, p, 4, 4, 4, 0.1, 1, p, p, None, p, p, p, 1, None) < 0
+    assert lib.egnn_nce_bwd_ws_floats(0, 4, 4) == 0 and lib.egnn_nce_bwd_ws_floats(128, 128, 16) >= 128 * 16
+    assert lib.egnn_nce_saves_exp(0.075, 1) == 1 and lib.egnn_nce_saves_exp(0.075, 0) == 0 and lib.egnn_nce_saves_exp(0.01, 1) == 0
+    # BatchNorm halves: null pointers
+    assert lib.egnn_bn_act_bwd_reduce_f32(None, 4, p, 4, 4, 4, p, p, 1e-5, p, p, 1, 0.0, 0, p, p, p, 1 << 20, None) < 0
+    assert lib.egnn_bn_act_bwd_apply_f32(p, 4, p, 4, 4, 4, p, p, 1e-5, p, p, 1, 0.0, 0, None, p, 1.0, p, 4, None) < 0
+
+
+def test_segment_plan_covers_every_entry_exactly_once():
+    """SparseTensor._seg_plan (integer preprocessing behind egnn_spmm_csr_seg_f32) on the host: every stored entry is in
+    exactly one range, ranges hold at most SEG_MAX entries, single-range rows write Y directly, the others own
+    consecutive partial slots in row order."""
+    import efficient_gnns_amd.sparse as SP
+    d = D.arxiv_like(scale=0.05, seed=11, with_teacher=False)
+    adj = d.adj_t
+    rowptr, col, _ = adj.csr()
+    n = adj.sparse_size(0)
+    seg, crow, cptr, slots = adj._seg_plan()
+    cnt = rowptr[1:] - rowptr[:-1]
+    assert int((cnt > SP.SEG_MAX).sum()) == crow.numel() > 0
+    length = seg[:, 1] - seg[:, 0]
+    assert int(length.max()) <= SP.SEG_MAX and int(length.min()) >= 0
+    covered = torch.zeros(int(rowptr[-1]) + 1, dtype=torch.int64)
+    covered.index_add_(0, seg[:, 0], torch.ones(seg.shape[0], dtype=torch.int64))
+    covered.index_add_(0, seg[:, 1], -torch.ones(seg.shape[0], dtype=torch.int64))
+    assert torch.equal(torch.cumsum(covered, 0)[:-1], torch.ones(int(rowptr[-1]), dtype=torch.int64))
+    direct = seg[seg[:, 2] < n]
+    assert torch.equal(torch.sort(direct[:, 2]).values, torch.nonzero(cnt <= SP.SEG_MAX).view(-1))
+    assert torch.equal(direct[:, 0], rowptr[direct[:, 2]]) and torch.equal(direct[:, 1], rowptr[direct[:, 2] + 1])
+    part = seg[seg[:, 2] >= n]
+    assert part.shape[0] == slots == int(cptr[-1]) and torch.equal(part[:, 2], n + torch.arange(slots))
+    for i in (0, crow.numel() // 2, crow.numel() - 1):     # slots of a row tile its entry range, in order
+        r = int(crow[i])
+        ps = part[int(cptr[i]):int(cptr[i + 1])]
+        assert int(ps[0, 0]) == int(rowptr[r]) and int(ps[-1, 1]) == int(rowptr[r + 1])
+        assert torch.equal(ps[1:, 0], ps[:-1, 1])
