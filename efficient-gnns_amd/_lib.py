@@ -23,6 +23,10 @@ SIGNATURES = {
     "egnn_spmm_csr_seg_f32": (_i32, [_i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p]),
     "egnn_spmm_csr_max_bwd_f32": (_i32, [_i64, _i64, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p]),
     "egnn_spmm_algorithmic_bytes": (_i64, [_i64, _i64, _i64, _i64, _i32, _i32]),
+    "egnn_csr_from_coo_ws_bytes": (_sz, [_i64, _i64, _i32]),
+    "egnn_csr_from_coo_i64": (_i32, [_p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _sz, _p]),
+    "egnn_csr_transpose_ws_bytes": (_sz, [_i64, _i64]),
+    "egnn_csr_transpose_i64": (_i32, [_p, _p, _i64, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     "egnn_rowptr_from_sorted_rows_i64": (_i32, [_p, _i64, _i64, _p, _p]),
     "egnn_narrow_i64_to_i32": (_i32, [_p, _i64, _p, _p, _p]),
     "egnn_gcn_norm_count_i64": (_i32, [_p, _p, _i64, _p, _p]),

@@ -156,14 +156,29 @@ class SparseTensor:
             raise NotImplementedError("to_symmetric with values is not used by the reference")
         n = max(self._sizes)
         row, col = self._row(), self._col
+        if col.is_cuda and 2 * col.numel() < 2 ** 31 - 1:
+            rowptr, col_s = csr_from_coo(row, col, n, symmetric=True)
+            return SparseTensor(rowptr=rowptr, col=col_s, sparse_sizes=(n, n))
         key = torch.unique(torch.cat([row * n + col, col * n + row]))
         return SparseTensor(row=torch.div(key, n, rounding_mode="floor"), col=key % n, sparse_sizes=(n, n), is_sorted=True)
 
     def _transpose_meta(self):
         """(colptr, csr2csc): stable sort of the entries by column (rows stay ascending per column)."""
         if "tmeta" not in self._struct:
-            perm = torch.argsort(self._col, stable=True)
-            colptr = _ind2ptr(self._col[perm], self._sizes[1])
+            if self._col.is_cuda and self.nnz() < 2 ** 31 - 1:   # egnn_csr_transpose_i64: also yields the transposed col array
+                lib, dev, nnz = _lib.load(), self.device, self.nnz()
+                colptr = torch.empty(self._sizes[1] + 1, dtype=torch.int64, device=dev)
+                t_col = torch.empty(nnz, dtype=torch.int64, device=dev)
+                perm = torch.empty(nnz, dtype=torch.int64, device=dev)
+                nws = lib.egnn_csr_transpose_ws_bytes(nnz, self._sizes[1])
+                ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+                _lib.check(lib.egnn_csr_transpose_i64(_lib.ptr(self._rowptr), _lib.ptr(self._col), self._sizes[0], self._sizes[1], nnz,
+                                                      _lib.ptr(colptr), _lib.ptr(t_col), _lib.ptr(perm), _lib.ptr(ws), nws, _lib.stream()),
+                           "egnn_csr_transpose_i64")
+                self._struct["t_col"] = t_col
+            else:
+                perm = torch.argsort(self._col, stable=True)
+                colptr = _ind2ptr(self._col[perm], self._sizes[1])
             self._struct["tmeta"] = (colptr, perm)
         return self._struct["tmeta"]
 
@@ -277,6 +292,24 @@ class SparseTensor:
         _, _, bits = self._index_arrays()
         return int(_lib.load().egnn_spmm_algorithmic_bytes(self._sizes[0], self._sizes[1], K, self.nnz(), bits,
                                                            int(self._value is not None)))
+
+
+def csr_from_coo(row: Tensor, col: Tensor, n: int, symmetric: bool):
+    """(rowptr, col) of the CSR sorted by (row, col) on the GPU (egnn_csr_from_coo_i64): ``symmetric`` adds the transposed
+    entries and merges duplicates (to_symmetric); otherwise duplicates are kept (ToSparseTensor)."""
+    _lib.require_gpu(row, col)
+    lib, dev, E = _lib.load(), col.device, col.numel()
+    row, col = row.contiguous(), col.contiguous()
+    rowptr = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    col_out = torch.empty((2 * E if symmetric else E), dtype=torch.int64, device=dev)
+    nnz = torch.empty(1, dtype=torch.int64, device=dev)
+    nws = lib.egnn_csr_from_coo_ws_bytes(E, n, int(symmetric))
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    _lib.check(lib.egnn_csr_from_coo_i64(_lib.ptr(row), _lib.ptr(col), E, n, int(symmetric), _lib.ptr(rowptr), _lib.ptr(col_out),
+                                         _lib.ptr(nnz), _lib.ptr(ws), nws, _lib.stream()), "egnn_csr_from_coo_i64")
+    if symmetric:
+        col_out = col_out[:int(nnz)].clone()   # one host read per constructed graph
+    return rowptr, col_out
 
 
 def gcn_norm(adj_t: SparseTensor) -> SparseTensor:

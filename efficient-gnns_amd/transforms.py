@@ -9,6 +9,10 @@ from .sparse import SparseTensor
 def to_sparse_tensor(edge_index: torch.Tensor, num_nodes: int) -> SparseTensor:
     """(source, target) edge list -> ``adj_t``: row i lists the sources j of edges j->i, ascending; no dedupe."""
     src, dst = edge_index[0], edge_index[1]
+    if edge_index.is_cuda and edge_index.shape[1] < 2 ** 31 - 1:
+        from .sparse import csr_from_coo
+        rowptr, col = csr_from_coo(dst, src, num_nodes, symmetric=False)   # egnn_csr_from_coo_i64: sort on the device
+        return SparseTensor(rowptr=rowptr, col=col, value=None, sparse_sizes=(num_nodes, num_nodes))
     perm = torch.argsort(dst * num_nodes + src, stable=True)
     return SparseTensor(row=dst[perm], col=src[perm], value=None, sparse_sizes=(num_nodes, num_nodes), is_sorted=True)
 

@@ -111,6 +111,24 @@ int64_t egnn_spmm_algorithmic_bytes(int64_t n_rows, int64_t n_src, int64_t K, in
 /* ------------------------------------------------------------------------------------------------
  * Graph structure (integer work is bit-exact vs torch-sparse semantics)
  * ---------------------------------------------------------------------------------------------- */
+/* Edge list -> CSR sorted by (row, col), on the device (hipCUB radix sort over the bits the keys use; bit-exact).
+ *   symmetric == 0: T.ToSparseTensor() (/root/reference/arxiv_pyg/gnn.py:237): duplicates are KEPT;
+ *                   pass row = edge targets, col = edge sources; col_out holds E entries.
+ *   symmetric != 0: SparseTensor.to_symmetric() (gnn.py:240): union of (r,c) and (c,r), duplicates merged;
+ *                   col_out needs room for 2*E entries.
+ * rowptr [N+1], nnz_out [1] (device scalar: the entry count, = E when symmetric == 0).  ws: egnn_csr_from_coo_ws_bytes.
+ * Requires N < 3 037 000 499 (row * N + col in int64) and fewer than 2^31 keys. */
+size_t egnn_csr_from_coo_ws_bytes(int64_t E, int64_t N, int symmetric);
+int egnn_csr_from_coo_i64(const int64_t* row, const int64_t* col, int64_t E, int64_t N, int symmetric,
+                          int64_t* rowptr, int64_t* col_out, int64_t* nnz_out, void* ws, size_t ws_bytes, void* stream);
+
+/* CSR -> CSC: colptr [n_cols+1], row_out [nnz] (the rows of each column, ascending) and perm [nnz] = the csr2csc
+ * permutation torch-sparse caches for the backward SpMM (stable sort of the entries by column; SURVEY 9.6,
+ * /root/reference/arxiv_pyg/gnn.py:192): value_csc = value[perm].  ws: egnn_csr_transpose_ws_bytes(nnz, n_cols). */
+size_t egnn_csr_transpose_ws_bytes(int64_t nnz, int64_t n_cols);
+int egnn_csr_transpose_i64(const int64_t* rowptr, const int64_t* col, int64_t n_rows, int64_t n_cols, int64_t nnz,
+                           int64_t* colptr, int64_t* row_out, int64_t* perm, void* ws, size_t ws_bytes, void* stream);
+
 /* rowptr[i] = #entries with row < i, for i in [0, n_rows]; `row` sorted ascending.
  * Replaces torch_sparse ind2ptr inside T.ToSparseTensor()  /root/reference/arxiv_pyg/gnn.py:237. */
 int egnn_rowptr_from_sorted_rows_i64(const int64_t* row, int64_t nnz, int64_t n_rows, int64_t* rowptr, void* stream);

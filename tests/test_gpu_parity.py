@@ -760,3 +760,34 @@ def test_linear_rows_fused_gather_gemm_vs_torch(n, C, P, m, padded):
     close(wg.grad, wd.grad, rtol=1e-5, atol_scale=1e-6)
     close(bg.grad, bd.grad, rtol=1e-5, atol_scale=1e-6)
     close(xg.grad, xd.grad, rtol=1e-5, atol_scale=1e-6)
+
+
+@pytest.mark.gpu
+def test_native_graph_construction_edge_cases_bit_exact():
+    """egnn_csr_from_coo_i64 / egnn_csr_transpose_i64 against the oracle: duplicates kept (ToSparseTensor) or merged
+    (to_symmetric), self loops, isolated nodes, a single edge, an empty edge list, a rectangular transpose with values."""
+    n = 37
+    g = torch.Generator().manual_seed(5)
+    src = torch.randint(0, n - 5, (400,), generator=g)          # nodes n-5 .. n-1 stay isolated
+    dst = torch.randint(0, n - 5, (400,), generator=g)
+    src[:20], dst[:20] = dst[20:40].clone(), src[20:40].clone()  # reverse duplicates
+    src[40:60] = dst[40:60]                                      # self loops
+    src[60:80], dst[60:80] = src[80:100].clone(), dst[80:100].clone()   # exact duplicates
+    for ei in (torch.stack([src, dst]), torch.tensor([[3], [7]]), torch.zeros(2, 0, dtype=torch.int64)):
+        o = OS.to_sparse_tensor(ei, n)
+        p = E.to_sparse_tensor(ei.to(DEV), n)
+        assert p.nnz() == ei.shape[1]
+        for a, b in zip(p.csr()[:2], o.csr()[:2]):
+            assert torch.equal(a.cpu(), b)
+        so, sp = o.to_symmetric(), p.to_symmetric()
+        for a, b in zip(sp.csr()[:2], so.csr()[:2]):
+            assert torch.equal(a.cpu(), b)
+        assert torch.equal(sp.storage.colptr().cpu(), so._colptr()) and torch.equal(sp.storage.csr2csc().cpu(), so._csr2csc())
+    # rectangular, valued: the transposed tensor carries value[csr2csc]
+    rows = torch.sort(torch.randint(0, 11, (90,), generator=g)).values
+    cols = torch.randint(0, 23, (90,), generator=g)
+    val = torch.randn(90, generator=g)
+    o, p = make_pair(rows, cols, val, (11, 23))
+    ot, pt = o.t(), p.t()
+    for a, b in zip(pt.csr(), ot.csr()):
+        assert torch.equal(a.cpu(), b)
