@@ -55,6 +55,7 @@ SIGNATURES = {
     "egnn_bce_pair_bwd_f32": (_i32, [_p, _p, _p, _i64, _p, _p, _p, _p]),
     "egnn_edge_sim_f32": (_i32, [_p, _i64, _i64, _p, _p, _i64, _i32, _p, _p, _p]),
     "egnn_edge_sim_coef_f32": (_i32, [_p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
+    "egnn_gat_attention_fwd_f32": (_i32, [_p, _p, _p, _p, _i64, _i64, _i32, _f32, _p, _p]),
     "egnn_segment_softmax_fwd_f32": (_i32, [_p, _p, _i64, _p, _p]),
     "egnn_segment_softmax_bwd_f32": (_i32, [_p, _p, _p, _i64, _p, _p]),
     "egnn_segment_sum_f32": (_i32, [_p, _p, _i64, _p, _p]),

@@ -137,7 +137,54 @@ inline unsigned wave_grid(int64_t n) {
   return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
 }
 
+// GAT attention coefficients of one target row per wavefront (PyG <=1.7 GATConv.message + utils.softmax):
+//   s_e,h = leaky_relu(alpha_src[col[e],h] + alpha_dst[i,h]);  att[h,e] = exp(s - max_e s) / (sum_e exp(s - max) + 1e-16)
+// The [E,H] score tensor, its gathers (u_add_v SDDMM) and the scatter-softmax never exist in memory; fixed order.
+__global__ __launch_bounds__(256) void gat_attention_fwd_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
+                                                                const float* __restrict__ asrc, const float* __restrict__ adst,
+                                                                int64_t n_rows, int64_t nnz, int H, float slope,
+                                                                float* __restrict__ att) {
+  const int lane = egnn_lane();
+  const int64_t row = (int64_t)blockIdx.x * 4 + egnn_wave_id();
+  if (row >= n_rows) return;
+  const int64_t start = rowptr[row], end = rowptr[row + 1];
+  for (int h = 0; h < H; ++h) {
+    const float ad = adst[row * H + h];
+    float m = -INFINITY;
+    for (int64_t e = start + lane; e < end; e += 64) {
+      float s = asrc[col[e] * H + h] + ad;
+      s = s > 0.f ? s : s * slope;
+      m = fmaxf(m, s);
+    }
+    m = egnn_wave_max(m);
+    float z = 0.f;
+    for (int64_t e = start + lane; e < end; e += 64) {
+      float s = asrc[col[e] * H + h] + ad;
+      s = s > 0.f ? s : s * slope;
+      z += expf(s - m);
+    }
+    z = egnn_wave_sum(z) + 1e-16f;
+    for (int64_t e = start + lane; e < end; e += 64) {
+      float s = asrc[col[e] * H + h] + ad;
+      s = s > 0.f ? s : s * slope;
+      att[(int64_t)h * nnz + e] = expf(s - m) / z;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int egnn_gat_attention_fwd_f32(const int64_t* rowptr, const int64_t* col, const float* alpha_src, const float* alpha_dst,
+                                          int64_t n_rows, int64_t nnz, int H, float negative_slope, float* att, void* stream) {
+  EGNN_CHECK_ARG(n_rows >= 0 && nnz >= 0 && H > 0 && H <= 64);
+  if (n_rows == 0 || nnz == 0) return EGNN_OK;
+  EGNN_CHECK_ARG(rowptr && col && alpha_src && alpha_dst && att);
+  const int64_t blocks = (n_rows + 3) / 4;
+  if (blocks > 0x7fffffffLL) return EGNN_EINVAL;
+  hipLaunchKernelGGL(gat_attention_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rowptr, col, alpha_src,
+                     alpha_dst, n_rows, nnz, H, negative_slope, att);
+  return egnn_launch_status();
+}
 
 extern "C" int egnn_edge_sim_f32(const float* F, int64_t ld, int64_t D, const int64_t* idx_a, const int64_t* idx_b, int64_t E,
                                  int kernel, float* sim, float* aux3, void* stream) {

@@ -1,1 +1,1 @@
-from efficient_gnns_amd.nn import GCNConv, SAGEConv  # noqa: F401
+from efficient_gnns_amd.nn import GATConv, GCNConv, SAGEConv  # noqa: F401

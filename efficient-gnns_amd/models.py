@@ -15,7 +15,7 @@ from torch import nn
 
 from . import criterion as C
 from . import ops
-from .nn import GCNConv, SAGEConv
+from .nn import GATConv, GCNConv, SAGEConv
 
 
 class _Student(nn.Module):
@@ -188,3 +188,58 @@ def evaluate(model, x, adj_t, y, split_idx):
     else:
         accs = tuple(accuracy(y[split_idx[k]], y_pred[split_idx[k]]) for k in ("train", "valid", "test"))
     return out, accs
+
+
+class GAT(nn.Module):
+    """The PPI GAT teacher (/root/reference/ppi_pyg/gnn.py:86-117), run frozen inside the student step (:208-209):
+    GATConv + linear skip per layer, ELU, dropout; the last layer averages its heads.  Inference only (nn.GATConv)."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout, heads=4):
+        super().__init__()
+        self.convs = nn.ModuleList([GATConv(in_channels, hidden_channels, heads=heads)])
+        self.lins = nn.ModuleList([nn.Linear(in_channels, hidden_channels * heads)])
+        for _ in range(num_layers - 2):
+            self.convs.append(GATConv(heads * hidden_channels, hidden_channels, heads=heads))
+            self.lins.append(nn.Linear(hidden_channels * heads, hidden_channels * heads))
+        self.convs.append(GATConv(heads * hidden_channels, out_channels, heads=heads, concat=False))
+        self.lins.append(nn.Linear(hidden_channels * heads, out_channels))
+        self.dropout = dropout
+        self.out_feat = None
+
+    def reset_parameters(self):
+        for m in list(self.convs) + list(self.lins):
+            m.reset_parameters()
+
+    def forward(self, x, adj_t):
+        for conv, lin in zip(self.convs[:-1], self.lins[:-1]):
+            x = conv(x, adj_t) + ops.linear(x, lin.weight, lin.bias)
+            x = F.elu(x)
+            x = F.dropout(x, p=self.dropout, training=self.training)
+            self.out_feat = x
+        return self.convs[-1](x, adj_t) + ops.linear(x, self.lins[-1].weight, self.lins[-1].bias)
+
+
+class TeacherNet(nn.Module):
+    """The PPI teacher checkpointed by the reference (/root/reference/ppi_pyg/gnn.py:23-47): 4 x 256 GAT layers with
+    linear skips, ELU, a 6-head averaging output layer; ``out_feat`` = second hidden.  Same attribute names (state_dict
+    keys ``conv1.*``, ``lin1.*``, ...) so that the reference's ``checkpoint.pt`` loads."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv1 = GATConv(in_channels, 256, heads=4)
+        self.lin1 = nn.Linear(in_channels, 4 * 256)
+        self.conv2 = GATConv(4 * 256, 256, heads=4)
+        self.lin2 = nn.Linear(4 * 256, 4 * 256)
+        self.conv3 = GATConv(4 * 256, out_channels, heads=6, concat=False)
+        self.lin3 = nn.Linear(4 * 256, out_channels)
+        self.out_feat = None
+
+    def reset_parameters(self):
+        for m in (self.conv1, self.conv2, self.conv3, self.lin1, self.lin2, self.lin3):
+            m.reset_parameters()
+
+    def forward(self, x, edge_index):
+        x = F.elu(self.conv1(x, edge_index) + ops.linear(x, self.lin1.weight, self.lin1.bias))
+        x = F.elu(self.conv2(x, edge_index) + ops.linear(x, self.lin2.weight, self.lin2.bias))
+        self.out_feat = x
+        return self.conv3(x, edge_index) + ops.linear(x, self.lin3.weight, self.lin3.bias)

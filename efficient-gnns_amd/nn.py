@@ -14,7 +14,8 @@ from torch import Tensor, nn
 from . import ops
 import os
 
-from .sparse import SparseTensor, _ind2ptr, gcn_norm
+from . import _lib
+from .sparse import SparseTensor, _ind2ptr, csr_from_coo, gcn_norm
 
 # opt-in: the headline bench keeps the reference's per-step work (aggregate every layer every step)
 _MEMOISE_AX = os.environ.get("EGNN_GCN_MEMOISE_AX", "0") == "1"
@@ -131,3 +132,80 @@ class SAGEConv(nn.Module):
 
     def __repr__(self):
         return f"SAGEConv({self.in_channels}, {self.out_channels}, aggr={self.aggr})"
+
+
+class GATConv(nn.Module):
+    """PyG <=1.7 ``GATConv`` for INFERENCE: the frozen GAT teacher that the PPI / MAG train loops run inside every student
+    step (/root/reference/ppi_pyg/gnn.py:86-117,208-209).  Same parameters and ``state_dict`` keys as PyG 1.6/1.7
+    (``lin_l.weight`` shared with ``lin_r``, ``att_l`` / ``att_r`` [1,H,C], ``bias``).
+
+    Forward on the gfx950 kernels: x W on the fp32 MFMA, the 2H attention logits per node as one more small GEMM
+    (block-diagonal ``att``), scores + LeakyReLU + per-target softmax fused in ``egnn_gat_attention_fwd_f32`` (no [E,H]
+    gathers or scatter-softmax temporaries), one valued SpMM per head written straight into its column block.
+    Training the teacher is out of scope: a call that would need gradients raises."""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True, negative_slope: float = 0.2,
+                 dropout: float = 0.0, add_self_loops: bool = True, bias: bool = True, **_):
+        super().__init__()
+        self.in_channels, self.out_channels, self.heads, self.concat = in_channels, out_channels, heads, concat
+        self.negative_slope, self.dropout, self.add_self_loops = negative_slope, dropout, add_self_loops
+        self.lin_l = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.lin_r = self.lin_l
+        self.att_l = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_r = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.empty(heads * out_channels if concat else out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            for t in (self.lin_l.weight, self.att_l, self.att_r):
+                a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))  # glorot
+                t.uniform_(-a, a)
+            if self.bias is not None:
+                self.bias.zero_()
+
+    def _structure(self, adj, n: int) -> SparseTensor:
+        """CSR by target with the self loops replaced (remove_self_loops + add_self_loops), built on the device."""
+        if isinstance(adj, SparseTensor):
+            src, dst = adj._col, adj._row()
+        else:
+            src, dst = adj[0], adj[1]
+        if self.add_self_loops:
+            keep = src != dst
+            loops = torch.arange(n, dtype=src.dtype, device=src.device)
+            src, dst = torch.cat([src[keep], loops]), torch.cat([dst[keep], loops])
+        rowptr, col = csr_from_coo(dst.contiguous(), src.contiguous(), n, symmetric=False)
+        return SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(n, n))
+
+    def forward(self, x: Tensor, edge_index) -> Tensor:
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("GATConv runs the frozen teacher (torch.no_grad() / requires_grad_(False)); "
+                                      "teacher training is out of scope")
+        _lib.require_gpu(x)
+        n, H, C = x.shape[0], self.heads, self.out_channels
+        xl = ops.linear(x, self.lin_l.weight)                                   # [n, H*C]
+        # alpha_l[i,h] = <xl[i,h,:], att_l[h,:]> (and alpha_r) as ONE GEMM with a block-diagonal [H*C, 2H] matrix
+        blk = torch.zeros(H * C, 2 * H, dtype=torch.float32, device=x.device)
+        rows = torch.arange(H * C, device=x.device)
+        blk[rows, rows // C] = self.att_l.detach().reshape(-1)
+        blk[rows, H + rows // C] = self.att_r.detach().reshape(-1)
+        alpha = ops.matmul(xl, blk)                                             # [n, 2H]
+        a_src, a_dst = alpha[:, :H].contiguous(), alpha[:, H:].contiguous()
+        adj = self._structure(edge_index, n)
+        rowptr, col, _ = adj.csr()
+        nnz = adj.nnz()
+        att = torch.empty(H, nnz, dtype=torch.float32, device=x.device)         # head-major: att[h] is a value array
+        _lib.check(_lib.load().egnn_gat_attention_fwd_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(a_src), _lib.ptr(a_dst), n, nnz, H,
+                                                          float(self.negative_slope), _lib.ptr(att), _lib.stream()),
+                   "egnn_gat_attention_fwd_f32")
+        if self.training and self.dropout > 0:
+            att = torch.nn.functional.dropout(att, p=self.dropout, training=True)
+        out = torch.empty(n, H * C, dtype=torch.float32, device=x.device)
+        for h in range(H):
+            ops.spmm_raw(adj.set_value(att[h]), xl[:, h * C:(h + 1) * C], "sum", out=out[:, h * C:(h + 1) * C])
+        if not self.concat:
+            out = out.view(n, H, C).mean(dim=1)
+        return out + self.bias if self.bias is not None else out
+
+    def __repr__(self):
+        return f"GATConv({self.in_channels}, {self.out_channels}, heads={self.heads})"

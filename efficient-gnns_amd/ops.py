@@ -40,8 +40,9 @@ _SPMM_SCHEDULE = os.environ.get("EGNN_SPMM_SCHEDULE", "segments")
 
 
 def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = None, use_plan: bool = True,
-             bias: Tensor | None = None):
-    """Y = REDUCE(adj, X) on the GPU (egnn_spmm_csr_f32).  Returns (Y, argmax | None)."""
+             bias: Tensor | None = None, out: Tensor | None = None):
+    """Y = REDUCE(adj, X) on the GPU (egnn_spmm_csr_seg_f32 / egnn_spmm_csr_f32).  Returns (Y, argmax | None).
+    ``out``: optional [n_rows, K] destination with unit column stride (e.g. a column block of a wider matrix)."""
     _lib.require_gpu(x, adj._col)
     x = _rowmajor(x)
     n_rows, n_src = adj.sparse_sizes()
@@ -49,12 +50,18 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
         raise ValueError(f"matmul: adjacency has {n_src} columns, x has {x.shape[0]} rows")
     K = x.shape[1]
     red = _REDUCE[reduce]
-    y = torch.empty(n_rows, K, dtype=torch.float32, device=x.device)
+    if out is not None:
+        if tuple(out.shape) != (n_rows, K) or out.stride(1) != 1 or out.dtype != torch.float32 or out.device != x.device:
+            raise ValueError("spmm_raw: `out` must be a float32 [n_rows, K] view with unit column stride on x's device")
+        y = out
+    else:
+        y = torch.empty(n_rows, K, dtype=torch.float32, device=x.device)
     arg = torch.empty(n_rows, K, dtype=torch.int64, device=x.device) if red == 2 else None
     rowptr, col, bits = adj._index_arrays()
     lib = _lib.load()
     if (use_plan and _SPMM_SCHEDULE == "segments" and red != 2 and K % 4 == 0 and x.stride(0) % 4 == 0
-            and x.data_ptr() % 16 == 0 and (bias is None or bias.data_ptr() % 16 == 0)):
+            and x.data_ptr() % 16 == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0
+            and (bias is None or bias.data_ptr() % 16 == 0)):
         # every row as ranges of <= 64 entries through the sub-group-per-row kernel (hub rows get the bulk's parallelism)
         seg, crow, cptr, slots = adj._seg_plan()
         partial = torch.empty(max(slots, 1), K, dtype=torch.float32, device=x.device)

@@ -292,6 +292,16 @@ int egnn_segment_softmax_fwd_f32(const int64_t* seg_ptr, const float* x, int64_t
 int egnn_segment_softmax_bwd_f32(const int64_t* seg_ptr, const float* p, const float* gp, int64_t n_seg, float* gx, void* stream);
 int egnn_segment_sum_f32(const int64_t* seg_ptr, const float* x, int64_t n_seg, float* out, void* stream);
 
+/* GAT attention coefficients (the teacher that the PPI / MAG train loops run inside the student step,
+ * /root/reference/ppi_pyg/gnn.py:86-117,208-209; PyG <=1.7 GATConv.message + utils.softmax):
+ *   s[e,h]   = leaky_relu(alpha_src[col[e],h] + alpha_dst[row(e),h], negative_slope)          (u_add_v SDDMM)
+ *   att[h,e] = exp(s - max over the row's entries) / (sum exp(..) + 1e-16)                     (edge softmax per target)
+ * rowptr / col: CSR by target, int64; alpha_src [n_src,H], alpha_dst [n_rows,H] row-major; att is HEAD-major [H,nnz]
+ * so that head h's values are a contiguous per-entry array for egnn_spmm_csr_*_f32 (u_mul_e_sum).  Forward only
+ * (the teacher is frozen inside the student step; teacher training is out of scope). */
+int egnn_gat_attention_fwd_f32(const int64_t* rowptr, const int64_t* col, const float* alpha_src, const float* alpha_dst,
+                               int64_t n_rows, int64_t nnz, int H, float negative_slope, float* att, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused BatchNorm1d (+ ReLU + dropout) over node rows -- SURVEY.md 8(f) rank 1; replaces the ATen BatchNorm /
  * threshold / fused_dropout chain at /root/reference/arxiv_pyg/gnn.py:48-50,80-82,296-306.

@@ -4,6 +4,11 @@ Call sites restated: /root/reference/arxiv_pyg/gnn.py:13,28-35,61-67,92 (SparseT
 ``cached=True``) and /root/reference/ppi_pyg/gnn.py:125-132,158-164 (``edge_index`` LongTensor input,
 ``cached=False``).  Parameter layout is the PyG <=1.7 one: ``GCNConv.weight [in,out]``, ``bias [out]``;
 ``SAGEConv.lin_l`` (bias) / ``lin_r`` (no bias).
+``GATConv`` (the PPI teacher, /root/reference/ppi_pyg/gnn.py:86-117): PyG 1.6/1.7 semantics restated from memory of
+that release (parity unpinned, like the other third-party operators): ``lin_l`` shared with ``lin_r`` (no bias),
+``att_l`` / ``att_r`` [1,H,C] glorot, self loops replaced (remove_self_loops + add_self_loops), LeakyReLU(0.2) scores,
+``utils.softmax`` over the edges of a target (+1e-16), dropout on the coefficients, sum aggregation, head concat or
+mean, bias zeros.
 """
 from __future__ import annotations
 
@@ -72,3 +77,60 @@ class SAGEConv(nn.Module):
             adj = _edge_index_to_adj_t(adj, x.shape[0])
         agg = matmul(adj.set_value(None), x, self.aggr)
         return self.lin_l(agg) + self.lin_r(x)
+
+
+class GATConv(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True, negative_slope: float = 0.2,
+                 dropout: float = 0.0, add_self_loops: bool = True, bias: bool = True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.heads, self.concat = in_channels, out_channels, heads, concat
+        self.negative_slope, self.dropout, self.add_self_loops = negative_slope, dropout, add_self_loops
+        self.lin_l = nn.Linear(in_channels, heads * out_channels, bias=False)
+        self.lin_r = self.lin_l
+        self.att_l = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_r = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.empty(heads * out_channels if concat else out_channels)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        def glorot(t):
+            a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+            with torch.no_grad():
+                t.uniform_(-a, a)
+        glorot(self.lin_l.weight)
+        glorot(self.att_l)
+        glorot(self.att_r)
+        if self.bias is not None:
+            with torch.no_grad():
+                self.bias.zero_()
+
+    @staticmethod
+    def _edges(adj, n: int, add_self_loops: bool):
+        """(src, dst) in the order PyG would see them: loops removed, then (i,i) appended for every node."""
+        if isinstance(adj, SparseTensor):
+            rowptr, col, _ = adj.csr()
+            dst = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+            src = col
+        else:
+            src, dst = adj[0], adj[1]
+        if add_self_loops:
+            keep = src != dst
+            loops = torch.arange(n, dtype=src.dtype)
+            src, dst = torch.cat([src[keep], loops]), torch.cat([dst[keep], loops])
+        return src, dst
+
+    def forward(self, x: Tensor, adj) -> Tensor:
+        from .utils import softmax
+        n, H, C = x.shape[0], self.heads, self.out_channels
+        xl = self.lin_l(x).view(n, H, C)
+        alpha_l = (xl * self.att_l).sum(-1)
+        alpha_r = (xl * self.att_r).sum(-1)
+        src, dst = self._edges(adj, n, self.add_self_loops)
+        e = torch.nn.functional.leaky_relu(alpha_l[src] + alpha_r[dst], self.negative_slope)   # [E,H]
+        a = torch.stack([softmax(e[:, h], dst, num_nodes=n) for h in range(H)], dim=1)
+        a = torch.nn.functional.dropout(a, p=self.dropout, training=self.training)
+        out = torch.zeros(n, H, C, dtype=x.dtype).index_add_(0, dst, xl[src] * a.unsqueeze(-1))
+        out = out.reshape(n, H * C) if self.concat else out.mean(dim=1)
+        if self.bias is not None:
+            out = out + self.bias
+        return out

@@ -10,6 +10,7 @@ What is executed for real (imported from /root/reference, unmodified):
   * ppi_pyg/criterion.py     -> multi-label kd_criterion
   * arxiv_pyg/gnn.py         -> GCN, SAGE, ProjectionGCD, train(), test()
   * arxiv_pyg/gnn_kd_and_aux.py -> train() (KD + aux combination rule)
+  * ppi_pyg/gnn.py           -> GAT and TeacherNet (the frozen teacher the PPI student step runs, :208-209)
 
 What is shimmed (third-party packages that are neither vendored by the reference nor installable
 here -- SURVEY.md 8c): ``torch_geometric`` (GCNConv, SAGEConv, utils.softmax, utils.subgraph,
@@ -57,7 +58,9 @@ def install_shims():
 
     utils = mod("torch_geometric.utils", softmax=outils.softmax, subgraph=outils.subgraph,
                 to_dense_adj=None, negative_sampling=None, add_self_loops=None)
-    nn_ = mod("torch_geometric.nn", GCNConv=onn.GCNConv, SAGEConv=onn.SAGEConv)
+    nn_ = mod("torch_geometric.nn", GCNConv=onn.GCNConv, SAGEConv=onn.SAGEConv, GATConv=onn.GATConv)
+    mod("torch_geometric.datasets", PPI=None)
+    mod("torch_geometric.data", DataLoader=None)
     tr = mod("torch_geometric.transforms", ToSparseTensor=osp.ToSparseTensor)
     mod("torch_geometric", utils=utils, nn=nn_, transforms=tr)
     mod("torch_sparse", SparseTensor=osp.SparseTensor)
@@ -272,9 +275,44 @@ def make_train_goldens():
     print("train_arxiv.npz:", len(runs), "runs")
 
 
+def make_ppi_teacher_goldens():
+    """The reference's own GAT / TeacherNet bodies (skip connections, ELU, head averaging, out_feat) in eval mode on a
+    small multi-graph-free input; GATConv itself is the oracle restatement (shim)."""
+    ref = load_ref("ppi_pyg/gnn.py", "ref_ppi_gnn")
+    g = torch.Generator().manual_seed(11)
+    n, F_in, C = 53, 9, 7
+    src = torch.randint(0, n - 3, (300,), generator=g)      # the last three nodes only have their self loops
+    dst = torch.cat([torch.randint(0, n - 3, (260,), generator=g), torch.full((40,), 2)])
+    src[:15] = dst[:15]                                      # self loops in the input (GATConv replaces them)
+    edge_index = torch.stack([src, dst])
+    x = torch.randn(n, F_in, generator=g)
+    out = {"in_x": t2n(x), "in_edge_index": t2n(edge_index)}
+    torch.manual_seed(3)
+    m = ref.GAT(F_in, 6, C, 3, 0.5, heads=2)
+    m.eval()
+    with torch.no_grad():
+        y = m(x, edge_index)
+    for k, v in m.state_dict().items():
+        out["gat_param__" + k] = t2n(v)
+    out["gat_logits"], out["gat_out_feat"] = t2n(y), t2n(m.out_feat)
+    # TeacherNet is hard-wired to 4 x 256 hidden units (2.3 M parameters): its weights are rebuilt from the seed by the
+    # tests (same module construction order), with a few checksums to detect a different RNG stream
+    torch.manual_seed(4)
+    t = ref.TeacherNet(F_in, C)
+    t.eval()
+    with torch.no_grad():
+        yt = t(x, edge_index)
+    out["teachernet_logits"], out["teachernet_out_feat_sum"] = t2n(yt), t2n(t.out_feat.double().sum())
+    out["teachernet_param_sums"] = np.array([float(v.double().sum()) for v in t.state_dict().values()])
+    out["teachernet_keys"] = np.array(list(t.state_dict().keys()))
+    np.savez_compressed(os.path.join(HERE, "ppi_teacher.npz"), **out)
+    print("ppi_teacher.npz: GAT + TeacherNet forward")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "needs /root/reference (build container only)"
     torch.set_num_threads(1)  # reproducible reduction order in the recorded numbers
     install_shims()
     make_criterion_goldens()
     make_train_goldens()
+    make_ppi_teacher_goldens()

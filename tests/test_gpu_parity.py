@@ -791,3 +791,80 @@ def test_native_graph_construction_edge_cases_bit_exact():
     ot, pt = o.t(), p.t()
     for a, b in zip(pt.csr(), ot.csr()):
         assert torch.equal(a.cpu(), b)
+
+
+# ------------------------------------------------------------------------------------------------
+# the frozen GAT teacher the PPI train loop runs inside every student step (ppi_pyg/gnn.py:208-209)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("heads,concat,C,sparse_input", [(4, True, 32, False), (6, False, 121, False), (1, True, 8, True), (3, True, 20, True)])
+def test_gatconv_inference_vs_oracle(heads, concat, C, sparse_input):
+    g = torch.Generator().manual_seed(heads * 7 + C)
+    n, F_in = 700, 50
+    src = torch.randint(0, n - 4, (9000,), generator=g)           # isolated tail nodes keep only their self loop
+    dst = torch.cat([torch.randint(0, n - 4, (8000,), generator=g), torch.full((1000,), 11)])   # one hub target
+    src[:50] = dst[:50]                                           # self loops in the input are replaced, not doubled
+    ei = torch.stack([src, dst])
+    x = torch.randn(n, F_in, generator=g)
+    torch.manual_seed(1)
+    oc = ON.GATConv(F_in, C, heads=heads, concat=concat)
+    with torch.no_grad():
+        oc.bias.uniform_(-0.1, 0.1)
+    pc = E.GATConv(F_in, C, heads=heads, concat=concat).to(DEV)
+    pc.load_state_dict(oc.state_dict())
+    oc.eval(); pc.eval()
+    adj_o = OS.to_sparse_tensor(ei, n) if sparse_input else ei
+    adj_p = E.to_sparse_tensor(ei.to(DEV), n) if sparse_input else ei.to(DEV)
+    with torch.no_grad():
+        ref, out = oc(x, adj_o), pc(x.to(DEV), adj_p)
+    close(out, ref, rtol=1e-5, atol_scale=1e-5)
+    with pytest.raises(NotImplementedError):                      # teacher training is out of scope: no silent wrong gradients
+        pc(x.to(DEV), adj_p)
+
+
+@pytest.mark.gpu
+def test_ppi_teacher_models_match_reference_golden_and_oracle(golden_ppi_teacher):
+    G = golden_ppi_teacher
+    x, ei = as_t(G["in_x"], DEV), as_t(G["in_edge_index"], DEV)
+    m = PM.GAT(x.shape[1], 6, G["gat_logits"].shape[1], 3, 0.5, heads=2).to(DEV)
+    m.load_state_dict({k[len("gat_param__"):]: as_t(G[k], DEV) for k in G.files if k.startswith("gat_param__")})
+    m.eval()
+    with torch.no_grad():
+        y = m(x, ei)
+    close(y, G["gat_logits"], rtol=1e-5, atol_scale=1e-5)
+    close(m.out_feat, G["gat_out_feat"], rtol=1e-5, atol_scale=1e-5)
+    # TeacherNet (4 x 256, 6-head output layer) on a PPI-shaped graph against the oracle with the same weights
+    train, _, _ = D.ppi_like(seed=2, n_train=1, total_train_nodes=1500)
+    gph = train[0]
+    torch.manual_seed(0)
+    ot = OM.TeacherNet(50, 121)
+    pt = PM.TeacherNet(50, 121).to(DEV)
+    pt.load_state_dict(ot.state_dict())
+    ot.eval(); pt.eval()
+    with torch.no_grad():
+        ref, out = ot(gph.x, gph.edge_index), pt(gph.x.to(DEV), gph.edge_index.to(DEV))
+    close(out, ref, rtol=1e-5, atol_scale=1e-5)
+    close(pt.out_feat, ot.out_feat, rtol=1e-5, atol_scale=1e-5)
+
+
+@pytest.mark.gpu
+def test_ppi_student_step_with_teacher_forward_inside_vs_oracle():
+    """ppi_pyg/gnn.py:205-212: every student step first runs the frozen GAT teacher on the batch graph, then the KD loss."""
+    train, _, _ = D.ppi_like(seed=3, n_train=2, total_train_nodes=1800)
+    torch.manual_seed(0)
+    ot, om = OM.TeacherNet(50, 121), OM.GCN(50, 64, 121, 2, 0.0, cached=False)
+    pt, pm = PM.TeacherNet(50, 121).to(DEV), PM.GCN(50, 64, 121, 2, 0.0, cached=False).to(DEV)
+    pt.load_state_dict(ot.state_dict()); pm.load_state_dict(om.state_dict())
+    ot.eval(); pt.eval()
+    oo, po = torch.optim.Adam(om.parameters(), lr=0.005), torch.optim.Adam(pm.parameters(), lr=0.005)
+    for gph in train:
+        om.train(); pm.train()
+        with torch.no_grad():
+            t_ref = ot(gph.x, gph.edge_index)
+            t_out = pt(gph.x.to(DEV), gph.edge_index.to(DEV))
+        ref = OC.ppi_kd_criterion(om(gph.x, gph.edge_index), gph.y, t_ref, 0.5, 1.0)
+        oo.zero_grad(); ref[0].backward(); oo.step()
+        out = E.ppi_kd_criterion(pm(gph.x.to(DEV), gph.edge_index.to(DEV)), gph.y.to(DEV), t_out, 0.5, 1.0)
+        po.zero_grad(); out[0].backward(); po.step()
+        for a, b in zip(out, ref):
+            close(a, b, rtol=2e-4, atol_scale=0)

@@ -158,3 +158,29 @@ def test_train_and_eval_match_reference(golden_train):
             if noise_driven(k, int(G["hp"][2])):
                 continue
             np.testing.assert_allclose(v.numpy(), G[f"{tag}__final__model.{k}"], rtol=1e-4, atol=1e-6, err_msg=f"{name}:{k}")
+
+
+def test_oracle_gat_and_teachernet_match_reference_bodies(golden_ppi_teacher):
+    """The PPI teacher models (ppi_pyg/gnn.py GAT :86-117, TeacherNet :23-47) executed from the reference's own file when
+    the golden was made; the oracle restatement with the same weights must reproduce logits and out_feat."""
+    import oracle.models as OM
+    G = golden_ppi_teacher
+    x, ei = torch.from_numpy(G["in_x"]), torch.from_numpy(G["in_edge_index"])
+    m = OM.GAT(x.shape[1], 6, G["gat_logits"].shape[1], 3, 0.5, heads=2)
+    m.load_state_dict({k[len("gat_param__"):]: torch.from_numpy(G[k]) for k in G.files if k.startswith("gat_param__")})
+    m.eval()
+    with torch.no_grad():
+        y = m(x, ei)
+    np.testing.assert_allclose(y.numpy(), G["gat_logits"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(m.out_feat.numpy(), G["gat_out_feat"], rtol=1e-5, atol=1e-6)
+    torch.manual_seed(4)   # TeacherNet (2.3 M parameters): weights rebuilt from the seed the golden used
+    t = OM.TeacherNet(x.shape[1], G["teachernet_logits"].shape[1])
+    assert list(t.state_dict().keys()) == list(G["teachernet_keys"])
+    sums = np.array([float(v.double().sum()) for v in t.state_dict().values()])
+    if not np.allclose(sums, G["teachernet_param_sums"], rtol=1e-9, atol=1e-9):
+        pytest.skip("this torch build draws a different init stream than the one the golden was made with")
+    t.eval()
+    with torch.no_grad():
+        yt = t(x, ei)
+    np.testing.assert_allclose(yt.numpy(), G["teachernet_logits"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(float(t.out_feat.double().sum()), float(G["teachernet_out_feat_sum"]), rtol=1e-6)

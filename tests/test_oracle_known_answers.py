@@ -119,3 +119,37 @@ def test_conv_parameter_counts_match_paper():
     assert tuple(c.weight.shape) == (3, 4) and float(c.bias.abs().sum()) == 0.0
     s = ON.SAGEConv(3, 4)
     assert s.lin_l.bias is not None and s.lin_r.bias is None
+
+
+def test_gatconv_hand_values():
+    """PyG <=1.7 GATConv on a 3-node graph, one head, identity-like weights: scores, softmax and aggregation by hand."""
+    import math
+    import oracle.nn as ON
+    conv = ON.GATConv(2, 2, heads=1, bias=True)
+    with torch.no_grad():
+        conv.lin_l.weight.copy_(torch.eye(2))
+        conv.att_l.copy_(torch.tensor([[[1.0, 0.0]]]))     # alpha_l[i] = x[i,0]
+        conv.att_r.copy_(torch.tensor([[[0.0, 1.0]]]))     # alpha_r[i] = x[i,1]
+        conv.bias.copy_(torch.tensor([0.5, -0.5]))
+    x = torch.tensor([[1.0, 2.0], [3.0, -1.0], [-2.0, 0.5]])
+    edge_index = torch.tensor([[1, 2, 0, 0], [0, 0, 1, 0]])   # 1->0, 2->0, 0->1, and a self loop 0->0 that gets replaced
+    out = conv(x, edge_index)
+    lrelu = lambda v: v if v > 0 else 0.2 * v  # noqa: E731
+    # target 0: sources {1, 2, 0(loop)}; score = lrelu(x[src,0] + x[0,1])
+    s0 = [lrelu(3.0 + 2.0), lrelu(-2.0 + 2.0), lrelu(1.0 + 2.0)]
+    e0 = [math.exp(v - max(s0)) for v in s0]
+    a0 = [v / (sum(e0) + 1e-16) for v in e0]
+    row0 = [a0[0] * 3.0 + a0[1] * -2.0 + a0[2] * 1.0 + 0.5, a0[0] * -1.0 + a0[1] * 0.5 + a0[2] * 2.0 - 0.5]
+    # target 1: sources {0, 1(loop)}
+    s1 = [lrelu(1.0 - 1.0), lrelu(3.0 - 1.0)]
+    e1 = [math.exp(v - max(s1)) for v in s1]
+    a1 = [v / (sum(e1) + 1e-16) for v in e1]
+    row1 = [a1[0] * 1.0 + a1[1] * 3.0 + 0.5, a1[0] * 2.0 + a1[1] * -1.0 - 0.5]
+    # target 2: only its self loop -> coefficient 1
+    row2 = [-2.0 + 0.5, 0.5 - 0.5]
+    torch.testing.assert_close(out, torch.tensor([row0, row1, row2]), rtol=1e-6, atol=1e-6)
+    assert sorted(conv.state_dict()) == ["att_l", "att_r", "bias", "lin_l.weight", "lin_r.weight"]
+    # two heads averaged (concat=False) = mean of the per-head results; parameter shapes of the PPI teacher's last layer
+    c2 = ON.GATConv(4, 3, heads=6, concat=False)
+    assert tuple(c2.lin_l.weight.shape) == (18, 4) and tuple(c2.att_l.shape) == (1, 6, 3) and tuple(c2.bias.shape) == (3,)
+    assert tuple(c2(torch.randn(5, 4), torch.tensor([[0, 1], [1, 2]])).shape) == (5, 3)
