@@ -5,7 +5,7 @@ Host-side mirror of the reference's operator interface over the C
 """
 from efficient_gnns_amd import _lib  # noqa: F401
 from efficient_gnns_amd.sparse import SparseTensor, gcn_norm  # noqa: F401
-from efficient_gnns_amd.nn import GATConv, GCNConv, SAGEConv  # noqa: F401
+from efficient_gnns_amd.nn import GATConv, GCNConv, RGCNConv, SAGEConv  # noqa: F401
 from efficient_gnns_amd.transforms import ToSparseTensor, to_sparse_tensor  # noqa: F401
 from efficient_gnns_amd.utils import softmax, subgraph  # noqa: F401
 from efficient_gnns_amd.criterion import (  # noqa: F401

@@ -189,3 +189,66 @@ class TeacherNet(nn.Module):
         x = F.elu(self.conv2(x, edge_index) + self.lin2(x))
         self.out_feat = x
         return self.conv3(x, edge_index) + self.lin3(x)
+
+
+class RGCN(nn.Module):
+    """/root/reference/mag_pyg/gnn.py:71-168: R-GCN over the grouped heterogeneous graph; ``forward`` on a (sampled)
+    homogeneous subgraph, ``inference`` full-batch per relation with ``adj_t.matmul(x, reduce='mean')`` (:151,162)."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout, num_nodes_dict, x_types, num_edge_types):
+        super().__init__()
+        from .nn import RGCNConv
+        self.in_channels, self.hidden_channels, self.out_channels = in_channels, hidden_channels, out_channels
+        self.num_layers, self.dropout = num_layers, dropout
+        node_types = list(num_nodes_dict.keys())
+        self.num_node_types, self.num_edge_types = len(node_types), num_edge_types
+        self.emb_dict = nn.ParameterDict({f"{key}": nn.Parameter(torch.empty(num_nodes_dict[key], in_channels))
+                                          for key in sorted(set(node_types).difference(set(x_types)))})
+        dims = [in_channels] + [hidden_channels] * (num_layers - 1) + [out_channels]
+        self.convs = nn.ModuleList(RGCNConv(a, b, self.num_node_types, num_edge_types) for a, b in zip(dims[:-1], dims[1:]))
+        self.out_feat = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for emb in self.emb_dict.values():
+            nn.init.xavier_uniform_(emb)
+        for conv in self.convs:
+            conv.reset_parameters()
+
+    def group_input(self, x_dict, node_type, local_node_idx):
+        h = torch.zeros((node_type.size(0), self.in_channels), device=node_type.device)
+        for key, x in x_dict.items():
+            mask = node_type == key
+            h[mask] = x[local_node_idx[mask]]
+        for key, emb in self.emb_dict.items():
+            mask = node_type == int(key)
+            h[mask] = emb[local_node_idx[mask]]
+        return h
+
+    def forward(self, x_dict, edge_index, edge_type, node_type, local_node_idx):
+        x = self.group_input(x_dict, node_type, local_node_idx)
+        for i, conv in enumerate(self.convs):
+            x = conv(x, edge_index, edge_type, node_type)
+            if i != self.num_layers - 1:
+                x = F.dropout(F.relu(x), p=0.5, training=self.training)
+                self.out_feat = x
+        return x
+
+    def inference(self, x_dict, edge_index_dict, key2int):
+        from .sparse import SparseTensor, matmul
+        x_dict = dict(x_dict)
+        for key, emb in self.emb_dict.items():
+            x_dict[int(key)] = emb
+        adj_t_dict = {}
+        for key, (row, col) in edge_index_dict.items():
+            n_dst, n_src = x_dict[key2int[key[-1]]].shape[0], x_dict[key2int[key[0]]].shape[0]
+            adj_t_dict[key] = SparseTensor(row=col, col=row, sparse_sizes=(n_dst, n_src))
+        for i, conv in enumerate(self.convs):
+            out_dict = {j: conv.root_lins[j](x) for j, x in x_dict.items()}
+            for keys, adj_t in adj_t_dict.items():
+                tmp = matmul(adj_t, x_dict[key2int[keys[0]]], "mean")
+                out_dict[key2int[keys[-1]]] = out_dict[key2int[keys[-1]]] + conv.rel_lins[key2int[keys]](tmp)
+            if i != self.num_layers - 1:
+                out_dict = {j: F.relu(v) for j, v in out_dict.items()}
+            x_dict = out_dict
+        return x_dict

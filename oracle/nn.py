@@ -134,3 +134,51 @@ class GATConv(nn.Module):
         if self.bias is not None:
             out = out + self.bias
         return out
+
+
+class MessagePassing(nn.Module):
+    """The slice of PyG's ``MessagePassing`` the reference's own ``RGCNConv`` subclass uses (mag_pyg/gnn.py:25-68):
+    ``propagate(edge_index, x=..., **kw)`` = gather source rows, ``self.message(x_j, **kw)``, aggregate at the targets
+    (``aggr`` in {'mean', 'add'}; targets without messages get 0).  flow = source_to_target."""
+
+    def __init__(self, aggr: str = "add"):
+        super().__init__()
+        self.aggr = aggr
+
+    def propagate(self, edge_index: Tensor, x: Tensor, **kw) -> Tensor:
+        src, dst = edge_index[0], edge_index[1]
+        msg = self.message(x[src], **kw)
+        out = torch.zeros(x.shape[0], msg.shape[1], dtype=msg.dtype).index_add_(0, dst, msg)
+        if self.aggr == "mean":
+            cnt = torch.zeros(x.shape[0], dtype=msg.dtype).index_add_(0, dst, torch.ones(dst.numel(), dtype=msg.dtype))
+            out = out / cnt.clamp(min=1).unsqueeze(1)
+        return out
+
+
+class RGCNConv(MessagePassing):
+    """/root/reference/mag_pyg/gnn.py:25-68 restated: per edge type a mean over the incoming edges of that type of
+    ``rel_lins[type](x_j)`` (no bias), plus ``root_lins[node type](x_i)`` (bias)."""
+
+    def __init__(self, in_channels, out_channels, num_node_types, num_edge_types):
+        super().__init__(aggr="mean")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_node_types, self.num_edge_types = num_node_types, num_edge_types
+        self.rel_lins = nn.ModuleList([nn.Linear(in_channels, out_channels, bias=False) for _ in range(num_edge_types)])
+        self.root_lins = nn.ModuleList([nn.Linear(in_channels, out_channels, bias=True) for _ in range(num_node_types)])
+
+    def reset_parameters(self):
+        for lin in list(self.rel_lins) + list(self.root_lins):
+            lin.reset_parameters()
+
+    def forward(self, x, edge_index, edge_type, node_type):
+        out = x.new_zeros(x.size(0), self.out_channels)
+        for i in range(self.num_edge_types):
+            mask = edge_type == i
+            out = out + self.propagate(edge_index[:, mask], x=x, edge_type=i)
+        for i in range(self.num_node_types):
+            mask = node_type == i
+            out = out.index_add(0, torch.nonzero(mask).view(-1), self.root_lins[i](x[mask]))
+        return out
+
+    def message(self, x_j, edge_type: int):
+        return self.rel_lins[edge_type](x_j)

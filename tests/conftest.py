@@ -38,9 +38,31 @@ def golden_ppi_teacher():
 
 
 @pytest.fixture(scope="session")
+def golden_mag_rgcn():
+    return np.load(os.path.join(GOLDEN, "mag_rgcn.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
 def golden_train():
     return np.load(os.path.join(GOLDEN, "train_arxiv.npz"), allow_pickle=False)
 
 
 def as_t(a, device="cpu"):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+def mag_rgcn_case(G, device="cpu"):
+    """Inputs of tests/golden/mag_rgcn.npz in the shapes RGCN.forward / .inference take."""
+    sizes = {0: 23, 1: 17, 2: 9}
+    rel_names = [k[len("in_rel__"):] for k in G.files if k.startswith("in_rel__")]
+    key2int = {"a": 0, "b": 1, "c": 2}
+    edge_index_dict = {}
+    for i, name in enumerate(rel_names):
+        key = tuple(name.split("|"))
+        r, c = as_t(G["in_rel__" + name], device)
+        edge_index_dict[key] = (r, c)
+        key2int[key] = i
+    params = {k[len("param__"):]: as_t(G[k], device) for k in G.files if k.startswith("param__")}
+    args = ({0: as_t(G["in_x0"], device)}, as_t(G["in_edge_index"], device), as_t(G["in_edge_type"], device),
+            as_t(G["in_node_type"], device), as_t(G["in_local_idx"], device))
+    return sizes, edge_index_dict, key2int, params, args

@@ -11,6 +11,7 @@ What is executed for real (imported from /root/reference, unmodified):
   * arxiv_pyg/gnn.py         -> GCN, SAGE, ProjectionGCD, train(), test()
   * arxiv_pyg/gnn_kd_and_aux.py -> train() (KD + aux combination rule)
   * ppi_pyg/gnn.py           -> GAT and TeacherNet (the frozen teacher the PPI student step runs, :208-209)
+  * mag_pyg/gnn.py           -> RGCNConv (a MessagePassing subclass of the reference's own), RGCN.forward / .inference
 
 What is shimmed (third-party packages that are neither vendored by the reference nor installable
 here -- SURVEY.md 8c): ``torch_geometric`` (GCNConv, SAGEConv, utils.softmax, utils.subgraph,
@@ -57,10 +58,13 @@ def install_shims():
         return m
 
     utils = mod("torch_geometric.utils", softmax=outils.softmax, subgraph=outils.subgraph,
-                to_dense_adj=None, negative_sampling=None, add_self_loops=None)
-    nn_ = mod("torch_geometric.nn", GCNConv=onn.GCNConv, SAGEConv=onn.SAGEConv, GATConv=onn.GATConv)
+                to_dense_adj=None, negative_sampling=None, add_self_loops=None, to_undirected=None)
+    hetero = mod("torch_geometric.utils.hetero", group_hetero_graph=None)
+    utils.hetero = hetero
+    nn_ = mod("torch_geometric.nn", GCNConv=onn.GCNConv, SAGEConv=onn.SAGEConv, GATConv=onn.GATConv,
+              MessagePassing=onn.MessagePassing)
     mod("torch_geometric.datasets", PPI=None)
-    mod("torch_geometric.data", DataLoader=None)
+    mod("torch_geometric.data", DataLoader=None, Data=None, GraphSAINTRandomWalkSampler=None)
     tr = mod("torch_geometric.transforms", ToSparseTensor=osp.ToSparseTensor)
     mod("torch_geometric", utils=utils, nn=nn_, transforms=tr)
     mod("torch_sparse", SparseTensor=osp.SparseTensor)
@@ -309,6 +313,51 @@ def make_ppi_teacher_goldens():
     print("ppi_teacher.npz: GAT + TeacherNet forward")
 
 
+def mag_toy(seed=21):
+    """Three node types (0 has features, 1 and 2 get embeddings), four relations incl. a reverse pair."""
+    g = torch.Generator().manual_seed(seed)
+    sizes = {0: 23, 1: 17, 2: 9}
+    rels = {("a", "r0", "b"): (0, 1, 60), ("b", "r1", "a"): (1, 0, 60), ("a", "r2", "c"): (0, 2, 30), ("c", "r3", "a"): (2, 0, 45)}
+    key2int = {"a": 0, "b": 1, "c": 2}
+    edge_index_dict = {}
+    for i, (k, (s, t, e)) in enumerate(rels.items()):
+        row = torch.randint(0, sizes[s], (e,), generator=g)
+        col = torch.randint(0, sizes[t], (e,), generator=g)
+        row[-1], col[-1] = sizes[s] - 1, sizes[t] - 1          # the inferred SparseTensor sizes (mag:151) equal the true ones
+        edge_index_dict[k] = (row, col)
+        key2int[k] = i
+    x0 = torch.randn(sizes[0], 8, generator=g)
+    # grouped homogeneous form (what group_hetero_graph would give): offsets per node type
+    off = {0: 0, 1: sizes[0], 2: sizes[0] + sizes[1]}
+    ei = torch.cat([torch.stack([r + off[rels[k][0]], c + off[rels[k][1]]]) for k, (r, c) in edge_index_dict.items()], dim=1)
+    et = torch.cat([torch.full((rels[k][2],), key2int[k]) for k in rels])
+    node_type = torch.cat([torch.full((sizes[t],), t) for t in (0, 1, 2)])
+    local_idx = torch.cat([torch.arange(sizes[t]) for t in (0, 1, 2)])
+    return sizes, edge_index_dict, key2int, x0, ei, et, node_type, local_idx
+
+
+def make_mag_rgcn_goldens():
+    ref = load_ref("mag_pyg/gnn.py", "ref_mag_gnn")
+    sizes, edge_index_dict, key2int, x0, ei, et, node_type, local_idx = mag_toy()
+    torch.manual_seed(9)
+    m = ref.RGCN(8, 12, 5, 2, 0.5, sizes, [0], 4)
+    m.eval()
+    out = {"in_x0": t2n(x0), "in_edge_index": t2n(ei), "in_edge_type": t2n(et), "in_node_type": t2n(node_type),
+           "in_local_idx": t2n(local_idx)}
+    for k, (r, c) in edge_index_dict.items():
+        out["in_rel__" + "|".join(k)] = t2n(torch.stack([r, c]))
+    for k, v in m.state_dict().items():
+        out["param__" + k] = t2n(v)
+    with torch.no_grad():
+        y = m({0: x0}, ei, et, node_type, local_idx)
+        inf = m.inference({0: x0}, edge_index_dict, key2int)
+    out["forward_logits"], out["forward_out_feat"] = t2n(y), t2n(m.out_feat)
+    for j, v in inf.items():
+        out[f"inference__{j}"] = t2n(v)
+    np.savez_compressed(os.path.join(HERE, "mag_rgcn.npz"), **out)
+    print("mag_rgcn.npz: RGCN forward + inference")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "needs /root/reference (build container only)"
     torch.set_num_threads(1)  # reproducible reduction order in the recorded numbers
@@ -316,3 +365,4 @@ if __name__ == "__main__":
     make_criterion_goldens()
     make_train_goldens()
     make_ppi_teacher_goldens()
+    make_mag_rgcn_goldens()

@@ -19,7 +19,7 @@ import oracle.models as OM
 import oracle.nn as ON
 import oracle.sparse as OS
 import oracle.utils as OU
-from conftest import as_t
+from conftest import as_t, mag_rgcn_case
 from test_oracle_golden import criterion_cases, run_training, noise_driven
 
 pytestmark = pytest.mark.gpu
@@ -868,3 +868,52 @@ def test_ppi_student_step_with_teacher_forward_inside_vs_oracle():
         po.zero_grad(); out[0].backward(); po.step()
         for a, b in zip(out, ref):
             close(a, b, rtol=2e-4, atol_scale=0)
+
+
+# ------------------------------------------------------------------------------------------------
+# R-GCN per-relation mean aggregation (mag_pyg/gnn.py:25-68,140-168)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_rgcn_matches_reference_golden(golden_mag_rgcn):
+    G = golden_mag_rgcn
+    sizes, edge_index_dict, key2int, params, args = mag_rgcn_case(G, DEV)
+    m = PM.RGCN(8, 12, 5, 2, 0.5, sizes, [0], 4).to(DEV)
+    m.load_state_dict(params)
+    m.eval()
+    with torch.no_grad():
+        y = m(*args)
+    inf = m.inference(args[0], edge_index_dict, key2int)
+    close(y, G["forward_logits"], rtol=1e-5, atol_scale=1e-5)
+    close(m.out_feat, G["forward_out_feat"], rtol=1e-5, atol_scale=1e-5)
+    for j, v in inf.items():
+        close(v, G[f"inference__{j}"], rtol=1e-5, atol_scale=1e-5)
+
+
+@pytest.mark.gpu
+def test_rgcnconv_forward_backward_vs_oracle():
+    """A larger grouped graph: 4 node types, 7 relations (one of them empty), hub targets; values and all gradients."""
+    g = torch.Generator().manual_seed(17)
+    n, F_in, F_out, NT, ET = 3000, 64, 48, 4, 7
+    node_type = torch.randint(0, NT, (n,), generator=g)
+    E_ = 40000
+    ei = torch.stack([torch.randint(0, n, (E_,), generator=g),
+                      torch.cat([torch.randint(0, n, (E_ - 3000,), generator=g), torch.full((3000,), 5)])])
+    et = torch.randint(0, ET - 1, (E_,), generator=g)             # relation ET-1 has no edges
+    x = torch.randn(n, F_in, generator=g)
+    gy = torch.randn(n, F_out, generator=g)
+    torch.manual_seed(2)
+    oc = ON.RGCNConv(F_in, F_out, NT, ET)
+    pc = E.RGCNConv(F_in, F_out, NT, ET).to(DEV)
+    pc.load_state_dict(oc.state_dict())
+    xo = x.clone().requires_grad_(True)
+    xp = x.to(DEV).requires_grad_(True)
+    ref = oc(xo, ei, et, node_type)
+    out = pc(xp, ei.to(DEV), et.to(DEV), node_type.to(DEV))
+    close(out, ref, rtol=1e-5, atol_scale=1e-5)
+    ref.backward(gy)
+    out.backward(gy.to(DEV))
+    close(xp.grad, xo.grad, rtol=1e-4, atol_scale=1e-5)
+    for (k, a), (_, b) in zip(pc.named_parameters(), oc.named_parameters()):
+        ga = torch.zeros_like(a) if a.grad is None else a.grad      # an unused relation: no gradient == zero gradient
+        gb = torch.zeros_like(b) if b.grad is None else b.grad
+        close(ga, gb, rtol=1e-4, atol_scale=1e-5, msg=k)

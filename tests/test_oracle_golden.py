@@ -7,7 +7,7 @@ import oracle.criterion as OC
 import oracle.models as OM
 import oracle.sparse as OS
 import oracle.utils as OU
-from conftest import as_t
+from conftest import as_t, mag_rgcn_case
 
 RT, AT = 1e-6, 1e-7
 
@@ -184,3 +184,20 @@ def test_oracle_gat_and_teachernet_match_reference_bodies(golden_ppi_teacher):
         yt = t(x, ei)
     np.testing.assert_allclose(yt.numpy(), G["teachernet_logits"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(float(t.out_feat.double().sum()), float(G["teachernet_out_feat_sum"]), rtol=1e-6)
+
+
+def test_oracle_rgcn_matches_reference_body(golden_mag_rgcn):
+    """mag_pyg/gnn.py RGCNConv / RGCN.forward / RGCN.inference executed from the reference's own file (MessagePassing and
+    SparseTensor shimmed by the oracle); the oracle restatement with the same weights reproduces them."""
+    G = golden_mag_rgcn
+    sizes, edge_index_dict, key2int, params, args = mag_rgcn_case(G)
+    m = OM.RGCN(8, 12, 5, 2, 0.5, sizes, [0], 4)
+    m.load_state_dict(params)
+    m.eval()
+    with torch.no_grad():
+        y = m(*args)
+        inf = m.inference(args[0], edge_index_dict, key2int)
+    np.testing.assert_allclose(y.numpy(), G["forward_logits"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(m.out_feat.numpy(), G["forward_out_feat"], rtol=1e-5, atol=1e-6)
+    for j, v in inf.items():
+        np.testing.assert_allclose(v.numpy(), G[f"inference__{j}"], rtol=1e-5, atol=1e-6)
