@@ -25,3 +25,14 @@ class ToSparseTensor:
         data.adj_t = to_sparse_tensor(data.edge_index, int(n))
         data.edge_index = None
         return data
+
+
+def neighbor_average_features(adj_t: SparseTensor, x: torch.Tensor, R: int):
+    """SIGN preprocessing (/root/reference/arxiv_dgl/sign.py:175-186): ``[x, A x, A^2 x, ..., A^R x]`` with A = mean over
+    the in-neighbours (``fn.copy_u`` + ``fn.mean``; nodes without in-edges get 0) -- R mean-SpMMs on the GPU."""
+    from .ops import spmm_raw
+    feats = [x]
+    adj = adj_t.set_value(None) if adj_t.has_value() else adj_t
+    for _ in range(R):
+        feats.append(spmm_raw(adj, feats[-1], "mean")[0])
+    return feats

@@ -342,3 +342,12 @@ def gcn_norm_edge_index(edge_index: Tensor, num_nodes: int, dtype=torch.float32)
     dinv = deg.pow(-0.5)
     dinv.masked_fill_(dinv == float("inf"), 0.0)
     return edge_index, dinv[row] * ew * dinv[col]
+
+
+def neighbor_average_features(adj_t: "SparseTensor", x, R: int):
+    """SIGN hop features (/root/reference/arxiv_dgl/sign.py:175-186): repeated mean over the in-neighbours."""
+    feats = [x]
+    adj = adj_t.set_value(None) if adj_t.has_value() else adj_t
+    for _ in range(R):
+        feats.append(matmul(adj, feats[-1], "mean"))
+    return feats

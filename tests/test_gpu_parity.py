@@ -917,3 +917,17 @@ def test_rgcnconv_forward_backward_vs_oracle():
         ga = torch.zeros_like(a) if a.grad is None else a.grad      # an unused relation: no gradient == zero gradient
         gb = torch.zeros_like(b) if b.grad is None else b.grad
         close(ga, gb, rtol=1e-4, atol_scale=1e-5, msg=k)
+
+
+@pytest.mark.gpu
+def test_sign_neighbor_averaged_features_vs_oracle():
+    """arxiv_dgl/sign.py:175-186: R rounds of mean aggregation over the in-neighbours."""
+    d = D.arxiv_like(scale=0.03, seed=4, with_teacher=False)
+    import efficient_gnns_amd.transforms as T
+    rowptr, col, _ = d.adj_t.csr()
+    oadj = OS.SparseTensor(rowptr=rowptr, col=col, sparse_sizes=d.adj_t.sparse_sizes())
+    ref = OS.neighbor_average_features(oadj, d.x, 3)
+    out = T.neighbor_average_features(d.adj_t.to(DEV), d.x.to(DEV), 3)
+    assert len(out) == 4 and torch.equal(out[0].cpu(), d.x)
+    for a, b in zip(out[1:], ref[1:]):
+        close(a, b, rtol=1e-5, atol_scale=1e-5)
