@@ -134,6 +134,9 @@ class SAGEConv(nn.Module):
         return f"SAGEConv({self.in_channels}, {self.out_channels}, aggr={self.aggr})"
 
 
+_GAT_STRUCT_CACHE: dict = {}
+
+
 class GATConv(nn.Module):
     """PyG <=1.7 ``GATConv`` for INFERENCE: the frozen GAT teacher that the PPI / MAG train loops run inside every student
     step (/root/reference/ppi_pyg/gnn.py:86-117,208-209).  Same parameters and ``state_dict`` keys as PyG 1.6/1.7
@@ -165,7 +168,21 @@ class GATConv(nn.Module):
                 self.bias.zero_()
 
     def _structure(self, adj, n: int) -> SparseTensor:
-        """CSR by target with the self loops replaced (remove_self_loops + add_self_loops), built on the device."""
+        """CSR by target with the self loops replaced (remove_self_loops + add_self_loops), built on the device.
+        Integer preprocessing, memoised on the identity of the index tensor (the PPI teacher meets the same 20 batch
+        graphs every epoch, in each of its three layers; PyG rebuilds the loops per call)."""
+        base = adj._col if isinstance(adj, SparseTensor) else adj
+        key = (base.data_ptr(), base._version, tuple(base.shape), n, self.add_self_loops,
+               adj._rowptr.data_ptr() if isinstance(adj, SparseTensor) else 0)
+        hit = _GAT_STRUCT_CACHE.get(key)
+        if hit is not None:
+            return hit
+        if len(_GAT_STRUCT_CACHE) >= 64:
+            _GAT_STRUCT_CACHE.clear()
+        out = _GAT_STRUCT_CACHE[key] = self._build_structure(adj, n)
+        return out
+
+    def _build_structure(self, adj, n: int) -> SparseTensor:
         if isinstance(adj, SparseTensor):
             src, dst = adj._col, adj._row()
         else:
