@@ -88,7 +88,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.egnn_abi_version() != 1:
+    if lib.egnn_abi_version() != 2:
         raise HipExtensionError("libegnn_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -34,7 +34,7 @@ extern "C" {
 #define EGNN_EWORKSPACE (-3) /* caller-provided workspace too small */
 #define EGNN_EALIGN (-4)   /* pointer / leading dimension not aligned as the entry point requires */
 
-#define EGNN_ABI_VERSION 1
+#define EGNN_ABI_VERSION 2
 int egnn_abi_version(void);
 const char* egnn_error_string(int code);
 /* Number of distinct kernels-families compiled in; used by the loader's self check. */
