@@ -257,6 +257,37 @@ int row_blocks(int64_t n) {
 
 }  // namespace
 
+namespace {
+// merge per-shard (mean | var | n) triples in shard order (Chan et al. pairwise update): one thread per column
+__global__ void bn_merge_shards_kernel(const float* __restrict__ st, int world, int64_t C, float* __restrict__ mean,
+                                       float* __restrict__ var, float* __restrict__ total) {
+  const int64_t c = blockIdx.x * 256LL + threadIdx.x;
+  if (c >= C) return;
+  const int64_t ld = 2 * C + 1;
+  float n = 0.f, m = 0.f, m2 = 0.f;   // running count, mean, sum of squared deviations
+  for (int w = 0; w < world; ++w) {
+    const float nb = st[w * ld + 2 * C];
+    if (nb <= 0.f) continue;
+    const float mb = st[w * ld + c], vb = st[w * ld + C + c];
+    const float nt = n + nb, d = mb - m;
+    m2 = m2 + vb * nb + d * d * (n * nb / nt);
+    m = m + d * (nb / nt);
+    n = nt;
+  }
+  mean[c] = m;
+  var[c] = n > 0.f ? m2 / n : 0.f;
+  if (c == 0) total[0] = n;
+}
+}  // namespace
+
+extern "C" int egnn_bn_merge_shards_f32(const float* stats, int world, int64_t C, float* mean, float* var, float* total,
+                                        void* stream) {
+  EGNN_CHECK_ARG(world > 0 && C > 0 && stats && mean && var && total);
+  hipLaunchKernelGGL(bn_merge_shards_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, stats, world, C, mean,
+                     var, total);
+  return egnn_launch_status();
+}
+
 extern "C" size_t egnn_bn_ws_floats(int64_t C) { return (size_t)kStatBlocks * 2 * (size_t)C; }
 
 extern "C" int egnn_bn_stats_f32(const float* x, int64_t ld, int64_t n, int64_t C, float* mean, float* var, float* ws,

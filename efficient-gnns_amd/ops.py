@@ -566,13 +566,13 @@ class _SyncBnAct(torch.autograd.Function):
             ws = torch.empty(nws, dtype=torch.float32, device=dev)
             _lib.check(lib.egnn_bn_stats_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(stats), _lib.ptr(stats[C:]), _lib.ptr(ws), nws,
                                              _lib.stream()), "egnn_bn_stats_f32")
-            stats[2 * C] = float(n)
+            stats[2 * C:].fill_(float(n))     # a fill kernel, not a host->device copy
         allst = torch.empty(world, 2 * C + 1, dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(allst, stats, group=group)
-        cnt = allst[:, 2 * C:]                                   # [world, 1]
-        total = cnt.sum()
-        mean = (allst[:, :C] * cnt).sum(0) / total
-        var = ((allst[:, C:2 * C] + (allst[:, :C] - mean) ** 2) * cnt).sum(0) / total
+        merged = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
+        mean, var, total = merged[:C], merged[C:2 * C], merged[2 * C:]
+        _lib.check(lib.egnn_bn_merge_shards_f32(_lib.ptr(allst), world, C, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(total), _lib.stream()),
+                   "egnn_bn_merge_shards_f32")
         y = torch.empty(n, C, dtype=torch.float32, device=dev)
         if n > 0:
             rc = lib.egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),

@@ -329,6 +329,10 @@ int egnn_bn_act_bwd_f32(const float* x, int64_t ld, const float* dy, int64_t ld_
                         int batch_stats, float* dgamma, float* dbeta, float* dx, int64_t ld_dx, float* ws, size_t ws_floats,
                         void* stream);
 
+/* Merge the per-shard statistics of a sharded batch: stats [world, 2C+1] = (mean[C] | biased var[C] | rows) per shard
+ * (all-gathered over RCCL), combined in shard order with the pairwise update of Chan et al. (identical on every rank);
+ * shards with 0 rows are skipped.  Outputs mean [C], biased var [C], total [1] (rows of all shards). */
+int egnn_bn_merge_shards_f32(const float* stats, int world, int64_t C, float* mean, float* var, float* total, void* stream);
 int egnn_bn_act_bwd_reduce_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
                                const float* mean, const float* var, float eps, const float* gamma, const float* beta, int relu,
                                float p, uint64_t seed, float* dgamma, float* dbeta, float* ws, size_t ws_floats, void* stream);
