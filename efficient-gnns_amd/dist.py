@@ -20,17 +20,15 @@ Everything else (local aggregation, GEMMs, losses) is the single-GPU kernel path
 from __future__ import annotations
 
 import json
-import math
 import os
 import time
-import types
 
 import numpy as np
 import torch
 import torch.distributed as dist
 from torch import Tensor, nn
 
-from . import _lib, ops
+from . import ops
 from .sparse import SparseTensor
 
 
