@@ -312,7 +312,7 @@ __device__ __forceinline__ float nce_bwd_finish(float v, int64_t row, int64_t c,
   return scale * v;
 }
 
-template <int BM, int AMAJ, bool VEC4, bool EXPZ>
+template <int BM, int AMAJ, bool VEC4, bool EXPZ, bool BW = true>
 __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ Z, int64_t ldz, int64_t M, int64_t Kd,
                                                       int64_t diag_off, const float* __restrict__ lse, float shift,
                                                       const float* __restrict__ Bm, int64_t P, int64_t ldb,
@@ -346,9 +346,11 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ 
     mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, kbeg, kend, xf, id, smem);
   } else if constexpr (AMAJ == KMAJOR) {
     mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, kbeg, kend, id, id, smem);
-  } else {
+  } else if constexpr (BW) {   // teacher side, rows of fhat weighted while they are staged
     RowWeightXf xw{lse, shift};
     mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, kbeg, kend, id, xw, smem);
+  } else {                     // teacher side, Bm already holds w o fhat (nce_row_weight_kernel)
+    mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, kbeg, kend, id, id, smem);
   }
   const int lane = egnn_lane();
   const int wave = egnn_wave_id();
@@ -389,6 +391,17 @@ __global__ __launch_bounds__(256) void nce_bwd_reduce_kernel(const float* __rest
   }
 }
 
+// out[i,:] = exp(shift - lse[i]) * x[i,:]: the weighted student rows of the unit-rows backward, formed once instead of
+// inside the GEMM's staging loop (an exp per four staged elements there competes with the MFMA issue)
+__global__ __launch_bounds__(256) void nce_row_weight_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ lse,
+                                                             float shift, int64_t n, int64_t P, float* __restrict__ out) {
+  const int64_t total = n * P;
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t i = t / P, c = t % P;
+    out[t] = x[i * ldx + c] * expf(shift - lse[i]);
+  }
+}
+
 // split-K factor of a backward GEMM with M output rows over a reduction of Kd: aim at >= 3 workgroups of 128 x 128 per CU
 inline int nce_bwd_split(int64_t M, int64_t P, int64_t Kd) {
   const int64_t t128 = ((M + 127) / 128) * ((P + 127) / 128);
@@ -414,6 +427,21 @@ void launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag
   const int64_t ksteps = (Kd + BK - 1) / BK;
   const int64_t k_per_split = ((ksteps + nsplit - 1) / nsplit) * BK;
   const dim3 grid((unsigned)(big ? t128 : ((M + 63) / 64) * tiles_n), (unsigned)nsplit);
+  if constexpr (AMAJ == MNMAJOR) {
+    if (ws && expz && vec4 && big) {   // teacher side of the unit-rows form: weight the Kd student rows once, then a plain GEMM
+      float* wx = ws + (size_t)nsplit * M * P;
+      const int64_t blocks = (Kd * P + 255) / 256;
+      hipLaunchKernelGGL(nce_row_weight_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, Bm, ldb, lse, shift, Kd, P, wx);
+      hipLaunchKernelGGL((nce_bwd_kernel<128, AMAJ, true, true, false>), grid, dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, shift, wx, P, P,
+                         Im, ldi, coef, g, C, ldc, k_per_split, ws);
+      if (nsplit > 1) {
+        const int64_t rb = (M * P + 255) / 256;
+        hipLaunchKernelGGL((nce_bwd_reduce_kernel<AMAJ, true>), dim3((unsigned)(rb < 4096 ? rb : 4096)), dim3(256), 0, st, ws, nsplit, M, P, Kd,
+                           diag_off, lse, shift, Im, ldi, coef, g, C, ldc);
+      }
+      return;
+    }
+  }
 #define EGNN_NCE_BWD(BM_, V, E) hipLaunchKernelGGL((nce_bwd_kernel<BM_, AMAJ, V, E>), grid, dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, shift, Bm, P, ldb, Im, ldi, coef, g, C, ldc, k_per_split, ws)
   if (big) {
     if (vec4) { if (expz) EGNN_NCE_BWD(128, true, true); else EGNN_NCE_BWD(128, true, false); }
@@ -438,7 +466,7 @@ extern "C" size_t egnn_nce_ws_floats(int64_t S) { return (size_t)S * (1 + 2 * kM
 extern "C" size_t egnn_nce_bwd_ws_floats(int64_t Sr, int64_t Sc, int64_t P) {
   if (Sr <= 0 || Sc <= 0 || P <= 0) return 0;
   const size_t a = (size_t)nce_bwd_split(Sr, P, Sc) * Sr * P, b = (size_t)nce_bwd_split(Sc, P, Sr) * Sc * P;
-  return a > b ? a : b;
+  return (a > b ? a : b) + (size_t)Sr * P;   // split-K partials + the weighted student rows of the teacher-side GEMM
 }
 
 extern "C" int egnn_nce_saves_exp(float tau, int unit_rows) { return tau > 0.f && nce_unit_form(tau, unit_rows) ? 1 : 0; }
