@@ -91,23 +91,26 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
   }
 }
 
-// merge the per-block partials: a block owns 32 columns, 8 thread groups stride over the partial rows, fixed-order
-// LDS combine (a single thread per column walking all partials is latency-bound: ~250 us for 1024 partials)
+// merge the per-block partials: a block owns kMergeCols columns, 256 / kMergeCols thread groups stride over the partial
+// rows (16 dependent-latency steps for 512 partials), fixed-order LDS combine.  (A single thread per column walking all
+// partials took ~250 us for 1024 partials; 32 columns x 8 groups 22 us; this shape ~8 us.)
+constexpr int kMergeCols = 8;
+constexpr int kMergeGroups = 256 / kMergeCols;
 __device__ __forceinline__ void merge_partials(const float* __restrict__ part, int nblocks, int64_t C, float& a, float& b, bool& owner,
                                                int64_t& c) {
-  __shared__ float sh[2][8][32];
-  const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  c = blockIdx.x * 32LL + col;
+  __shared__ float sh[2][kMergeGroups][kMergeCols];
+  const int col = threadIdx.x % kMergeCols, grp = threadIdx.x / kMergeCols;
+  c = (int64_t)blockIdx.x * kMergeCols + col;
   float sa = 0.f, sb = 0.f;
   if (c < C)
-    for (int i = grp; i < nblocks; i += 8) { sa += part[((int64_t)i * 2) * C + c]; sb += part[((int64_t)i * 2 + 1) * C + c]; }
+    for (int i = grp; i < nblocks; i += kMergeGroups) { sa += part[((int64_t)i * 2) * C + c]; sb += part[((int64_t)i * 2 + 1) * C + c]; }
   sh[0][grp][col] = sa;
   sh[1][grp][col] = sb;
   __syncthreads();
   owner = grp == 0 && c < C;
   a = 0.f; b = 0.f;
   if (owner)
-    for (int g = 0; g < 8; ++g) { a += sh[0][g][col]; b += sh[1][g][col]; }
+    for (int g = 0; g < kMergeGroups; ++g) { a += sh[0][g][col]; b += sh[1][g][col]; }
 }
 
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const float* __restrict__ part, int nblocks, const float* __restrict__ x,
@@ -299,7 +302,7 @@ extern "C" int egnn_bn_stats_f32(const float* x, int64_t ld, int64_t n, int64_t 
   const int64_t want = (n + 3) / 4;
   const int nb = (int)(want < kStatBlocks ? want : kStatBlocks);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(256), 0, st, x, ld, n, C, ws);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, ws, nb, x, n, C, mean, var);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((unsigned)((C + kMergeCols - 1) / kMergeCols)), dim3(256), 0, st, ws, nb, x, n, C, mean, var);
   return egnn_launch_status();
 }
 
@@ -325,7 +328,7 @@ extern "C" int egnn_bn_act_bwd_reduce_f32(const float* x, int64_t ld, const floa
   const int64_t want = (n + 3) / 4;
   const int nb = (int)(want < kStatBlocks ? want : kStatBlocks);
   hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, q, dy, ld_dy, ws);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, ws, nb, C, dbeta, dgamma);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)((C + kMergeCols - 1) / kMergeCols)), dim3(256), 0, st, ws, nb, C, dbeta, dgamma);
   return egnn_launch_status();
 }
 
