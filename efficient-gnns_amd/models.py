@@ -114,8 +114,8 @@ def _const_rows(t, idx):
     if hit is None:
         if len(_ROW_CACHE) > 8:
             _ROW_CACHE.clear()
-        hit = _ROW_CACHE[key] = t[idx]
-    return hit
+        hit = _ROW_CACHE[key] = (t[idx], t, idx)   # holds t / idx: their addresses cannot be reused while the entry lives
+    return hit[0]
 
 
 def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_logits, hp,

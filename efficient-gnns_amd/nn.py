@@ -45,6 +45,31 @@ def _gcn_norm_edge_index(edge_index: Tensor, n: int) -> SparseTensor:
     return _adj_from_edge_index(torch.stack([src2, dst2]), n, val)
 
 
+class _TensorKeyedCache:
+    """Memo for integer preprocessing keyed on the identity of index tensors (storage address, version counter, shape).
+    Every entry keeps a reference to its key tensors: while an entry lives, the allocator cannot hand the same address
+    to a different tensor, so an address match really means the same data."""
+
+    def __init__(self, capacity: int = 64):
+        self.capacity, self.store = capacity, {}
+
+    @staticmethod
+    def _key(tensors, extra):
+        return tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in tensors) + tuple(extra)
+
+    def get(self, tensors, extra, build):
+        key = self._key(tensors, extra)
+        hit = self.store.get(key)
+        if hit is None:
+            if len(self.store) >= self.capacity:
+                self.store.clear()
+            hit = self.store[key] = (tuple(tensors), build())
+        return hit[1]
+
+
+_GCN_NORM_CACHE = _TensorKeyedCache()
+
+
 class GCNConv(nn.Module):
     """out = A^ (x W) + b;  W [in,out] glorot, b zeros;  ``cached=True`` keeps A^ until reset_parameters().
 
@@ -83,7 +108,11 @@ class GCNConv(nn.Module):
             if isinstance(edge_index, SparseTensor):
                 norm = gcn_norm(edge_index)
             else:
-                norm = _gcn_norm_edge_index(edge_index, x.shape[0])
+                # ``cached=False`` (PPI: one batch graph per step, ppi_pyg/gnn.py:125) re-normalises on every call in PyG.
+                # The result only depends on the integer edge list, so it is memoised on that tensor's identity: the 20
+                # training graphs come back every epoch, in every layer, and building A^ costs a device->host read.
+                n_nodes = x.shape[0]
+                norm = _GCN_NORM_CACHE.get((edge_index,), (n_nodes,), lambda: _gcn_norm_edge_index(edge_index, n_nodes))
             if self.cached:
                 self._cached_adj_t = norm
         if (self.cached and _MEMOISE_AX and not x.requires_grad and self.in_channels <= self.out_channels
@@ -94,7 +123,7 @@ class GCNConv(nn.Module):
             key = (x.data_ptr(), x._version, tuple(x.shape), id(norm))
             if self._cached_ax is None or self._cached_ax[0] != key:
                 with torch.no_grad():
-                    self._cached_ax = (key, ops.spmm_raw(norm, x, "sum")[0])
+                    self._cached_ax = (key, ops.spmm_raw(norm, x, "sum")[0], x)   # holds x: its address cannot be reused meanwhile
             out = ops.matmul(self._cached_ax[1], self.weight)
             return out + self.bias if self.bias is not None else out
         if agg_first:
@@ -134,7 +163,7 @@ class SAGEConv(nn.Module):
         return f"SAGEConv({self.in_channels}, {self.out_channels}, aggr={self.aggr})"
 
 
-_GAT_STRUCT_CACHE: dict = {}
+_GAT_STRUCT_CACHE = _TensorKeyedCache()
 
 
 class GATConv(nn.Module):
@@ -171,16 +200,8 @@ class GATConv(nn.Module):
         """CSR by target with the self loops replaced (remove_self_loops + add_self_loops), built on the device.
         Integer preprocessing, memoised on the identity of the index tensor (the PPI teacher meets the same 20 batch
         graphs every epoch, in each of its three layers; PyG rebuilds the loops per call)."""
-        base = adj._col if isinstance(adj, SparseTensor) else adj
-        key = (base.data_ptr(), base._version, tuple(base.shape), n, self.add_self_loops,
-               adj._rowptr.data_ptr() if isinstance(adj, SparseTensor) else 0)
-        hit = _GAT_STRUCT_CACHE.get(key)
-        if hit is not None:
-            return hit
-        if len(_GAT_STRUCT_CACHE) >= 64:
-            _GAT_STRUCT_CACHE.clear()
-        out = _GAT_STRUCT_CACHE[key] = self._build_structure(adj, n)
-        return out
+        keys = (adj._col, adj._rowptr) if isinstance(adj, SparseTensor) else (adj,)
+        return _GAT_STRUCT_CACHE.get(keys, (n, self.add_self_loops), lambda: self._build_structure(adj, n))
 
     def _build_structure(self, adj, n: int) -> SparseTensor:
         if isinstance(adj, SparseTensor):
@@ -228,6 +249,9 @@ class GATConv(nn.Module):
         return f"GATConv({self.in_channels}, {self.out_channels}, heads={self.heads})"
 
 
+_RGCN_REL_CACHE = _TensorKeyedCache(capacity=8)
+
+
 class RGCNConv(nn.Module):
     """The reference's own R-GCN layer (/root/reference/mag_pyg/gnn.py:25-68, a ``MessagePassing(aggr='mean')`` subclass) on
     the kernels: per edge type i, ``mean_{j -> t, type i} rel_lins[i](x_j)`` is computed as ``rel_lins[i](mean x_j)`` (the
@@ -241,7 +265,6 @@ class RGCNConv(nn.Module):
         self.num_node_types, self.num_edge_types = num_node_types, num_edge_types
         self.rel_lins = nn.ModuleList([nn.Linear(in_channels, out_channels, bias=False) for _ in range(num_edge_types)])
         self.root_lins = nn.ModuleList([nn.Linear(in_channels, out_channels, bias=True) for _ in range(num_node_types)])
-        self._rel_cache = None
 
     def reset_parameters(self):
         for lin in list(self.rel_lins) + list(self.root_lins):
@@ -249,20 +272,19 @@ class RGCNConv(nn.Module):
 
     def _relations(self, edge_index: Tensor, edge_type: Tensor, node_type: Tensor, n: int):
         """Per-type CSR (by target) and per-node-type row lists; integer preprocessing, cached on the tensors' identity."""
-        key = (edge_index.data_ptr(), edge_index._version, edge_type.data_ptr(), edge_type._version, node_type.data_ptr(), n)
-        if self._rel_cache is None or self._rel_cache[0] != key:
+        def build():
             adjs = []
             for i in range(self.num_edge_types):
                 sel = torch.nonzero(edge_type == i).view(-1)
-                src, dst = edge_index[0, sel].contiguous(), edge_index[1, sel].contiguous()
                 if sel.numel() == 0:
                     adjs.append(None)
                     continue
+                src, dst = edge_index[0, sel].contiguous(), edge_index[1, sel].contiguous()
                 rowptr, col = csr_from_coo(dst, src, n, symmetric=False)
                 adjs.append(SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(n, n)))
             rows = [torch.nonzero(node_type == i).view(-1) for i in range(self.num_node_types)]
-            self._rel_cache = (key, adjs, rows)
-        return self._rel_cache[1], self._rel_cache[2]
+            return adjs, rows
+        return _RGCN_REL_CACHE.get((edge_index, edge_type, node_type), (n, self.num_edge_types, self.num_node_types), build)
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_type: Tensor, node_type: Tensor) -> Tensor:
         _lib.require_gpu(x, edge_index)
