@@ -931,3 +931,33 @@ def test_sign_neighbor_averaged_features_vs_oracle():
     assert len(out) == 4 and torch.equal(out[0].cpu(), d.x)
     for a, b in zip(out[1:], ref[1:]):
         close(a, b, rtol=1e-5, atol_scale=1e-5)
+
+
+@pytest.mark.gpu
+def test_structure_memo_is_not_fooled_by_allocator_address_reuse():
+    """GCNConv / GATConv memoise A^ / the attention CSR on the identity of the edge_index tensor.  A different graph of the
+    same shape created right after the first one was dropped (the caching allocator would hand out the same address) must
+    not hit the old entry: the entries keep their key tensors alive."""
+    n = 300
+    torch.manual_seed(0)
+    og, pg = ON.GCNConv(16, 8, cached=False), E.GCNConv(16, 8, cached=False).to(DEV)
+    pg.load_state_dict(og.state_dict())
+    oa, pa = ON.GATConv(16, 8, heads=2).eval(), E.GATConv(16, 8, heads=2).to(DEV).eval()
+    pa.load_state_dict(oa.state_dict())
+    x = torch.randn(n, 16)
+    xg = x.to(DEV)
+    for seed in range(4):
+        g = torch.Generator().manual_seed(seed)
+        ei = torch.randint(0, n, (2, 2000), generator=g)
+        ei_dev = ei.to(DEV)
+        with torch.no_grad():
+            close(pg(xg, ei_dev), og(x, ei), rtol=1e-5, atol_scale=1e-5, msg=f"gcn seed {seed}")
+            close(pa(xg, ei_dev), oa(x, ei), rtol=1e-5, atol_scale=1e-5, msg=f"gat seed {seed}")
+        del ei_dev
+    # in-place edits bump the version counter: a new entry, not the stale one
+    ei_dev = ei.to(DEV)
+    with torch.no_grad():
+        pg(xg, ei_dev)
+        ei_dev[0, :50] = 0
+        ei2 = ei.clone(); ei2[0, :50] = 0
+        close(pg(xg, ei_dev), og(x, ei2), rtol=1e-5, atol_scale=1e-5, msg="in-place edit")
