@@ -206,3 +206,45 @@ def test_segment_plan_covers_every_entry_exactly_once():
         ps = part[int(cptr[i]):int(cptr[i + 1])]
         assert int(ps[0, 0]) == int(rowptr[r]) and int(ps[-1, 1]) == int(rowptr[r + 1])
         assert torch.equal(ps[1:, 0], ps[:-1, 1])
+
+
+# ------------------------------------------------------------------------------------------------
+# property-based: host structure logic vs the oracle on arbitrary edge lists
+# ------------------------------------------------------------------------------------------------
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@st.composite
+def _edge_lists(draw):
+    n = draw(st.integers(1, 40))
+    e = draw(st.integers(0, 120))
+    src = draw(st.lists(st.integers(0, n - 1), min_size=e, max_size=e))
+    dst = draw(st.lists(st.integers(0, n - 1), min_size=e, max_size=e))
+    if e and draw(st.booleans()):                      # a hub target and duplicate edges
+        dst = [dst[0]] * (e // 2) + dst[e // 2:]
+        src = src[:e // 2] + src[:e - e // 2]
+    return n, torch.tensor([src, dst], dtype=torch.int64).reshape(2, e)
+
+
+@settings(max_examples=40, deadline=None)
+@given(_edge_lists())
+def test_host_structure_logic_property(case):
+    """ToSparseTensor / to_symmetric / csr2csc / segment plan on arbitrary edge lists: empty graphs, isolated nodes, self
+    loops, duplicates, hubs -- bit-exact against the oracle; the segment plan always tiles the entry range."""
+    import efficient_gnns_amd.sparse as SP
+    n, ei = case
+    o, p = OS.to_sparse_tensor(ei, n), E.to_sparse_tensor(ei, n)
+    for a, b in zip(p.csr()[:2], o.csr()[:2]):
+        assert torch.equal(a, b)
+    so, sp = o.to_symmetric(), p.to_symmetric()
+    for a, b in zip(sp.csr()[:2], so.csr()[:2]):
+        assert torch.equal(a, b)
+    assert torch.equal(sp.storage.colptr(), so._colptr()) and torch.equal(sp.storage.csr2csc(), so._csr2csc())
+    seg, crow, cptr, slots = p._seg_plan()
+    rowptr = p.csr()[0]
+    assert int((seg[:, 1] - seg[:, 0]).sum()) == p.nnz() and seg.shape[0] == n - crow.numel() + slots
+    assert max((seg[:, 1] - seg[:, 0]).tolist(), default=0) <= SP.SEG_MAX
+    assert sorted(seg[seg[:, 2] < n][:, 2].tolist() + crow.tolist()) == list(range(n))
+    for i, r in enumerate(crow.tolist()):
+        ps = seg[(seg[:, 2] >= n + int(cptr[i])) & (seg[:, 2] < n + int(cptr[i + 1]))]
+        assert int(ps[:, 0].min()) == int(rowptr[r]) and int(ps[:, 1].max()) == int(rowptr[r + 1])

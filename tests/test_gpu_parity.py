@@ -961,3 +961,46 @@ def test_structure_memo_is_not_fooled_by_allocator_address_reuse():
         ei_dev[0, :50] = 0
         ei2 = ei.clone(); ei2[0, :50] = 0
         close(pg(xg, ei_dev), og(x, ei2), rtol=1e-5, atol_scale=1e-5, msg="in-place edit")
+
+
+# ------------------------------------------------------------------------------------------------
+# property-based: SpMM on arbitrary CSR structures (empty rows, self loops, duplicates, hub rows)
+# ------------------------------------------------------------------------------------------------
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@st.composite
+def _spmm_cases(draw):
+    n_rows = draw(st.integers(1, 60))
+    n_cols = draw(st.integers(1, 60))
+    e = draw(st.integers(0, 400))
+    seed = draw(st.integers(0, 2 ** 16))
+    hub = draw(st.booleans())
+    K = draw(st.sampled_from([1, 3, 4, 8, 12, 32, 40, 64, 68]))
+    reduce = draw(st.sampled_from(["sum", "mean", "max"]))
+    valued = draw(st.booleans())
+    return n_rows, n_cols, e, seed, hub, K, reduce, valued
+
+
+@pytest.mark.gpu
+@settings(max_examples=60, deadline=None)
+@given(_spmm_cases())
+def test_spmm_property_random_structures(case):
+    n_rows, n_cols, e, seed, hub, K, reduce, valued = case
+    g = torch.Generator().manual_seed(seed)
+    rows = torch.randint(0, n_rows, (e,), generator=g)
+    cols = torch.randint(0, n_cols, (e,), generator=g)
+    if hub and e:
+        rows[: (3 * e) // 4] = rows[0]                 # one row holds 3/4 of the entries (> 64 of them when e is large)
+    rows, perm = torch.sort(rows, stable=True)
+    cols = cols[perm]
+    val = torch.randn(e, generator=g) if valued else None
+    x = torch.randn(n_cols, K, generator=g)
+    gy = torch.randn(n_rows, K, generator=g)
+    o, p = make_pair(rows, cols, val, (n_rows, n_cols))
+    xo, xp = x.clone().requires_grad_(True), x.to(DEV).requires_grad_(True)
+    yo, yp = OS.matmul(o, xo, reduce), p.matmul(xp, reduce)
+    close(yp, yo, rtol=1e-5, atol_scale=1e-5, msg=f"fwd {case}")
+    yo.backward(gy)
+    yp.backward(gy.to(DEV))
+    close(xp.grad, xo.grad, rtol=1e-4, atol_scale=1e-5, msg=f"bwd {case}")
