@@ -57,6 +57,13 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
     else:
         y = torch.empty(n_rows, K, dtype=torch.float32, device=x.device)
     arg = torch.empty(n_rows, K, dtype=torch.int64, device=x.device) if red == 2 else None
+    if adj.nnz() == 0:   # no stored entry at all: every row is empty (sum / mean / max = 0, argmax = -1), plus the bias
+        y.zero_()
+        if bias is not None:
+            y.add_(bias)
+        if arg is not None:
+            arg.fill_(-1)
+        return y, arg
     rowptr, col, bits = adj._index_arrays()
     lib = _lib.load()
     if (use_plan and _SPMM_SCHEDULE == "segments" and red != 2 and K % 4 == 0 and x.stride(0) % 4 == 0
@@ -129,6 +136,8 @@ class _SpMM(torch.autograd.Function):
             n_rows, n_src = adj.sparse_sizes()
             K = gy.shape[1]
             gx = torch.zeros(n_src, K, dtype=torch.float32, device=gy.device)
+            if adj.nnz() == 0:   # no stored entry: nothing receives gradient
+                return gx, None, None, (gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None)
             _, col, bits = adj._index_arrays()
             rc = _lib.load().egnn_spmm_csr_max_bwd_f32(n_rows, K, _lib.ptr(col), bits, _lib.ptr(adj._value), _lib.ptr(arg),
                                                        _lib.ptr(gy), gy.stride(0), _lib.ptr(gx), gx.stride(0), _lib.stream())

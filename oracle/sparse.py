@@ -251,6 +251,8 @@ class _SpmmMax(torch.autograd.Function):
         n = adj.sparse_sizes()[1]
         k = gout.shape[1]
         gx = torch.zeros(n, k, dtype=gout.dtype)
+        if col.numel() == 0:   # no stored entry: nothing receives gradient
+            return gx, None
         valid = arg >= 0
         e = arg.clamp(min=0)
         g = gout if val is None else gout * val[e]
