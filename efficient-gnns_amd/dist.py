@@ -139,8 +139,21 @@ class ShardedAdj:
             raise RuntimeError("ShardedAdj was built without the normalised adjacency (pass gcn_struct=)")
         return self._gcn
 
+    def register_static(self, x_local: Tensor) -> None:
+        """Declare ``x_local`` (the input node features: constant for the whole run) static: its halo rows are fetched
+        from the peers ONCE and kept next to the local rows, as a partitioned graph store keeps the features of a
+        partition's halo nodes.  Every later aggregation of exactly this tensor skips the exchange (2 of the 8 per
+        epoch, 22 % of the halo volume of the GCN run).  Collective: all ranks must register."""
+        self._static = (x_local, _HaloExchange.apply(x_local.detach(), self))
+        if self._gcn is not None:
+            self._gcn.register_static(x_local)
+
     def aggregate(self, x_local: Tensor, reduce: str, valueless: bool = False) -> Tensor:
-        x_ext = _HaloExchange.apply(x_local, self)
+        st = getattr(self, "_static", None)
+        if st is not None and st[0] is x_local and not x_local.requires_grad and x_local._version == st[0]._version:
+            x_ext = st[1]
+        else:
+            x_ext = _HaloExchange.apply(x_local, self)
         adj = self.raw.set_value(None) if valueless and self.raw.has_value() else self.raw
         return ops.spmm(adj, x_ext, reduce)
 
@@ -307,6 +320,7 @@ class ShardedProblem:
             gcn_struct = gcn_norm(data.adj_t.to(device)) if torch.device(device).type == "cuda" else data.gcn_struct
         self.adj = ShardedAdj(data.adj_t, world, rank, device, group, gcn_struct=gcn_struct)
         self.x = data.x[lo:hi].to(device)
+        self.adj.register_static(self.x)          # input features never change: halo copy fetched once
         self.y = data.y[lo:hi].to(device)
         self.teacher_out_feat = data.teacher_out_feat[lo:hi].to(device) if getattr(data, "teacher_out_feat", None) is not None else None
         if self.teacher_out_feat is not None and self.teacher_out_feat.is_cuda:
