@@ -1004,3 +1004,20 @@ def test_spmm_property_random_structures(case):
     yo.backward(gy)
     yp.backward(gy.to(DEV))
     close(xp.grad, xo.grad, rtol=1e-4, atol_scale=1e-5, msg=f"bwd {case}")
+
+
+@pytest.mark.gpu
+def test_plain_c_host_program_drives_the_c_abi(tmp_path):
+    """examples/c_abi_spmm.c: a C99 program (gcc, no Python / torch) that allocates with the HIP runtime C API, calls
+    egnn_spmm_csr_f32 / egnn_gcn_norm_count_i64 through include/egnn_hip.h and checks them against host loops."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "efficient-gnns_amd", "lib")
+    exe = str(tmp_path / "c_abi_spmm")
+    cmd = ["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I", os.path.join(root, "include"),
+           os.path.join(root, "examples", "c_abi_spmm.c"), "-L", lib, "-legnn_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+           f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=120)
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "max rel err" in run.stdout and run.stdout.strip().endswith("ok")
