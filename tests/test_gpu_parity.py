@@ -4,6 +4,8 @@ product package, against the CPU oracle and the golden vectors.
 Bars: integer / index results bit-exact; fp32 layer outputs rtol 1e-5 with
 atol = 1e-5 * max|ref|; scalar losses rtol 1e-5 (NCE 2e-5); gradients rtol 1e-4.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
