@@ -248,3 +248,23 @@ def test_host_structure_logic_property(case):
     for i, r in enumerate(crow.tolist()):
         ps = seg[(seg[:, 2] >= n + int(cptr[i])) & (seg[:, 2] < n + int(cptr[i + 1]))]
         assert int(ps[:, 0].min()) == int(rowptr[r]) and int(ps[:, 1].max()) == int(rowptr[r + 1])
+
+
+@settings(max_examples=40, deadline=None)
+@given(_edge_lists(), st.integers(0, 2 ** 16), st.booleans())
+def test_subgraph_property(case, seed, as_mask):
+    """utils.subgraph (gnn.py:246-249: the train-induced subgraph handed to the LSP loss): kept edges, their order and the
+    relabelling equal the oracle's for index and boolean-mask subsets, with and without relabelling."""
+    import efficient_gnns_amd.utils as PU
+    n, ei = case
+    g = torch.Generator().manual_seed(seed)
+    k = int(torch.randint(0, n + 1, (1,), generator=g))
+    subset = torch.randperm(n, generator=g)[:k]
+    if as_mask:
+        m = torch.zeros(n, dtype=torch.bool)
+        m[subset] = True
+        subset = m
+    for relabel in (False, True):
+        a, _ = PU.subgraph(subset, ei, relabel_nodes=relabel, num_nodes=n)
+        b, _ = OU.subgraph(subset, ei, relabel_nodes=relabel, num_nodes=n)
+        assert torch.equal(a, b)
