@@ -268,3 +268,25 @@ def test_subgraph_property(case, seed, as_mask):
         a, _ = PU.subgraph(subset, ei, relabel_nodes=relabel, num_nodes=n)
         b, _ = OU.subgraph(subset, ei, relabel_nodes=relabel, num_nodes=n)
         assert torch.equal(a, b)
+
+
+def test_integration_md_ctypes_snippet_matches_the_header():
+    """The binding shown in INTEGRATION.md must have exactly the parameters include/egnn_hip.h declares (doc rot guard)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    md = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = md[md.index("```python\nimport ctypes, torch"):]
+    block = block[len("```python\n"):block.index("```", 10)]
+    stmt = block[block.index("lib.egnn_spmm_csr_f32.argtypes"):block.index("def spmm_sum")]
+
+    class _Fn:
+        pass
+
+    class _Lib:
+        egnn_spmm_csr_f32 = _Fn()
+    exec(stmt, {"ctypes": ctypes, "lib": _Lib})
+    shown = _Lib.egnn_spmm_csr_f32.argtypes
+    table = _lib.SIGNATURES["egnn_spmm_csr_f32"][1]
+    assert len(shown) == len(table)
+    assert [ctypes.sizeof(a) for a in shown] == [ctypes.sizeof(a) for a in table]
+    call = block[block.index("rc = lib.egnn_spmm_csr_f32("):block.index("assert rc == 0")]
+    assert call.count(",") + 1 == len(table), "the example call passes a different number of arguments"
