@@ -14,6 +14,8 @@ beta=0.1, nce_T=0.075, max_samples=16384, proj_dim=256).  Inputs are resident in
 Rank 0 prints ONE JSON line (contract in the task statement) carrying also
   "roofline":     the SpMM aggregate kernel (K=256 GCN layer) timed with HIP events on its own stream
                   inside the timed region; achieved = algorithmic bytes / avg launch time
+  "roofline_mfma": (extra) the G-CRD entry points -- the largest share of the step, fp32-MFMA-bound -- timed the same way;
+                  achieved = 6 S^2 P flops per step / their time
   "cpu_baseline": the CPU oracle (pure-PyTorch restatement of the reference path) timed on the host cores
                   on the SAME synthetic inputs, a bounded sample of epochs (rank 0, N=1 only).
 """
@@ -133,6 +135,45 @@ class SpmmProbe:
         return dict(launches=len(ts), avg_s=avg, bytes=ts[0][1])
 
 
+class NceProbe:
+    """Brackets the G-CRD entry points (egnn_nce_fwd_f32 / egnn_nce_bwd_f32: the largest share of the step, MFMA-bound) with
+    HIP events on the launch stream, for the secondary `roofline_mfma` object."""
+
+    def __init__(self, lib):
+        self.lib, self.records, self.active = lib, [], False
+        self._orig = {n: getattr(lib, n) for n in ("egnn_nce_fwd_f32", "egnn_nce_bwd_f32")}
+
+    def __enter__(self):
+        def wrap(name, flops_per_s2p):
+            orig = self._orig[name]
+
+            def wrapped(*a):
+                if not self.active:
+                    return orig(*a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = orig(*a)
+                e1.record()
+                S, P = int(a[2]), int(a[3])
+                self.records.append((flops_per_s2p * S * S * P, e0, e1))
+                return rc
+            return wrapped
+        setattr(self.lib, "egnn_nce_fwd_f32", wrap("egnn_nce_fwd_f32", 2))   # Z = F T^T
+        setattr(self.lib, "egnn_nce_bwd_f32", wrap("egnn_nce_bwd_f32", 4))   # dF = P T, dT = P^T F
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self._orig.items():
+            setattr(self.lib, n, f)
+
+    def summary(self):
+        if not self.records:
+            return None
+        flops = sum(f for f, _, _ in self.records)
+        secs = sum(a.elapsed_time(b) * 1e-3 for _, a, b in self.records)
+        return dict(calls=len(self.records), flops=flops, secs=secs)
+
+
 def cpu_baseline(args, data, hp):
     """The CPU oracle on the host cores: same inputs, same epoch definition, bounded number of epochs."""
     import oracle.models as OM
@@ -218,8 +259,10 @@ def main():
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     train_ms = eval_ms = 0.0
-    with SpmmProbe(ops) as probe:
+    from efficient_gnns_amd import _lib as _egnn_lib
+    with SpmmProbe(ops) as probe, NceProbe(_egnn_lib.load()) as nce_probe:
         probe.active = True
+        nce_probe.active = True
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -235,6 +278,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         probe.active = False
+        nce_probe.active = False
     K = MODEL["hidden"]
     roof = probe.summary(K)
     roofline = None
@@ -258,6 +302,15 @@ def main():
                         algorithmic_bytes_per_launch=roof["bytes"], avg_launch_us=round(roof["avg_s"] * 1e6, 2),
                         launches_timed=roof["launches"], traffic=float(traffic) if traffic else None,
                         traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (profiles/r01_spmm_traffic.json)" if traffic else None)
+    roofline_mfma = None
+    nsum = nce_probe.summary()
+    if nsum:
+        tf = nsum["flops"] / nsum["secs"] / 1e12
+        roofline_mfma = dict(bound="mfma", kernel="nce_fwd_kernel + nce_bwd_kernel x2 + split-K reduce (egnn_nce_fwd_f32, egnn_nce_bwd_f32): "
+                                                  "the G-CRD loss, largest share of the step", achieved=round(tf, 1), peak=157.3,
+                             unit="TFLOP/s", frac=round(tf / 157.3, 4), dtype="f32 (v_mfma_f32_32x32x2_f32)",
+                             flops_per_step=int(nsum["flops"] / max(1, args.steps)),
+                             ms_per_step=round(1e3 * nsum["secs"] / max(1, args.steps), 3), calls_timed=nsum["calls"])
     cpu = cpu_baseline(args, data, hp) if args.cpu_epochs > 0 else None
 
     out = dict(
@@ -276,7 +329,7 @@ def main():
                     adam=os.environ.get("EGNN_ADAM", "fused"),
                     memoise_first_layer_aggregation=os.environ.get("EGNN_GCN_MEMOISE_AX", "0") == "1",
                     cache_constant_row_gathers=os.environ.get("EGNN_CACHE_CONST_ROWS", "0") == "1"),
-        roofline=roofline, cpu_baseline=cpu,
+        roofline=roofline, roofline_mfma=roofline_mfma, cpu_baseline=cpu,
         phases_ms=dict(train_step=round(train_ms / args.steps, 3), eval=round(eval_ms / args.steps, 3)),
         last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs],
     )
