@@ -1023,3 +1023,60 @@ def test_plain_c_host_program_drives_the_c_abi(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "max rel err" in run.stdout and run.stdout.strip().endswith("ok")
+
+
+@pytest.mark.gpu
+def test_sharded_batchnorm_pieces_on_simulated_shards():
+    """The N > 1 BatchNorm math without N GPUs: rows split into 3 uneven shards (one of them empty), per-shard
+    egnn_bn_stats_f32 -> egnn_bn_merge_shards_f32 must equal the full-batch statistics, and per-shard
+    egnn_bn_act_bwd_reduce_f32 summed over shards (what the all-reduce does) -> egnn_bn_act_bwd_apply_f32 with 1/N_total
+    must equal the single-GPU backward on the whole batch."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    n, C = 5000, 64
+    x = (torch.randn(n, C, generator=g) * 2.0 + 0.7).to(DEV)
+    dy = torch.randn(n, C, generator=g).to(DEV)
+    gamma, beta = torch.rand(C, generator=g).to(DEV) + 0.5, torch.randn(C, generator=g).to(DEV)
+    cuts = [0, 1234, 1234, 5000]                                    # shard 1 is empty
+    world = 3
+    nws = lib.egnn_bn_ws_floats(C)
+    ws = torch.empty(nws, device=DEV)
+    stats = torch.zeros(world, 2 * C + 1, device=DEV)
+    for w in range(world):
+        xs = x[cuts[w]:cuts[w + 1]]
+        if xs.shape[0]:
+            _lib.check(lib.egnn_bn_stats_f32(_lib.ptr(xs), C, xs.shape[0], C, _lib.ptr(stats[w]), _lib.ptr(stats[w, C:]), _lib.ptr(ws), nws,
+                                             _lib.stream()), "stats")
+            stats[w, 2 * C] = float(xs.shape[0])
+    merged = torch.empty(2 * C + 1, device=DEV)
+    _lib.check(lib.egnn_bn_merge_shards_f32(_lib.ptr(stats), world, C, _lib.ptr(merged), _lib.ptr(merged[C:]), _lib.ptr(merged[2 * C:]),
+                                            _lib.stream()), "merge")
+    mean, var = merged[:C].clone(), merged[C:2 * C].clone()
+    assert float(merged[2 * C]) == n
+    close(mean, x.double().mean(0), rtol=1e-5, atol_scale=1e-6)
+    close(var, x.double().var(0, unbiased=False), rtol=1e-5, atol_scale=1e-6)
+    # backward: reference = the single-GPU entry point on the whole batch with the same statistics
+    eps, relu, p, seed = 1e-5, 1, 0.0, 0
+    dg_ref, db_ref, dx_ref = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty_like(x)
+    _lib.check(lib.egnn_bn_act_bwd_f32(_lib.ptr(x), C, _lib.ptr(dy), C, n, C, _lib.ptr(mean), _lib.ptr(var), eps, _lib.ptr(gamma), _lib.ptr(beta),
+                                       relu, p, seed, 1, _lib.ptr(dg_ref), _lib.ptr(db_ref), _lib.ptr(dx_ref), C, _lib.ptr(ws), nws,
+                                       _lib.stream()), "bwd")
+    total = torch.zeros(2 * C, device=DEV)                           # [dbeta | dgamma] summed over the shards
+    for w in range(world):
+        xs, ds = x[cuts[w]:cuts[w + 1]], dy[cuts[w]:cuts[w + 1]]
+        if xs.shape[0]:
+            part = torch.empty(2 * C, device=DEV)
+            _lib.check(lib.egnn_bn_act_bwd_reduce_f32(_lib.ptr(xs), C, _lib.ptr(ds), C, xs.shape[0], C, _lib.ptr(mean), _lib.ptr(var), eps,
+                                                      _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(part[C:]), _lib.ptr(part),
+                                                      _lib.ptr(ws), nws, _lib.stream()), "reduce")
+            total += part
+    close(total[:C], db_ref, rtol=1e-4, atol_scale=1e-5)
+    close(total[C:], dg_ref, rtol=1e-4, atol_scale=1e-5)
+    dx = torch.empty_like(x)
+    for w in range(world):
+        xs, ds = x[cuts[w]:cuts[w + 1]], dy[cuts[w]:cuts[w + 1]]
+        if xs.shape[0]:
+            _lib.check(lib.egnn_bn_act_bwd_apply_f32(_lib.ptr(xs), C, _lib.ptr(ds), C, xs.shape[0], C, _lib.ptr(mean), _lib.ptr(var), eps,
+                                                     _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(total), _lib.ptr(total[C:]),
+                                                     1.0 / n, _lib.ptr(dx[cuts[w]:cuts[w + 1]]), C, _lib.stream()), "apply")
+    close(dx, dx_ref, rtol=1e-4, atol_scale=1e-5)
