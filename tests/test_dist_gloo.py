@@ -121,12 +121,12 @@ def _worker(rank, world, port, gnn, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("gnn,mode", [("gcn", "kd"), ("gcn", "nce"), ("sage", "nce"), ("sage", "supervised")])
-def test_sharded_training_matches_single_process_oracle(gnn, mode):
-    world = 2
+@pytest.mark.parametrize("gnn,mode,world", [("gcn", "kd", 2), ("gcn", "nce", 2), ("sage", "nce", 2), ("sage", "supervised", 2),
+                                            ("gcn", "nce", 3)])   # 3 ranks: uneven node ranges and sample counts
+def test_sharded_training_matches_single_process_oracle(gnn, mode, world):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    port = 29500 + (os.getpid() + hash((gnn, mode))) % 2000
+    port = 29500 + (os.getpid() + hash((gnn, mode, world))) % 2000
     procs = [ctx.Process(target=_worker, args=(r, world, port, gnn, mode, q)) for r in range(world)]
     for p in procs:
         p.start()
