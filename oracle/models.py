@@ -252,3 +252,47 @@ class RGCN(nn.Module):
                 out_dict = {j: F.relu(v) for j, v in out_dict.items()}
             x_dict = out_dict
         return x_dict
+
+
+def ppi_train_epoch(model, teacher_model, graphs, optimizer, mode, hp):
+    """One PPI epoch (/root/reference/ppi_pyg/gnn.py:185-274): one optimisation step per batch graph; in ``kd`` mode the
+    frozen teacher's forward runs inside every step (:208-209).  ``graphs``: objects with x / edge_index / y.
+    Returns the epoch means (loss, loss_cls, loss_aux) like the reference."""
+    model.train()
+    if teacher_model is not None:
+        teacher_model.eval()
+    tot = [0.0, 0.0, 0.0]
+    for g in graphs:
+        out = model(g.x, g.edge_index)
+        if mode == "supervised":
+            loss = F.binary_cross_entropy_with_logits(out, g.y)
+            loss_cls, loss_aux = loss, loss * 0
+        elif mode == "kd":
+            with torch.no_grad():
+                teacher_out = teacher_model(g.x, g.edge_index)
+            loss, loss_cls, loss_aux = C.ppi_kd_criterion(out, g.y, teacher_out, hp["alpha"], hp["kd_T"])
+        else:
+            raise NotImplementedError(mode)
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        for i, v in enumerate((loss, loss_cls, loss_aux)):
+            tot[i] += v.detach().item()
+    return tuple(v / max(1, len(graphs)) for v in tot)
+
+
+@torch.no_grad()
+def ppi_test(model, graphs):
+    """Micro-F1 over all nodes and labels of ``graphs`` (/root/reference/ppi_pyg/gnn.py:277-288: predictions = logits > 0,
+    sklearn ``f1_score(average='micro')``, 0 when nothing is predicted positive)."""
+    model.eval()
+    tp = fp = fn = 0.0
+    for g in graphs:
+        pred = (model(g.x, g.edge_index) > 0).float()
+        y = g.y
+        tp += float((pred * y).sum())
+        fp += float((pred * (1 - y)).sum())
+        fn += float(((1 - pred) * y).sum())
+    if tp + fp == 0:
+        return 0
+    return 2 * tp / (2 * tp + fp + fn)

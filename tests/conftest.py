@@ -43,6 +43,11 @@ def golden_mag_rgcn():
 
 
 @pytest.fixture(scope="session")
+def golden_ppi_train():
+    return np.load(os.path.join(GOLDEN, "ppi_train.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
 def golden_train():
     return np.load(os.path.join(GOLDEN, "train_arxiv.npz"), allow_pickle=False)
 
@@ -66,3 +71,16 @@ def mag_rgcn_case(G, device="cpu"):
     args = ({0: as_t(G["in_x0"], device)}, as_t(G["in_edge_index"], device), as_t(G["in_edge_type"], device),
             as_t(G["in_node_type"], device), as_t(G["in_local_idx"], device))
     return sizes, edge_index_dict, key2int, params, args
+
+
+def ppi_train_case(G, device="cpu"):
+    """Batch graphs and parameter dicts of tests/golden/ppi_train.npz."""
+    import types
+    graphs = []
+    i = 0
+    while f"in_x{i}" in G.files:
+        graphs.append(types.SimpleNamespace(x=as_t(G[f"in_x{i}"], device), edge_index=as_t(G[f"in_ei{i}"], device),
+                                            y=as_t(G[f"in_y{i}"], device)))
+        i += 1
+    sd = lambda prefix: {k[len(prefix):]: as_t(G[k], device) for k in G.files if k.startswith(prefix)}  # noqa: E731
+    return graphs, sd("teacher__"), {m: sd(f"{m}_init__") for m in ("kd", "supervised")}

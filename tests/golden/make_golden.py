@@ -10,7 +10,8 @@ What is executed for real (imported from /root/reference, unmodified):
   * ppi_pyg/criterion.py     -> multi-label kd_criterion
   * arxiv_pyg/gnn.py         -> GCN, SAGE, ProjectionGCD, train(), test()
   * arxiv_pyg/gnn_kd_and_aux.py -> train() (KD + aux combination rule)
-  * ppi_pyg/gnn.py           -> GAT and TeacherNet (the frozen teacher the PPI student step runs, :208-209)
+  * ppi_pyg/gnn.py           -> GAT and TeacherNet (the frozen teacher the PPI student step runs, :208-209), GCN,
+                                train() (kd with the teacher forward inside every step, supervised) and test() (micro-F1)
   * mag_pyg/gnn.py           -> RGCNConv (a MessagePassing subclass of the reference's own), RGCN.forward / .inference
 
 What is shimmed (third-party packages that are neither vendored by the reference nor installable
@@ -313,6 +314,55 @@ def make_ppi_teacher_goldens():
     print("ppi_teacher.npz: GAT + TeacherNet forward")
 
 
+class _Batch:
+    """What the PPI loops need from a PyG batch: x / edge_index / y and .to(device)."""
+
+    def __init__(self, x, edge_index, y):
+        self.x, self.edge_index, self.y = x, edge_index, y
+
+    def to(self, device):
+        return self
+
+
+def ppi_toy(seed=31, n_graphs=3, F_in=9, C=7):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(n_graphs):
+        n = 40 + 11 * i
+        src = torch.randint(0, n, (6 * n,), generator=g)
+        dst = torch.randint(0, n, (6 * n,), generator=g)
+        key = torch.unique(torch.cat([src * n + dst, dst * n + src]))       # symmetric, like PPI
+        out.append(_Batch(torch.randn(n, F_in, generator=g), torch.stack([key // n, key % n]),
+                          (torch.rand(n, C, generator=g) < 0.3).float()))
+    return out
+
+
+def make_ppi_train_goldens():
+    """The reference's own ppi_pyg train() / test() loops (kd with the teacher forward inside each step; supervised)."""
+    ref = load_ref("ppi_pyg/gnn.py", "ref_ppi_gnn_train")
+    graphs = ppi_toy()
+    F_in, C = graphs[0].x.shape[1], graphs[0].y.shape[1]
+    out = {}
+    for i, b in enumerate(graphs):
+        out[f"in_x{i}"], out[f"in_ei{i}"], out[f"in_y{i}"] = t2n(b.x), t2n(b.edge_index), t2n(b.y)
+    torch.manual_seed(5)
+    teacher = ref.GAT(F_in, 6, C, 3, 0.0, heads=2)
+    for k, v in teacher.state_dict().items():
+        out["teacher__" + k] = t2n(v)
+    for mode in ("kd", "supervised"):
+        torch.manual_seed(6)
+        model = ref.GCN(F_in, 16, C, 2, 0.0)
+        for k, v in model.state_dict().items():
+            out[f"{mode}_init__" + k] = t2n(v)
+        opt = torch.optim.Adam(model.parameters(), lr=0.005)
+        args = types.SimpleNamespace(training=mode, alpha=0.5, kd_T=1.0)
+        recs = [ref.train(model, teacher if mode == "kd" else None, None, graphs, opt, args, "cpu") for _ in range(3)]
+        out[f"{mode}_epoch_losses"] = np.array(recs, dtype=np.float64)
+        out[f"{mode}_f1"] = np.array(ref.test(model, None, graphs, "cpu"), dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "ppi_train.npz"), **out)
+    print("ppi_train.npz: kd + supervised epochs, micro-F1")
+
+
 def mag_toy(seed=21):
     """Three node types (0 has features, 1 and 2 get embeddings), four relations incl. a reverse pair."""
     g = torch.Generator().manual_seed(seed)
@@ -366,3 +416,4 @@ if __name__ == "__main__":
     make_train_goldens()
     make_ppi_teacher_goldens()
     make_mag_rgcn_goldens()
+    make_ppi_train_goldens()

@@ -21,7 +21,7 @@ import oracle.models as OM
 import oracle.nn as ON
 import oracle.sparse as OS
 import oracle.utils as OU
-from conftest import as_t, mag_rgcn_case
+from conftest import as_t, mag_rgcn_case, ppi_train_case
 from test_oracle_golden import criterion_cases, run_training, noise_driven
 
 pytestmark = pytest.mark.gpu
@@ -1080,3 +1080,22 @@ def test_sharded_batchnorm_pieces_on_simulated_shards():
                                                      _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(total), _lib.ptr(total[C:]),
                                                      1.0 / n, _lib.ptr(dx[cuts[w]:cuts[w + 1]]), C, _lib.stream()), "apply")
     close(dx, dx_ref, rtol=1e-4, atol_scale=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["kd", "supervised"])
+def test_ppi_epochs_match_reference_train_loop_golden(golden_ppi_train, mode):
+    """models.ppi_train_epoch / ppi_test on the GPU against the records of the reference's own ppi_pyg train() / test()."""
+    G = golden_ppi_train
+    graphs, teacher_sd, init = ppi_train_case(G, DEV)
+    F_in, Cn = graphs[0].x.shape[1], graphs[0].y.shape[1]
+    teacher = PM.GAT(F_in, 6, Cn, 3, 0.0, heads=2).to(DEV)
+    teacher.load_state_dict(teacher_sd)
+    teacher.requires_grad_(False)
+    model = PM.GCN(F_in, 16, Cn, 2, 0.0, cached=False).to(DEV)
+    model.load_state_dict(init[mode])
+    opt = torch.optim.Adam(model.parameters(), lr=0.005)
+    hp = dict(alpha=0.5, kd_T=1.0)
+    recs = [PM.ppi_train_epoch(model, teacher if mode == "kd" else None, graphs, opt, mode, hp) for _ in range(3)]
+    np.testing.assert_allclose(np.array(recs), G[f"{mode}_epoch_losses"], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(PM.ppi_test(model, graphs), float(G[f"{mode}_f1"]), atol=5e-3)

@@ -7,7 +7,7 @@ import oracle.criterion as OC
 import oracle.models as OM
 import oracle.sparse as OS
 import oracle.utils as OU
-from conftest import as_t, mag_rgcn_case
+from conftest import as_t, mag_rgcn_case, ppi_train_case
 
 RT, AT = 1e-6, 1e-7
 
@@ -201,3 +201,21 @@ def test_oracle_rgcn_matches_reference_body(golden_mag_rgcn):
     np.testing.assert_allclose(m.out_feat.numpy(), G["forward_out_feat"], rtol=1e-5, atol=1e-6)
     for j, v in inf.items():
         np.testing.assert_allclose(v.numpy(), G[f"inference__{j}"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["kd", "supervised"])
+def test_oracle_ppi_epochs_match_reference_train_loop(golden_ppi_train, mode):
+    """ppi_pyg/gnn.py train() (:185-274; kd = frozen GAT teacher forward inside every step) and test() (:277-288) executed
+    from the reference's own file; the oracle's ppi_train_epoch / ppi_test reproduce the three epoch records and micro-F1."""
+    G = golden_ppi_train
+    graphs, teacher_sd, init = ppi_train_case(G)
+    F_in, Cn = graphs[0].x.shape[1], graphs[0].y.shape[1]
+    teacher = OM.GAT(F_in, 6, Cn, 3, 0.0, heads=2)
+    teacher.load_state_dict(teacher_sd)
+    model = OM.GCN(F_in, 16, Cn, 2, 0.0, cached=False)
+    model.load_state_dict(init[mode])
+    opt = torch.optim.Adam(model.parameters(), lr=0.005)
+    hp = dict(alpha=0.5, kd_T=1.0)
+    recs = [OM.ppi_train_epoch(model, teacher if mode == "kd" else None, graphs, opt, mode, hp) for _ in range(3)]
+    np.testing.assert_allclose(np.array(recs), G[f"{mode}_epoch_losses"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(OM.ppi_test(model, graphs), float(G[f"{mode}_f1"]), atol=2e-3)
