@@ -119,3 +119,39 @@ def mag_like(scale: float = 1.0, seed: int = 0, feats: int = 128):
     d.x = torch.randn(n, feats, generator=g)
     d.adj_t = to_sparse_tensor(ei, n).to_symmetric()
     return d
+
+
+# ------------------------------------------------------------------------------------------------
+# teacher artefacts on disk: what the teacher run leaves for the student run
+# ------------------------------------------------------------------------------------------------
+def teacher_artifact_paths(root: str, expt_name: str, seed: int):
+    """The reference's layout: ``arxiv_dgl/gat.py:245-251`` writes ``features/<expt>/<seed>.pt`` ([N, 750] fp32 hidden
+    features of the last GAT layer) and ``logits/<expt>/<seed>.pt`` ([N, 40] fp32); ``arxiv_pyg/gnn.py:278-279`` reads
+    them back with ``torch.load`` (expt ``gat-3L250x3h``)."""
+    import os
+    return (os.path.join(root, "features", expt_name, f"{seed}.pt"), os.path.join(root, "logits", expt_name, f"{seed}.pt"))
+
+
+def save_teacher_artifacts(root: str, expt_name: str, seed: int, out_feat: torch.Tensor, logits: torch.Tensor) -> None:
+    import os
+    f_path, l_path = teacher_artifact_paths(root, expt_name, seed)
+    for path, t in ((f_path, out_feat), (l_path, logits)):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        torch.save(t.detach().to("cpu", torch.float32).contiguous(), path)
+
+
+def load_teacher_artifacts(root: str, expt_name: str, seed: int, num_nodes: int | None = None, device="cpu"):
+    """(teacher_out_feat, teacher_logits) as ``gnn.py:278-279`` loads them; on a GPU the features come back behind a
+    16-byte-aligned row pitch (``ops.pad_pitch``) so that the fused gather-GEMM of the projection head takes its float4 path."""
+    f_path, l_path = teacher_artifact_paths(root, expt_name, seed)
+    feat = torch.load(f_path, map_location="cpu")
+    logits = torch.load(l_path, map_location="cpu")
+    if feat.dim() != 2 or logits.dim() != 2 or feat.shape[0] != logits.shape[0]:
+        raise ValueError(f"teacher artefacts disagree: features {tuple(feat.shape)}, logits {tuple(logits.shape)}")
+    if num_nodes is not None and feat.shape[0] != num_nodes:
+        raise ValueError(f"teacher artefacts are for {feat.shape[0]} nodes, the graph has {num_nodes}")
+    feat, logits = feat.to(device, torch.float32), logits.to(device, torch.float32)
+    if feat.is_cuda:
+        from .ops import pad_pitch
+        feat = pad_pitch(feat)
+    return feat, logits

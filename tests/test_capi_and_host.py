@@ -290,3 +290,18 @@ def test_integration_md_ctypes_snippet_matches_the_header():
     assert [ctypes.sizeof(a) for a in shown] == [ctypes.sizeof(a) for a in table]
     call = block[block.index("rc = lib.egnn_spmm_csr_f32("):block.index("assert rc == 0")]
     assert call.count(",") + 1 == len(table), "the example call passes a different number of arguments"
+
+
+def test_teacher_artifact_round_trip(tmp_path):
+    """The on-disk hand-over between teacher and student runs (arxiv_dgl/gat.py:245-251 -> arxiv_pyg/gnn.py:278-279):
+    plain torch.save tensors under features/<expt>/<seed>.pt and logits/<expt>/<seed>.pt."""
+    g = torch.Generator().manual_seed(0)
+    feat, logits = torch.relu(torch.randn(37, 750, generator=g)), torch.randn(37, 40, generator=g)
+    D.save_teacher_artifacts(str(tmp_path), "gat-3L250x3h", 3, feat, logits)
+    f_path, l_path = D.teacher_artifact_paths(str(tmp_path), "gat-3L250x3h", 3)
+    assert f_path.endswith(os.path.join("features", "gat-3L250x3h", "3.pt")) and os.path.exists(l_path)
+    assert torch.equal(torch.load(f_path), feat)                      # exactly what gnn.py:278 would read
+    f2, l2 = D.load_teacher_artifacts(str(tmp_path), "gat-3L250x3h", 3, num_nodes=37)
+    assert torch.equal(f2, feat) and torch.equal(l2, logits)
+    with pytest.raises(ValueError):
+        D.load_teacher_artifacts(str(tmp_path), "gat-3L250x3h", 3, num_nodes=38)
