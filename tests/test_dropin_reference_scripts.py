@@ -91,3 +91,89 @@ def test_reference_train_loop_runs_unchanged_on_the_new_operators():
     out, accs = ref.test(model, data, split_idx, Ev())
     assert all(np.isfinite(l0)) and all(np.isfinite(l1)) and l1[0] < l0[0], (l0, l1)
     assert out.shape == (d.num_nodes, d.num_classes) and all(0 <= a <= 1 for a in accs)
+
+
+# ------------------------------------------------------------------------------------------------
+# CPU variant: the reference's own train()/test() on top of the drop-in HOST layer, kernels replaced by oracle stand-ins
+# ------------------------------------------------------------------------------------------------
+def _host_layer_worker(q, gnn, mode):
+    """Runs in a spawned process: the ops monkeypatches must not leak into the other tests of this session."""
+    import torch.nn.functional as F
+    sys.path.insert(0, ROOT)
+    import efficient_gnns_amd as E
+    import efficient_gnns_amd.data as D
+    import efficient_gnns_amd.nn as PN
+    import efficient_gnns_amd.ops as ops
+    import oracle.sparse as OS
+
+    def to_oracle(adj):
+        rowptr, col, val = adj.csr()
+        return OS.SparseTensor(rowptr=rowptr, col=col, value=val, sparse_sizes=adj.sparse_sizes())
+
+    def gcn_norm(adj):
+        g = OS.gcn_norm_sparse(to_oracle(adj))
+        return E.SparseTensor(rowptr=g.csr()[0], col=g.csr()[1], value=g.csr()[2], sparse_sizes=g.sparse_sizes())
+    PN.gcn_norm = gcn_norm
+    ops.spmm = lambda adj, x, reduce="sum", bias=None: OS.matmul(to_oracle(adj), x, reduce) + (0 if bias is None else bias)
+    ops.matmul = lambda x, w, bias=None: x @ w if bias is None else x @ w + bias
+    ops.linear = lambda x, w, b=None: F.linear(x, w, b)
+    ops.take_rows = lambda x, idx: x[idx]
+    ops.cross_entropy = lambda logits, labels: F.cross_entropy(logits, labels)
+    ops.gather_normalize = lambda x, idx=None, eps=1e-12: F.normalize(x if idx is None else x[idx], p=2, dim=-1)
+    ops.nce_unit = lambda f, t, tau: F.cross_entropy(f @ t.t() / tau, torch.arange(f.shape[0]))
+    ops.ce_and_kd = lambda logits, labels, teacher, T: (
+        F.cross_entropy(logits, labels), F.kl_div(F.log_softmax(logits / T, dim=1), F.softmax(teacher / T, dim=1), log_target=False))
+
+    ref = _load_reference_gnn()
+    d = D.arxiv_like(scale=0.004, seed=2)
+    data = types.SimpleNamespace(x=d.x, y=d.y, adj_t=d.adj_t)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = (ref.GCN if gnn == "gcn" else ref.SAGE)(d.num_features, 32, d.num_classes, 3, 0.0)
+    sp = torch.nn.Sequential(torch.nn.Linear(32, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU())
+    tp = torch.nn.Sequential(torch.nn.Linear(750, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU())
+    init = {k: v.clone() for m, pre in ((model, "m."), (sp, "s."), (tp, "t.")) for k, v in ((pre + kk, vv) for kk, vv in m.state_dict().items())}
+    opt = torch.optim.Adam([{"params": model.parameters()}, {"params": sp.parameters()}, {"params": tp.parameters()}], lr=0.01)
+    args = argparse.Namespace(training=mode, alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=96, kernel="rbf")
+
+    class Ev:
+        def eval(self, dd):
+            return {"acc": float((dd["y_true"].cpu().numpy() == dd["y_pred"].cpu().numpy()).mean())}
+    out0, accs0 = ref.test(model, data, d.split_idx, Ev())
+    losses = [ref.train(model, data, d.split_idx["train"], opt, args, d.teacher_out_feat, d.teacher_logits, sp, tp, None) for _ in range(3)]
+    q.put((losses, out0.numpy(), list(accs0), {k: v.numpy() for k, v in init.items()}))
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="the reference tree is only present in the build container")
+@pytest.mark.parametrize("gnn,mode", [("gcn", "nce"), ("sage", "kd"), ("sage", "nce"), ("gcn", "supervised")])
+def test_reference_train_loop_drives_the_host_layer_on_cpu(gnn, mode):
+    """arxiv_pyg/gnn.py's own GCN / train() / test(), imported unchanged through efficient-gnns_amd/dropin, running on the
+    package's host layer (GCNConv, SparseTensor, criterion) with the kernels swapped for oracle stand-ins in a child
+    process: the losses of three steps and the initial eval equal the oracle's train_step / evaluate."""
+    import torch.multiprocessing as mp
+    import efficient_gnns_amd.data as D
+    import oracle.models as OM
+    import oracle.sparse as OS
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    p = ctx.Process(target=_host_layer_worker, args=(q, gnn, mode))
+    p.start()
+    losses, out0, accs0, init = q.get()
+    p.join(300)
+    assert p.exitcode == 0
+    d = D.arxiv_like(scale=0.004, seed=2)
+    rowptr, col, _ = d.adj_t.csr()
+    oadj = OS.SparseTensor(rowptr=rowptr, col=col, sparse_sizes=d.adj_t.sparse_sizes())
+    om = (OM.GCN if gnn == "gcn" else OM.SAGE)(d.num_features, 32, d.num_classes, 3, 0.0)
+    osp, otp = OM.make_projection(32, 16), OM.make_projection(750, 16)
+    for m, pre in ((om, "m."), (osp, "s."), (otp, "t.")):
+        m.load_state_dict({k[len(pre):]: torch.from_numpy(v) for k, v in init.items() if k.startswith(pre)})
+    np.random.seed(0)   # the child seeded NumPy before building its modules; the draws of the three steps follow
+    oopt = torch.optim.Adam([{"params": om.parameters()}, {"params": osp.parameters()}, {"params": otp.parameters()}], lr=0.01)
+    hp = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=96, kernel="rbf")
+    ref_out0, ref_accs0 = OM.evaluate(om, d.x, oadj, d.y, d.split_idx)
+    ref_losses = [OM.train_step(om, d.x, oadj, d.y, d.split_idx["train"], oopt, mode, hp, d.teacher_out_feat, d.teacher_logits, osp, otp)
+                  for _ in range(3)]
+    np.testing.assert_allclose(out0, ref_out0.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(accs0, list(ref_accs0), atol=1e-9)
+    np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=1e-5, atol=1e-7)
