@@ -445,10 +445,11 @@ def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: di
     loss.backward()
     fg.all_reduce(group)
     optimizer.step()
-    rep = torch.stack([loss_cls.detach(), loss_aux.detach() if mode != "nce" else zero])
-    dist.all_reduce(rep, group=group)
-    loss_cls_g = float(rep[0])
-    loss_aux_g = float(loss_aux.detach()) if mode == "nce" else float(rep[1])
+    rep = torch.stack([loss_cls.detach(), loss_aux.detach() if mode != "nce" else zero, loss_aux.detach()])
+    dist.all_reduce(rep[:2], group=group)                     # loss_aux of nce is already global: not reduced
+    vals = rep.tolist()                                       # one device->host read per step
+    loss_cls_g = vals[0]
+    loss_aux_g = vals[2] if mode == "nce" else vals[1]
     if mode == "kd":
         loss_g = loss_aux_g * (hp["alpha"] * hp["kd_T"] ** 2) + loss_cls_g * (1 - hp["alpha"])
     elif mode == "nce":
@@ -465,7 +466,8 @@ def sharded_evaluate(model, prob: ShardedProblem):
     y_pred = out.argmax(dim=-1, keepdim=True)
     correct = torch.stack([(prob.y[prob.split_local[k]] == y_pred[prob.split_local[k]]).sum() for k in ("train", "valid", "test")]).float()
     dist.all_reduce(correct, group=prob.group)
-    accs = tuple(float(correct[i]) / max(1, prob.split_sizes[k]) for i, k in enumerate(("train", "valid", "test")))
+    hits = correct.tolist()                                   # one device->host read for the three counts
+    accs = tuple(hits[i] / max(1, prob.split_sizes[k]) for i, k in enumerate(("train", "valid", "test")))
     return out, accs
 
 
