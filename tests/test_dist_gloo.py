@@ -71,7 +71,8 @@ def _make_data(seed=3):
 HP = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=96, kernel="rbf")
 
 
-def _reference_run(gnn, mode, steps=3):
+def _reference_run(gnn, mode, steps=3, hp=None):
+    HP = dict(globals()["HP"], **(hp or {}))
     import oracle.models as OM
     d = _make_data()
     torch.manual_seed(0)
@@ -89,7 +90,8 @@ def _reference_run(gnn, mode, steps=3):
     return losses, logits, accs
 
 
-def _worker(rank, world, port, gnn, mode, q):
+def _worker(rank, world, port, gnn, mode, q, hp=None):
+    HP = dict(globals()["HP"], **(hp or {}))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -121,13 +123,16 @@ def _worker(rank, world, port, gnn, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("gnn,mode,world", [("gcn", "kd", 2), ("gcn", "nce", 2), ("sage", "nce", 2), ("sage", "supervised", 2),
-                                            ("gcn", "nce", 3)])   # 3 ranks: uneven node ranges and sample counts
-def test_sharded_training_matches_single_process_oracle(gnn, mode, world):
+@pytest.mark.parametrize("gnn,mode,world,max_samples", [
+    ("gcn", "kd", 2, 96), ("gcn", "nce", 2, 96), ("sage", "nce", 2, 96), ("sage", "supervised", 2, 96),
+    ("gcn", "nce", 3, 96),     # 3 ranks: uneven node ranges and sample counts
+    ("gcn", "nce", 4, 5)])     # 5 samples over 4 ranks: some ranks own no sampled row (empty row block, collectives still run)
+def test_sharded_training_matches_single_process_oracle(gnn, mode, world, max_samples):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    port = 29500 + (os.getpid() + hash((gnn, mode, world))) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, world, port, gnn, mode, q)) for r in range(world)]
+    hp = dict(max_samples=max_samples)
+    port = 29500 + (os.getpid() + hash((gnn, mode, world, max_samples))) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, gnn, mode, q, hp)) for r in range(world)]
     for p in procs:
         p.start()
     losses, logits, accs, n_halo = q.get()  # read before join: the payload is larger than the pipe buffer
@@ -135,7 +140,7 @@ def test_sharded_training_matches_single_process_oracle(gnn, mode, world):
         p.join(300)
         assert p.exitcode == 0, f"rank exited with {p.exitcode}"
 
-    ref_losses, ref_logits, ref_accs = _reference_run(gnn, mode)
+    ref_losses, ref_logits, ref_accs = _reference_run(gnn, mode, hp=hp)
     np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-4, atol=1e-6)
     # eval is compared at the initial state: after Adam steps the pre-BatchNorm biases are rounding-noise driven
     # (tests/golden/make_golden.py) and eval-mode logits stop being reproducible across implementations
