@@ -35,8 +35,8 @@ SIGNATURES = {
     "egnn_gemm_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _p]),
     "egnn_gemm_rows_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _p, _i64, _p, _p, _p, _i64, _i32, _p, _sz, _p]),
     "egnn_ce_kd_ws_floats": (_sz, [_i64]),
-    "egnn_ce_kd_fwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _f32, _p, _p, _p]),
-    "egnn_ce_kd_bwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _f32, _p, _p, _p, _i64, _p]),
+    "egnn_ce_kd_fwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _f32, _p, _p, _p]),
+    "egnn_ce_kd_bwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _p, _i64, _p]),
     "egnn_gather_normalize_rows_f32": (_i32, [_p, _i64, _p, _i64, _i64, _f32, _p, _i64, _p, _p]),
     "egnn_normalize_rows_bwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _f32, _p, _i64, _i32, _p]),
     "egnn_nce_ws_floats": (_sz, [_i64]),
@@ -89,7 +89,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.egnn_abi_version() != 2:
+    if lib.egnn_abi_version() != 3:
         raise HipExtensionError("libegnn_hip.so ABI version mismatch")
     _lib = lib
     return lib

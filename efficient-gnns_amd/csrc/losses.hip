@@ -20,20 +20,26 @@ __device__ __forceinline__ float row_lse(const float* p, int64_t C, float s, int
   return m + logf(z);
 }
 
+// Row i of the loss reads logits / teacher row r = rows ? rows[i] : i and label labels[r]: with a row list the
+// `out[train_idx]`, `y[train_idx]`, `teacher_logits[train_idx]` gathers of train() (gnn.py:107-116) happen in the operand
+// loads.  A label outside [0, C) is IGNORED (F.cross_entropy's ignore_index = -100 semantics: no loss, no gradient, not
+// counted in the mean) instead of being used as an address.
 __global__ __launch_bounds__(256) void ce_kd_fwd_kernel(const float* __restrict__ logits, int64_t ldl,
                                                         const float* __restrict__ teacher, int64_t ldt,
-                                                        const int64_t* __restrict__ labels, int64_t n, int64_t C,
-                                                        float T, float* __restrict__ partials) {
-  __shared__ float s_ce[kRowsPerBlock], s_kd[kRowsPerBlock];
+                                                        const int64_t* __restrict__ labels, const int64_t* __restrict__ rows,
+                                                        int64_t n, int64_t C, float T, float* __restrict__ partials) {
+  __shared__ float s_ce[kRowsPerBlock], s_kd[kRowsPerBlock], s_nv[kRowsPerBlock];
   const int lane = egnn_lane();
   const int wave = egnn_wave_id();
   const float invT = 1.f / T;
-  float ce = 0.f, kd = 0.f;  // lane 0 of each wave carries the wave's running sums
-  for (int64_t row = blockIdx.x * (int64_t)kRowsPerBlock + wave; row < n; row += (int64_t)gridDim.x * kRowsPerBlock) {
+  float ce = 0.f, kd = 0.f, nv = 0.f;  // lane 0 of each wave carries the wave's running sums
+  for (int64_t i = blockIdx.x * (int64_t)kRowsPerBlock + wave; i < n; i += (int64_t)gridDim.x * kRowsPerBlock) {
+    const int64_t row = rows ? rows[i] : i;
     const float* lp = logits + row * ldl;
     const float lse1 = row_lse(lp, C, 1.f, lane);
     const int64_t y = labels[row];
-    if (lane == 0) ce += lse1 - lp[y];
+    const bool valid = y >= 0 && y < C;
+    if (lane == 0 && valid) { ce += lse1 - lp[y]; nv += 1.f; }
     if (teacher != nullptr) {
       const float* tp = teacher + row * ldt;
       const float lseq = row_lse(lp, C, invT, lane);
@@ -49,47 +55,54 @@ __global__ __launch_bounds__(256) void ce_kd_fwd_kernel(const float* __restrict_
       if (lane == 0) kd += acc;
     }
   }
-  if (lane == 0) { s_ce[wave] = ce; s_kd[wave] = kd; }
+  if (lane == 0) { s_ce[wave] = ce; s_kd[wave] = kd; s_nv[wave] = nv; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float a = 0.f, b = 0.f;
-    for (int w = 0; w < kRowsPerBlock; ++w) { a += s_ce[w]; b += s_kd[w]; }
+    float a = 0.f, b = 0.f, c = 0.f;
+    for (int w = 0; w < kRowsPerBlock; ++w) { a += s_ce[w]; b += s_kd[w]; c += s_nv[w]; }
     partials[blockIdx.x] = a;
     partials[kMaxBlocks + blockIdx.x] = b;
+    partials[2 * kMaxBlocks + blockIdx.x] = c;
   }
 }
 
 __global__ __launch_bounds__(256) void ce_kd_finalize_kernel(const float* __restrict__ partials, int nblocks, int64_t n,
-                                                             int64_t C, int has_teacher, float* __restrict__ out2) {
-  __shared__ float s[2][256];
-  float a = 0.f, b = 0.f;
-  for (int i = threadIdx.x; i < nblocks; i += 256) { a += partials[i]; b += partials[kMaxBlocks + i]; }
-  s[0][threadIdx.x] = a; s[1][threadIdx.x] = b;
+                                                             int64_t C, int has_teacher, float* __restrict__ out3) {
+  __shared__ float s[3][256];
+  float a = 0.f, b = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) { a += partials[i]; b += partials[kMaxBlocks + i]; c += partials[2 * kMaxBlocks + i]; }
+  s[0][threadIdx.x] = a; s[1][threadIdx.x] = b; s[2][threadIdx.x] = c;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) { s[0][threadIdx.x] += s[0][threadIdx.x + o]; s[1][threadIdx.x] += s[1][threadIdx.x + o]; }
+    if ((int)threadIdx.x < o) {
+      s[0][threadIdx.x] += s[0][threadIdx.x + o]; s[1][threadIdx.x] += s[1][threadIdx.x + o]; s[2][threadIdx.x] += s[2][threadIdx.x + o];
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    out2[0] = s[0][0] / (float)n;
-    if (has_teacher) out2[1] = s[1][0] / ((float)n * (float)C);
+    out3[0] = s[0][0] / s[2][0];   // mean over the rows whose label is valid (all of them in the reference's use); 0/0 = nan like torch
+    out3[1] = has_teacher ? s[1][0] / ((float)n * (float)C) : 0.f;
+    out3[2] = s[2][0];
   }
 }
 
 __global__ __launch_bounds__(256) void ce_kd_bwd_kernel(const float* __restrict__ logits, int64_t ldl,
                                                         const float* __restrict__ teacher, int64_t ldt,
-                                                        const int64_t* __restrict__ labels, int64_t n, int64_t C, float T,
+                                                        const int64_t* __restrict__ labels, const int64_t* __restrict__ rows,
+                                                        int64_t n, int64_t C, float T, const float* __restrict__ out3,
                                                         const float* __restrict__ g_cls, const float* __restrict__ g_kd,
                                                         float* __restrict__ dl, int64_t ldd) {
   const int lane = egnn_lane();
   const int wave = egnn_wave_id();
   const float invT = 1.f / T;
-  const float gc = g_cls ? g_cls[0] / (float)n : 0.f;
+  const float gc = g_cls ? g_cls[0] / out3[2] : 0.f;
   const float gk = (g_kd && teacher) ? g_kd[0] * invT / ((float)n * (float)C) : 0.f;
-  for (int64_t row = blockIdx.x * (int64_t)kRowsPerBlock + wave; row < n; row += (int64_t)gridDim.x * kRowsPerBlock) {
+  for (int64_t i = blockIdx.x * (int64_t)kRowsPerBlock + wave; i < n; i += (int64_t)gridDim.x * kRowsPerBlock) {
+    const int64_t row = rows ? rows[i] : i;
     const float* lp = logits + row * ldl;
     const float lse1 = row_lse(lp, C, 1.f, lane);
     const int64_t y = labels[row];
+    const float gcr = (y >= 0 && y < C) ? gc : 0.f;
     float lseq = 0.f, lsep = 0.f;
     const float* tp = nullptr;
     if (gk != 0.f) {
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(256) void ce_kd_bwd_kernel(const float* __restrict_
       lsep = row_lse(tp, C, invT, lane);
     }
     for (int64_t c = lane; c < C; c += 64) {
-      float g = gc * (expf(lp[c] - lse1) - (c == y ? 1.f : 0.f));
+      float g = gcr * (expf(lp[c] - lse1) - (c == y ? 1.f : 0.f));
       if (gk != 0.f) g += gk * (expf(lp[c] * invT - lseq) - expf(tp[c] * invT - lsep));
       dl[row * ldd + c] = g;
     }
@@ -148,29 +161,39 @@ __global__ __launch_bounds__(256) void normalize_bwd_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" size_t egnn_ce_kd_ws_floats(int64_t) { return 2 * (size_t)kMaxBlocks; }
+extern "C" size_t egnn_ce_kd_ws_floats(int64_t) { return 3 * (size_t)kMaxBlocks; }
 
 extern "C" int egnn_ce_kd_fwd_f32(const float* logits, int64_t ld_logits, const float* teacher, int64_t ld_teacher,
-                                  const int64_t* labels, int64_t n, int64_t C, float T, float* out2, float* partials,
-                                  void* stream) {
-  EGNN_CHECK_ARG(n > 0 && C > 0 && logits && labels && out2 && partials && ld_logits >= C && T > 0.f);
+                                  const int64_t* labels, const int64_t* rows, int64_t n, int64_t C, float T, float* out3,
+                                  float* partials, void* stream) {
+  EGNN_CHECK_ARG(n > 0 && C > 0 && logits && labels && out3 && partials && ld_logits >= C && T > 0.f);
   EGNN_CHECK_ARG(teacher == nullptr || ld_teacher >= C);
   const int64_t want = (n + kRowsPerBlock - 1) / kRowsPerBlock;
   const int nblocks = (int)(want < kMaxBlocks ? want : kMaxBlocks);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ce_kd_fwd_kernel, dim3(nblocks), dim3(256), 0, st, logits, ld_logits, teacher, ld_teacher, labels, n, C, T, partials);
-  hipLaunchKernelGGL(ce_kd_finalize_kernel, dim3(1), dim3(256), 0, st, partials, nblocks, n, C, teacher != nullptr, out2);
+  hipLaunchKernelGGL(ce_kd_fwd_kernel, dim3(nblocks), dim3(256), 0, st, logits, ld_logits, teacher, ld_teacher, labels, rows, n, C, T, partials);
+  hipLaunchKernelGGL(ce_kd_finalize_kernel, dim3(1), dim3(256), 0, st, partials, nblocks, n, C, teacher != nullptr, out3);
   return egnn_launch_status();
 }
 
 extern "C" int egnn_ce_kd_bwd_f32(const float* logits, int64_t ld_logits, const float* teacher, int64_t ld_teacher,
-                                  const int64_t* labels, int64_t n, int64_t C, float T, const float* g_cls,
-                                  const float* g_kd, float* dlogits, int64_t ld_dlogits, void* stream) {
-  EGNN_CHECK_ARG(n > 0 && C > 0 && logits && labels && dlogits && ld_logits >= C && ld_dlogits >= C && T > 0.f);
+                                  const int64_t* labels, const int64_t* rows, int64_t n_total_rows, int64_t n, int64_t C, float T,
+                                  const float* out3, const float* g_cls, const float* g_kd, float* dlogits, int64_t ld_dlogits,
+                                  void* stream) {
+  EGNN_CHECK_ARG(n > 0 && C > 0 && logits && labels && dlogits && out3 && ld_logits >= C && ld_dlogits >= C && T > 0.f);
+  EGNN_CHECK_ARG(rows == nullptr || n_total_rows >= n);
+  hipStream_t st = (hipStream_t)stream;
+  if (rows) {   // rows outside the list receive no gradient: clear the whole [n_total_rows, C] block first
+    if (ld_dlogits == C) {
+      if (hipMemsetAsync(dlogits, 0, (size_t)n_total_rows * (size_t)C * sizeof(float), st) != hipSuccess) return EGNN_ELAUNCH;
+    } else if (hipMemset2DAsync(dlogits, (size_t)ld_dlogits * sizeof(float), 0, (size_t)C * sizeof(float), (size_t)n_total_rows, st) != hipSuccess) {
+      return EGNN_ELAUNCH;
+    }
+  }
   const int64_t want = (n + kRowsPerBlock - 1) / kRowsPerBlock;
   const int nblocks = (int)(want < 4096 ? want : 4096);
-  hipLaunchKernelGGL(ce_kd_bwd_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, logits, ld_logits, teacher, ld_teacher,
-                     labels, n, C, T, g_cls, g_kd, dlogits, ld_dlogits);
+  hipLaunchKernelGGL(ce_kd_bwd_kernel, dim3(nblocks), dim3(256), 0, st, logits, ld_logits, teacher, ld_teacher,
+                     labels, rows, n, C, T, out3, g_cls, g_kd, dlogits, ld_dlogits);
   return egnn_launch_status();
 }
 

@@ -144,13 +144,13 @@ class ShardedAdj:
         from the peers ONCE and kept next to the local rows, as a partitioned graph store keeps the features of a
         partition's halo nodes.  Every later aggregation of exactly this tensor skips the exchange (2 of the 8 per
         epoch, 22 % of the halo volume of the GCN run).  Collective: all ranks must register."""
-        self._static = (x_local, _HaloExchange.apply(x_local.detach(), self))
+        self._static = (x_local, _HaloExchange.apply(x_local.detach(), self), x_local._version)
         if self._gcn is not None:
             self._gcn.register_static(x_local)
 
     def aggregate(self, x_local: Tensor, reduce: str, valueless: bool = False) -> Tensor:
         st = getattr(self, "_static", None)
-        if st is not None and st[0] is x_local and not x_local.requires_grad and x_local._version == st[0]._version:
+        if st is not None and st[0] is x_local and not x_local.requires_grad and x_local._version == st[2]:   # version AT registration
             x_ext = st[1]
         else:
             x_ext = _HaloExchange.apply(x_local, self)
@@ -405,8 +405,11 @@ def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: di
     frac = out.shape[0] / prob.n_train_global               # local mean -> contribution to the global mean
     dev = out.device
     zero = torch.zeros((), dtype=torch.float32, device=dev)
+    # A rank that owns no train row still has to run the SAME backward collectives as its peers (halo exchange and
+    # SyncBN reductions of every layer): its loss terms are exact zeros that stay attached to the model's graph.
+    attached_zero = out.sum() * 0.0
     if mode == "supervised":
-        loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else zero
+        loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else attached_zero
         loss_aux = zero
         loss = loss_cls
     elif mode == "kd":
@@ -414,10 +417,10 @@ def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: di
             lc, lk = ops.ce_and_kd(out, labels, prob.teacher_logits[prob.train_local], hp["kd_T"])
             loss_cls, loss_aux = lc * frac, lk * frac
         else:
-            loss_cls = loss_aux = zero
+            loss_cls = loss_aux = attached_zero
         loss = loss_aux * (hp["alpha"] * hp["kd_T"] ** 2) + loss_cls * (1 - hp["alpha"])
     elif mode == "nce":
-        loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else zero
+        loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else attached_zero
         if hasattr(student_proj, "forward_rows") and prob.x.is_cuda:
             f = student_proj.forward_rows(model.out_feat, prob.train_local)
             t = teacher_proj.forward_rows(prob.teacher_out_feat, prob.train_local)

@@ -322,47 +322,65 @@ def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None) -> Tensor:
 # cross entropy (+ logit KD)
 # ------------------------------------------------------------------------------------------------
 class _CeKd(torch.autograd.Function):
+    """(mean CE, mean KD) of the rows ``rows`` (None: all) of logits / teacher with labels[rows] (fused row gathers)."""
+
     @staticmethod
-    def forward(ctx, logits, labels, teacher, T):
-        _lib.require_gpu(logits, labels, teacher)
+    def forward(ctx, logits, labels, teacher, T, rows=None):
+        _lib.require_gpu(logits, labels, teacher, rows)
         logits = _rowmajor(logits)
         teacher = None if teacher is None else _rowmajor(teacher)
+        # the kernels index with the labels: PyTorch's own checks (class-index targets are int64 [n]) are kept on the host;
+        # out-of-range values (incl. ignore_index = -100) are ignored inside the kernel, never used as an address
+        if labels.dtype != torch.int64:
+            raise TypeError(f"cross_entropy: expected int64 class-index labels, got {labels.dtype} "
+                            "(multi-label float targets are the PPI path: criterion.ppi_kd_criterion)")
+        if labels.dim() != 1 or labels.shape[0] != logits.shape[0]:
+            raise ValueError(f"cross_entropy: labels must have shape ({logits.shape[0]},), got {tuple(labels.shape)}")
+        if teacher is not None and teacher.shape != logits.shape:
+            raise ValueError(f"kd: teacher logits {tuple(teacher.shape)} do not match the student's {tuple(logits.shape)}")
         labels = labels.contiguous()
-        n, C = logits.shape
+        if rows is not None:
+            if rows.dtype != torch.int64 or rows.dim() != 1:
+                raise TypeError("cross_entropy: `rows` must be a 1-D int64 index tensor")
+            rows = rows.contiguous()
+        n = logits.shape[0] if rows is None else rows.numel()
+        C = logits.shape[1]
         lib = _lib.load()
-        out = torch.zeros(2, dtype=torch.float32, device=logits.device)
+        out = torch.empty(3, dtype=torch.float32, device=logits.device)
         ws = torch.empty(lib.egnn_ce_kd_ws_floats(n), dtype=torch.float32, device=logits.device)
         rc = lib.egnn_ce_kd_fwd_f32(_lib.ptr(logits), logits.stride(0), _lib.ptr(teacher), 0 if teacher is None else teacher.stride(0),
-                                    _lib.ptr(labels), n, C, float(T), _lib.ptr(out), _lib.ptr(ws), _lib.stream())
+                                    _lib.ptr(labels), _lib.ptr(rows), n, C, float(T), _lib.ptr(out), _lib.ptr(ws), _lib.stream())
         _lib.check(rc, "egnn_ce_kd_fwd_f32")
-        ctx.save_for_backward(logits, labels, *([] if teacher is None else [teacher]))
-        ctx.T = float(T)
+        ctx.save_for_backward(logits, labels, out, *([] if teacher is None else [teacher]), *([] if rows is None else [rows]))
+        ctx.T, ctx.has_teacher, ctx.has_rows, ctx.n = float(T), teacher is not None, rows is not None, n
         return out[0], out[1]
 
     @staticmethod
     def backward(ctx, g_cls, g_kd):
-        saved = ctx.saved_tensors
-        logits, labels = saved[0], saved[1]
-        teacher = saved[2] if len(saved) > 2 else None
-        n, C = logits.shape
+        saved = list(ctx.saved_tensors)
+        logits, labels, out = saved[:3]
+        rest = saved[3:]
+        teacher = rest.pop(0) if ctx.has_teacher else None
+        rows = rest.pop(0) if ctx.has_rows else None
+        n_total, C = logits.shape
         dl = torch.empty_like(logits)
         g_cls = None if g_cls is None else g_cls.contiguous().to(torch.float32)
         g_kd = None if g_kd is None else g_kd.contiguous().to(torch.float32)
         rc = _lib.load().egnn_ce_kd_bwd_f32(_lib.ptr(logits), logits.stride(0), _lib.ptr(teacher),
-                                            0 if teacher is None else teacher.stride(0), _lib.ptr(labels), n, C, ctx.T,
-                                            _lib.ptr(g_cls), _lib.ptr(g_kd), _lib.ptr(dl), dl.stride(0), _lib.stream())
+                                            0 if teacher is None else teacher.stride(0), _lib.ptr(labels), _lib.ptr(rows), n_total, ctx.n,
+                                            C, ctx.T, _lib.ptr(out), _lib.ptr(g_cls), _lib.ptr(g_kd), _lib.ptr(dl), dl.stride(0), _lib.stream())
         _lib.check(rc, "egnn_ce_kd_bwd_f32")
-        return dl, None, None, None
+        return dl, None, None, None, None
 
 
-def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
-    """mean CE (F.cross_entropy) on the fused kernel."""
-    return _CeKd.apply(logits, labels, None, 1.0)[0]
+def cross_entropy(logits: Tensor, labels: Tensor, rows: Tensor | None = None) -> Tensor:
+    """mean CE (F.cross_entropy) on the fused kernel; ``rows``: evaluate logits[rows] against labels[rows] without the copies."""
+    return _CeKd.apply(logits, labels, None, 1.0, rows)[0]
 
 
-def ce_and_kd(logits: Tensor, labels: Tensor, teacher_logits: Tensor, T: float):
-    """(mean CE, F.kl_div(log_softmax(logits/T), softmax(teacher/T)) with reduction='mean')."""
-    return _CeKd.apply(logits, labels, teacher_logits, T)
+def ce_and_kd(logits: Tensor, labels: Tensor, teacher_logits: Tensor, T: float, rows: Tensor | None = None):
+    """(mean CE, F.kl_div(log_softmax(logits/T), softmax(teacher/T)) with reduction='mean'); ``rows`` as in cross_entropy."""
+    return _CeKd.apply(logits, labels, teacher_logits, T, rows)
 
 
 # ------------------------------------------------------------------------------------------------

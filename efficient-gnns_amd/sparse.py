@@ -81,6 +81,9 @@ class SparseTensor:
             n = int(col.max()) + 1 if col.numel() else 0
             sparse_sizes = (m, n)
         self._sizes = (int(sparse_sizes[0]), int(sparse_sizes[1]))
+        # columns ascending within every row?  True on the sorting paths below, None (unknown) for caller-provided CSR
+        # arrays: gcn_norm's fill kernel needs it and checks / sorts once when it is not known
+        self._cols_sorted = True if (row is not None) else None
         if row is not None and not is_sorted:
             perm = torch.argsort(row * self._sizes[1] + col, stable=True)
             row, col = row[perm], col[perm]
@@ -130,6 +133,7 @@ class SparseTensor:
         out = SparseTensor(rowptr=self._rowptr, col=self._col, value=value, sparse_sizes=self._sizes)
         out._row_cache = self._row_cache
         out._struct = self._struct
+        out._cols_sorted = self._cols_sorted
         return out
 
     def fill_value(self, fill: float, dtype=torch.float32) -> "SparseTensor":
@@ -141,6 +145,7 @@ class SparseTensor:
             return self
         out = SparseTensor(rowptr=self._rowptr.to(device), col=self._col.to(device),
                            value=None if self._value is None else self._value.to(device), sparse_sizes=self._sizes)
+        out._cols_sorted = self._cols_sorted
         return out
 
     def cuda(self):
@@ -158,7 +163,9 @@ class SparseTensor:
         row, col = self._row(), self._col
         if col.is_cuda and 2 * col.numel() < 2 ** 31 - 1:
             rowptr, col_s = csr_from_coo(row, col, n, symmetric=True)
-            return SparseTensor(rowptr=rowptr, col=col_s, sparse_sizes=(n, n))
+            out = SparseTensor(rowptr=rowptr, col=col_s, sparse_sizes=(n, n))
+            out._cols_sorted = True
+            return out
         key = torch.unique(torch.cat([row * n + col, col * n + row]))
         return SparseTensor(row=torch.div(key, n, rounding_mode="floor"), col=key % n, sparse_sizes=(n, n), is_sorted=True)
 
@@ -321,6 +328,16 @@ def gcn_norm(adj_t: SparseTensor) -> SparseTensor:
     n = adj_t.sparse_size(0)
     if adj_t.sparse_size(1) != n:
         raise ValueError("gcn_norm needs a square adjacency")
+    if adj_t._cols_sorted is None:
+        # caller-provided CSR arrays: the fill kernel places entries by (col < row | col > row) rank and needs ascending
+        # columns per row (torch-sparse's own invariant).  One check per structure (one host read), one sort if violated.
+        row = adj_t._row()
+        key = row * n + col
+        if key.numel() > 1 and bool((key[1:] < key[:-1]).any()):
+            order = torch.argsort(key, stable=True)
+            adj_t = SparseTensor(rowptr=rowptr, col=col[order].contiguous(), sparse_sizes=(n, n))
+            rowptr, col, _ = adj_t.csr()
+        adj_t._cols_sorted = True
     lib, st = _lib.load(), _lib.stream()
     dev = col.device
     counts = torch.empty(n, dtype=torch.int64, device=dev)
@@ -336,4 +353,6 @@ def gcn_norm(adj_t: SparseTensor) -> SparseTensor:
                                           _lib.ptr(dinv), st), "egnn_gcn_norm_fill_i64")
     _lib.check(lib.egnn_gcn_norm_values_i64(_lib.ptr(rowptr_out), _lib.ptr(col_out), n, _lib.ptr(dinv), _lib.ptr(val), st),
                "egnn_gcn_norm_values_i64")
-    return SparseTensor(rowptr=rowptr_out, col=col_out, value=val, sparse_sizes=(n, n))
+    out = SparseTensor(rowptr=rowptr_out, col=col_out, value=val, sparse_sizes=(n, n))
+    out._cols_sorted = True
+    return out

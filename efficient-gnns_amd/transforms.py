@@ -12,7 +12,9 @@ def to_sparse_tensor(edge_index: torch.Tensor, num_nodes: int) -> SparseTensor:
     if edge_index.is_cuda and edge_index.shape[1] < 2 ** 31 - 1:
         from .sparse import csr_from_coo
         rowptr, col = csr_from_coo(dst, src, num_nodes, symmetric=False)   # egnn_csr_from_coo_i64: sort on the device
-        return SparseTensor(rowptr=rowptr, col=col, value=None, sparse_sizes=(num_nodes, num_nodes))
+        out = SparseTensor(rowptr=rowptr, col=col, value=None, sparse_sizes=(num_nodes, num_nodes))
+        out._cols_sorted = True
+        return out
     perm = torch.argsort(dst * num_nodes + src, stable=True)
     return SparseTensor(row=dst[perm], col=src[perm], value=None, sparse_sizes=(num_nodes, num_nodes), is_sorted=True)
 

@@ -34,7 +34,7 @@ extern "C" {
 #define EGNN_EWORKSPACE (-3) /* caller-provided workspace too small */
 #define EGNN_EALIGN (-4)   /* pointer / leading dimension not aligned as the entry point requires */
 
-#define EGNN_ABI_VERSION 2
+#define EGNN_ABI_VERSION 3
 int egnn_abi_version(void);
 const char* egnn_error_string(int code);
 /* Number of distinct kernels-families compiled in; used by the loader's self check. */
@@ -182,19 +182,27 @@ int egnn_gemm_rows_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K
 
 /* Row-wise cross entropy + logit-KD, /root/reference/arxiv_pyg/criterion.py:8-21 (and the
  * `loss_cls = F.cross_entropy(logits, labels)` first line of every criterion, :26,41,60,98,132).
- *   out[0] = mean_i CE(logits_i, labels_i)
- *   out[1] = sum_{i,c} p_t (log p_t - log q) / (n*C)   (F.kl_div default reduction='mean'), q = softmax(logits/T),
- *            p_t = softmax(teacher/T); written only when teacher != NULL
+ * Row i of the loss reads row r = rows ? rows[i] : i of logits / teacher and labels[r]: with a row list the
+ * `out[train_idx]`, `y[train_idx]`, `teacher_logits[train_idx]` gathers of train() (gnn.py:107-116) are fused into the
+ * operand loads (logits / teacher / labels are then the FULL [N,*] arrays).  A label outside [0, C) is ignored the
+ * way F.cross_entropy ignores ignore_index (no loss, no gradient, not counted in the mean); it is never an address.
+ *   out3[0] = mean over valid-label rows of CE(logits_r, labels_r)
+ *   out3[1] = sum_{i,c} p_t (log p_t - log q) / (n*C)   (F.kl_div default reduction='mean'), q = softmax(logits/T),
+ *             p_t = softmax(teacher/T); 0 when teacher == NULL
+ *   out3[2] = number of valid-label rows (the backward's CE denominator)
  * partials: workspace of egnn_ce_kd_ws_floats(n) floats. */
 size_t egnn_ce_kd_ws_floats(int64_t n);
 int egnn_ce_kd_fwd_f32(const float* logits, int64_t ld_logits, const float* teacher, int64_t ld_teacher,
-                       const int64_t* labels, int64_t n, int64_t C, float T,
-                       float* out2, float* partials, void* stream);
-/* dlogits[i,c] = g_cls * (softmax(logits_i)_c - [c == label_i]) / n  +  g_kd * (q_ic - p_t,ic) / (T * n * C)
- * g_cls / g_kd: device scalars (nullable = 0). */
+                       const int64_t* labels, const int64_t* rows, int64_t n, int64_t C, float T,
+                       float* out3, float* partials, void* stream);
+/* dlogits[r,c] = g_cls * (softmax(logits_r)_c - [c == label_r]) / out3[2]  +  g_kd * (q_rc - p_t,rc) / (T * n * C)
+ * g_cls / g_kd: device scalars (nullable = 0); out3: the forward's output.  With a row list, dlogits is the full
+ * [n_total_rows, C] block: it is cleared first and only the listed rows are written (the scatter of the
+ * `out[train_idx]` backward). */
 int egnn_ce_kd_bwd_f32(const float* logits, int64_t ld_logits, const float* teacher, int64_t ld_teacher,
-                       const int64_t* labels, int64_t n, int64_t C, float T,
-                       const float* g_cls, const float* g_kd, float* dlogits, int64_t ld_dlogits, void* stream);
+                       const int64_t* labels, const int64_t* rows, int64_t n_total_rows, int64_t n, int64_t C, float T,
+                       const float* out3, const float* g_cls, const float* g_kd, float* dlogits, int64_t ld_dlogits,
+                       void* stream);
 
 /* Gather + L2 row normalisation:  out[i,:] = x[idx[i],:] / max(||x[idx[i],:]||_2, eps), inv_norm[i] = 1/max(..).
  * idx nullable (identity).  F.normalize in criterion.py:29-30,71-72,139-140 fused with the

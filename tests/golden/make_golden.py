@@ -29,6 +29,9 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True   # importing from the read-only /root/reference must not leave __pycache__ there
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
 import numpy as np
 import torch
 

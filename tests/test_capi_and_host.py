@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/egnn_hip.h but not exported"
     assert set(syms) == set(E._lib.SIGNATURES), "ctypes table and header disagree"
-    assert E._lib.load().egnn_abi_version() == 2
+    assert E._lib.load().egnn_abi_version() == 3
     assert "gfx950" in E._lib.build_info()
     assert E._lib.load().egnn_error_string(-3) == b"workspace too small"
 
@@ -305,3 +305,33 @@ def test_teacher_artifact_round_trip(tmp_path):
     assert torch.equal(f2, feat) and torch.equal(l2, logits)
     with pytest.raises(ValueError):
         D.load_teacher_artifacts(str(tmp_path), "gat-3L250x3h", 3, num_nodes=38)
+
+
+def test_dropin_launcher_path_order(tmp_path):
+    """dropin/launch.py: a script directory's own criterion.py must NOT shadow the drop-in one (sys.path[0] is the script
+    directory under ``python gnn.py``); a multi-label (BCE) script directory gets the ppi_pyg shim instead of the arxiv one;
+    --keep-criterion keeps the script's own file."""
+    import subprocess
+    import sys as _sys
+    launch = os.path.join(ROOT, "efficient-gnns_amd", "dropin", "launch.py")
+    for flavour, body in (("arxiv_like", "import torch.nn.functional as F\ndef kd_criterion(*a): return F.cross_entropy\n"),
+                          ("ppi_like", "import torch.nn.functional as F\ndef kd_criterion(*a): return F.binary_cross_entropy_with_logits\n")):
+        sdir = tmp_path / flavour
+        sdir.mkdir()
+        (sdir / "criterion.py").write_text(body)
+        (sdir / "logger.py").write_text("NAME = 'script-local module'\n")
+        (sdir / "gnn.py").write_text(
+            "import sys, criterion, logger\nfrom criterion import *\nimport inspect\n"
+            "print('CRIT', criterion.__file__)\nprint('KD', inspect.signature(kd_criterion))\nprint('LOG', logger.NAME, sys.argv[1:])\n")
+        out = subprocess.run([_sys.executable, launch, str(sdir / "gnn.py"), "--gnn", "gcn"], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        crit = [l for l in out.stdout.splitlines() if l.startswith("CRIT")][0]
+        kd = [l for l in out.stdout.splitlines() if l.startswith("KD")][0]
+        assert "LOG script-local module ['--gnn', 'gcn']" in out.stdout
+        if flavour == "arxiv_like":
+            assert crit.endswith(os.path.join("dropin", "criterion.py")) and "alpha=0.9, T=4" in kd
+        else:
+            assert crit.endswith(os.path.join("dropin", "ppi_pyg", "criterion.py")) and "alpha=0.5, T=1" in kd
+        keep = subprocess.run([_sys.executable, launch, "--keep-criterion", str(sdir / "gnn.py")], capture_output=True, text=True, timeout=300)
+        assert keep.returncode == 0, keep.stderr[-2000:]
+        assert str(sdir / "criterion.py") in keep.stdout

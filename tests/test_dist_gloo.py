@@ -54,11 +54,14 @@ def _patch_ops_with_oracle():
     ops.nce_block_fwd, ops.nce_block_bwd = nce_block_fwd, nce_block_bwd
 
 
-def _make_data(seed=3):
+def _make_data(seed=3, train_ids_below=None):
     import types
     import efficient_gnns_amd.data as D
     import oracle.sparse as OS
     d = D.arxiv_like(scale=0.004, seed=seed)  # ~680 nodes
+    if train_ids_below is not None:   # id-ordered split: every train node in the low id range (the last shards own none)
+        tr = d.split_idx["train"]
+        d.split_idx["train"] = tr[tr < train_ids_below].clone()
     rowptr, col, _ = d.adj_t.csr()
     oadj = OS.SparseTensor(rowptr=rowptr, col=col, sparse_sizes=d.adj_t.sparse_sizes())
     g = OS.gcn_norm_sparse(oadj)
@@ -74,7 +77,7 @@ HP = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=96, kernel="rb
 def _reference_run(gnn, mode, steps=3, hp=None):
     HP = dict(globals()["HP"], **(hp or {}))
     import oracle.models as OM
-    d = _make_data()
+    d = _make_data(train_ids_below=HP.pop("train_ids_below", None))
     torch.manual_seed(0)
     np.random.seed(0)
     model = (OM.GCN if gnn == "gcn" else OM.SAGE)(d.num_features, 32, d.num_classes, 3, 0.0)
@@ -98,7 +101,7 @@ def _worker(rank, world, port, gnn, mode, q, hp=None):
         _patch_ops_with_oracle()
         import efficient_gnns_amd.dist as DD
         import efficient_gnns_amd.models as PM
-        d = _make_data()
+        d = _make_data(train_ids_below=HP.pop("train_ids_below", None))
         prob = DD.ShardedProblem(d, world, rank, "cpu", None, need_gcn=True)
         torch.manual_seed(0)
         np.random.seed(0)
@@ -126,11 +129,16 @@ def _worker(rank, world, port, gnn, mode, q, hp=None):
 @pytest.mark.parametrize("gnn,mode,world,max_samples", [
     ("gcn", "kd", 2, 96), ("gcn", "nce", 2, 96), ("sage", "nce", 2, 96), ("sage", "supervised", 2, 96),
     ("gcn", "nce", 3, 96),     # 3 ranks: uneven node ranges and sample counts
-    ("gcn", "nce", 4, 5)])     # 5 samples over 4 ranks: some ranks own no sampled row (empty row block, collectives still run)
+    ("gcn", "nce", 4, 5),      # 5 samples over 4 ranks: some ranks own no sampled row (empty row block, collectives still run)
+    # every train node in the first 300 ids: the last rank(s) own NO train row -- their loss terms must stay attached to
+    # the graph so that all ranks run the same backward collectives (no 'does not require grad', no hang)
+    ("gcn", "kd", 3, -300), ("gcn", "nce", 3, -300), ("sage", "supervised", 2, -300)])
 def test_sharded_training_matches_single_process_oracle(gnn, mode, world, max_samples):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     hp = dict(max_samples=max_samples)
+    if max_samples < 0:
+        hp = dict(max_samples=64, train_ids_below=-max_samples)
     port = 29500 + (os.getpid() + hash((gnn, mode, world, max_samples))) % 2000
     procs = [ctx.Process(target=_worker, args=(r, world, port, gnn, mode, q, hp)) for r in range(world)]
     for p in procs:

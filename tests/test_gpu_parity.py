@@ -216,6 +216,33 @@ def test_spmm_full_size_properties():
     close(rs[:, 0], dinv * (rs_ref[:, 0] + dinv), rtol=1e-5)
 
 
+def test_spmm_full_size_vs_oracle_k256():
+    """BASELINE.json size against the CPU oracle itself (not only properties): the K = 256 GCN aggregation of the headline
+    workload -- forward and the backward through the transposed CSR -- on the synthetic ogbn-arxiv graph, N = 169 343,
+    nnz_hat = 2.5 M (reference call sites arxiv_pyg/gnn.py:47,52).  Layer-output bar rtol 1e-5 / atol 1e-5 max|ref|,
+    gradient bar rtol 1e-4."""
+    d = D.arxiv_like(1.0, seed=0, with_teacher=False)
+    rowptr, col, _ = d.adj_t.csr()
+    oadj = OS.gcn_norm_sparse(OS.SparseTensor(rowptr=rowptr, col=col, sparse_sizes=d.adj_t.sparse_sizes()))
+    padj = E.gcn_norm(d.adj_t.to(DEV))
+    assert torch.equal(padj.csr()[0].cpu(), oadj.csr()[0]) and torch.equal(padj.csr()[1].cpu(), oadj.csr()[1])
+    close(padj.csr()[2], oadj.csr()[2], rtol=2e-6)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(d.num_nodes, 256, generator=g)
+    gy = torch.randn(d.num_nodes, 256, generator=g)
+    xo = x.clone().requires_grad_(True)
+    yo = OS.matmul(oadj, xo, "sum")
+    yo.backward(gy)
+    xp = x.to(DEV).requires_grad_(True)
+    yp = ops.spmm(padj, xp, "sum")
+    yp.backward(gy.to(DEV))
+    close(yp, yo, rtol=1e-5)
+    close(xp.grad, xo.grad, rtol=1e-4, atol_scale=1e-5)
+    # SAGE's valueless mean aggregation at the same size (gnn.py:79,84)
+    ym = ops.spmm(d.adj_t.to(DEV), x.to(DEV), "mean")
+    close(ym, OS.matmul(OS.SparseTensor(rowptr=rowptr, col=col, sparse_sizes=d.adj_t.sparse_sizes()), x, "mean"), rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------------------------
 # dense GEMM
 # ------------------------------------------------------------------------------------------------
@@ -398,6 +425,28 @@ def test_nce_vs_oracle(S, P, n, tau):
     out[0].backward()
     close(fp.grad, fo.grad, rtol=1e-4, atol_scale=2e-5)
     close(tp.grad, to_.grad, rtol=1e-4, atol_scale=2e-5)
+
+
+def test_nce_full_size_vs_oracle_s16384():
+    """G-CRD at the script-of-record size S = 16 384, P = 256, tau = 0.075 (run_gcn.sh:140-145) against the CPU oracle's
+    nce_criterion (criterion.py:129-149) on the same rows: loss rtol 2e-5, gradients rtol 1e-4 (atol 2e-5 max|ref|)."""
+    S, P, tau = 16384, 256, 0.075
+    g = torch.Generator().manual_seed(11)
+    f = torch.randn(S, P, generator=g)
+    t = torch.relu(torch.randn(S, P, generator=g)) + 0.05 * torch.randn(S, P, generator=g)
+    logits = torch.randn(S, 40, generator=g)
+    labels = torch.randint(0, 40, (S,), generator=g)
+
+    def run(mod, dev):
+        fl, tl, ll = (v.to(dev).clone().requires_grad_(True) for v in (f, t, logits))
+        loss, loss_cls, loss_aux = mod.nce_criterion(ll, labels.to(dev), fl, tl, 0.1, tau, S)   # max_samples == n: no draw
+        loss.backward()
+        return (loss, loss_cls, loss_aux), (fl.grad, tl.grad, ll.grad)
+    (lo, go), (lp, gp) = run(OC, "cpu"), run(PC, DEV)
+    for a, b in zip(lp, lo):
+        assert abs(float(a) - float(b)) <= 2e-5 * abs(float(b)), (lp, lo)
+    for a, b in zip(gp, go):
+        close(a, b, rtol=1e-4, atol_scale=2e-5)
 
 
 def test_nce_full_size_properties():
