@@ -57,18 +57,95 @@ def powerlaw_edges(n: int, e: int, gamma: float = 2.2, max_degree: int | None = 
     return np.stack([keys // n, keys % n])
 
 
-def arxiv_like(scale: float = 1.0, seed: int = 0, with_teacher: bool = True):
+def community_edges(n: int, e: int, gamma: float = 2.2, max_degree: int | None = None, seed: int = 0,
+                    mean_community: int = 400, mu: float = 0.25, shuffle_ids: bool = True):
+    """Directed edge list [2, e] with the SAME in-degree law as ``powerlaw_edges`` (Chung-Lu weights, same hub bisection)
+    plus COMMUNITY STRUCTURE (a degree-corrected stochastic block model): nodes belong to communities of log-normal size
+    (mean ``mean_community``); the source of an edge is drawn from the target's community with probability 1 - mu and from
+    the whole graph otherwise -- hubs whose in-degree exceeds half their community draw the surplus globally, so the degree
+    law survives.  Citation graphs look like this (papers cite inside their sub-field); the plain Chung-Lu graph is the
+    locality-free worst case.  ``shuffle_ids`` permutes the node ids, as real datasets come, so that locality has to be
+    DISCOVERED by a reorder pass (``SparseTensor.reorder``).  Returns (edges [2,e], community [n] of the returned ids)."""
+    rng = np.random.default_rng(seed)
+    alpha = 1.0 / (gamma - 1.0)
+    ranks = np.arange(n, dtype=np.float64)
+
+    def probs(i0):
+        w = (ranks + i0) ** (-alpha)
+        return w / w.sum()
+
+    i0 = 1.0
+    if max_degree is not None:
+        lo, hi = 1e-3, 1e4
+        for _ in range(60):
+            mid = (lo * hi) ** 0.5
+            if probs(mid)[0] * e > max_degree:
+                lo = mid
+            else:
+                hi = mid
+        i0 = hi
+    p = probs(i0)
+    # communities over a hidden order in which degree ranks are scattered (hubs spread over communities)
+    sizes = []
+    left = n
+    while left > 0:
+        s = int(min(left, max(32, rng.lognormal(np.log(mean_community) - 0.125, 0.5))))
+        sizes.append(s)
+        left -= s
+    sizes = np.array(sizes, dtype=np.int64)
+    comm_start = np.concatenate([[0], np.cumsum(sizes)])
+    comm_of_pos = np.repeat(np.arange(sizes.size), sizes)
+    pos_of_rank = rng.permutation(n)                 # degree rank r sits at hidden position pos_of_rank[r]
+    exp_deg = p * e
+    keys = np.empty(0, dtype=np.int64)
+    need = e
+    while need > 0:
+        m = int(need * 1.15) + 16
+        r = rng.choice(n, size=m, p=p)               # target by degree rank
+        dst = pos_of_rank[r]
+        c = comm_of_pos[dst]
+        p_local = (1.0 - mu) * np.minimum(1.0, 0.5 * sizes[c] / np.maximum(exp_deg[r], 1.0))
+        local = rng.random(m) < p_local
+        src = np.where(local, comm_start[c] + (rng.random(m) * sizes[c]).astype(np.int64), rng.integers(0, n, size=m))
+        ok = src != dst
+        k = src[ok].astype(np.int64) * n + dst[ok]
+        keys = np.unique(np.concatenate([keys, k]))
+        need = e - keys.size
+    if keys.size > e:
+        keys = np.sort(rng.choice(keys, size=e, replace=False))
+    src, dst = keys // n, keys % n
+    if shuffle_ids:
+        relabel = rng.permutation(n)
+        src, dst = relabel[src], relabel[dst]
+        community = np.empty(n, dtype=np.int64)
+        community[relabel] = comm_of_pos
+    else:
+        community = comm_of_pos
+    return np.stack([src, dst]), community
+
+
+def arxiv_like(scale: float = 1.0, seed: int = 0, with_teacher: bool = True, graph: str = "chunglu"):
     """Synthetic ogbn-arxiv-shaped node-classification problem (CPU tensors).  ``scale`` < 1 shrinks N and E
-    proportionally (test sizes); scale=1 is the BASELINE.json workload."""
+    proportionally (test sizes); scale=1 is the BASELINE.json workload.  ``graph``: 'chunglu' (the headline workload of
+    SURVEY 8d: power law, no locality at all) | 'local' (same degree law + community structure, ids shuffled: locality
+    must be found by ``SparseTensor.reorder``) | 'local-sorted' (the same graph with ids already in community order)."""
     from .transforms import to_sparse_tensor
     n = max(64, int(round(ARXIV["num_nodes"] * scale)))
     e = max(128, int(round(ARXIV["num_edges"] * scale)))
     md = max(8, int(ARXIV["max_degree"] * min(1.0, scale * 4)))
-    ei = torch.from_numpy(powerlaw_edges(n, e, max_degree=md, seed=seed))
+    community = None
+    if graph == "chunglu":
+        ei = torch.from_numpy(powerlaw_edges(n, e, max_degree=md, seed=seed))
+    elif graph in ("local", "local-sorted"):
+        edges, community = community_edges(n, e, max_degree=md, seed=seed, shuffle_ids=(graph == "local"))
+        ei = torch.from_numpy(edges)
+    else:
+        raise ValueError(f"unknown synthetic graph '{graph}'")
     g = torch.Generator().manual_seed(seed)
     d = types.SimpleNamespace()
     d.num_nodes, d.num_features, d.num_classes = n, ARXIV["num_features"], ARXIV["num_classes"]
     d.edge_index = ei
+    d.community = None if community is None else torch.from_numpy(community)
     d.x = torch.randn(n, d.num_features, generator=g)
     d.y = torch.randint(0, d.num_classes, (n, 1), generator=g)
     tr, va, te = ARXIV["split"]

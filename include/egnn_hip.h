@@ -96,6 +96,33 @@ int egnn_spmm_csr_seg_f32(int64_t n_rows, int64_t n_src, int64_t K,
                           const int64_t* seg, int64_t n_seg, const int64_t* comb_rows, const int64_t* comb_ptr, int64_t n_comb,
                           float* partial, int64_t partial_slots, void* stream);
 
+/* The same aggregation (EGNN_SUM / EGNN_MEAN) under the ROW-BLOCK schedule (csrc/spmm_blk.hip), the default of the host
+ * layer for K % 32 == 0: a workgroup owns `rows_per_blk` consecutive rows (or rows [blk_ptr[b], blk_ptr[b+1]) when
+ * blk_ptr != NULL; every block at most rows_per_blk rows) of one 128-byte column slice; int32 indices; X addressed through
+ * a 32-bit buffer descriptor (n_src * ldx * 4 < 2^31 bytes, else EGNN_EALIGN).  Rows with more than `seg_max` entries are
+ * NOT written: the caller runs egnn_spmm_csr_seg_f32 on the segment ranges of exactly those rows.
+ *   win        nullable [n_rows,2] int32 from egnn_spmm_blk_window_i32: entries [win[2r], win[2r+1]) of row r have their
+ *              source inside row r's own block.  When given (square adjacency, X rows in node order, rows_per_blk <= 1024)
+ *              the block's X rows are staged in LDS and those entries read LDS instead of L2 (graphs in a locality order).
+ *   stat_part  nullable [n_blk,2,K] fp32: per block sum_r (y_r - shift) and sum_r (y_r - shift)^2 over the rows the block
+ *              WROTE -- BatchNorm statistics in the aggregation epilogue (gnn.py:47-48), finished by egnn_bn_stats_merge_f32;
+ *              stat_shift: nullable [K] (any vector near the column means, e.g. BatchNorm's running_mean; exactness does
+ *              not depend on it, only the conditioning of the variance)
+ *   flags      bit 0: non-temporal index / value loads; bit 1: non-temporal Y stores; bit 2: write-through (sc1) Y stores;
+ *              bits 8-11: waves-per-SIMD target of the kernel variant (0 = default) -- tuning knobs, results are identical */
+int egnn_spmm_csr_blk_f32(int64_t n_rows, int64_t n_src, int64_t K,
+                          const int32_t* rowptr, const int32_t* col, const float* val, const float* src_scale, const float* bias,
+                          const float* X, int64_t ldx, float* Y, int64_t ldy, int reduce,
+                          int seg_max, int rows_per_blk, const int32_t* blk_ptr, int64_t n_blk, const int32_t* win,
+                          float* stat_part, const float* stat_shift, int flags, void* stream);
+int egnn_spmm_blk_window_i32(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int rows_per_blk,
+                             const int32_t* blk_ptr, int64_t n_blk, int32_t* win, void* stream);
+/* mean[c], var[c] (biased) of n_total rows of Y: the block partials of egnn_spmm_csr_blk_f32 plus the rows listed in
+ * extra_rows (the hub rows the block kernel skipped), read from Y.  Fixed summation order (deterministic). */
+int egnn_bn_stats_merge_f32(const float* stat_part, int64_t n_blk, int64_t C, const float* Y, int64_t ldy,
+                            const int64_t* extra_rows, int64_t n_extra, const float* stat_shift, int64_t n_total,
+                            float* mean, float* var, void* stream);
+
 /* Backward of EGNN_MAX: dX[col[argmax[i,k]], k] += val * dY[i,k].  dX must be zero-filled by the
  * caller.  Uses float atomics (the only entry point that does); max-aggregation is never exercised
  * by the reference and is provided because north_star names it. */
