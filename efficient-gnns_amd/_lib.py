@@ -21,7 +21,8 @@ SIGNATURES = {
     "egnn_build_info": (_i32, [C.c_char_p, _sz]),
     "egnn_spmm_csr_f32": (_i32, [_i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p, _i64, _p, _i64, _p, _i64, _p]),
     "egnn_spmm_csr_seg_f32": (_i32, [_i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p]),
-    "egnn_spmm_csr_blk_f32": (_i32, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _p, _i32, _p]),
+    "egnn_spmm_csr_blk_f32": (_i32, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i64, _p,
+                                     _p, _p, _i32, _p]),
     "egnn_spmm_blk_window_i32": (_i32, [_p, _p, _i64, _i32, _p, _i64, _p, _p]),
     "egnn_bn_stats_merge_f32": (_i32, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p]),
     "egnn_spmm_csr_max_bwd_f32": (_i32, [_i64, _i64, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p]),

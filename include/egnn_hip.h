@@ -97,23 +97,28 @@ int egnn_spmm_csr_seg_f32(int64_t n_rows, int64_t n_src, int64_t K,
                           float* partial, int64_t partial_slots, void* stream);
 
 /* The same aggregation (EGNN_SUM / EGNN_MEAN) under the ROW-BLOCK schedule (csrc/spmm_blk.hip), the default of the host
- * layer for K % 32 == 0: a workgroup owns `rows_per_blk` consecutive rows (or rows [blk_ptr[b], blk_ptr[b+1]) when
- * blk_ptr != NULL; every block at most rows_per_blk rows) of one 128-byte column slice; int32 indices; X addressed through
- * a 32-bit buffer descriptor (n_src * ldx * 4 < 2^31 bytes, else EGNN_EALIGN).  Rows with more than `seg_max` entries are
- * NOT written: the caller runs egnn_spmm_csr_seg_f32 on the segment ranges of exactly those rows.
+ * layer: ONE launch walks, per 128-byte column slice, first the hub segments and then blocks of `rows_per_blk`
+ * consecutive rows (or rows [blk_ptr[b], blk_ptr[b+1]) when blk_ptr != NULL; every block at most rows_per_blk rows);
+ * int32 indices; any K % 4 == 0; X addressed through a 32-bit buffer descriptor (n_src * ldx * 4 < 2^31 bytes, else
+ * EGNN_EALIGN).
+ *   hub_seg    [n_hub_seg,4] int32 (first entry, end entry, partial slot, 0): the entry ranges (<= seg_max entries each) of
+ *              the rows with MORE than seg_max entries; their sums go to partial[slot,:] ([slots,K] fp32, 16-byte aligned)
+ *              and the caller finishes those rows with the combine step of egnn_spmm_csr_seg_f32 (n_seg = 0, comb_* lists).
+ *              Rows with at most seg_max entries are written here, completely.
  *   win        nullable [n_rows,2] int32 from egnn_spmm_blk_window_i32: entries [win[2r], win[2r+1]) of row r have their
- *              source inside row r's own block.  When given (square adjacency, X rows in node order, rows_per_blk <= 1024)
- *              the block's X rows are staged in LDS and those entries read LDS instead of L2 (graphs in a locality order).
+ *              source inside row r's own block.  When given (square adjacency, X rows in node order, rows_per_blk a multiple
+ *              of 128, <= 512) the block's X rows are streamed into LDS (LDS-DMA) while the out-of-block entries are
+ *              gathered, and the in-block entries read LDS instead of L2 (graphs in a locality order).
  *   stat_part  nullable [n_blk,2,K] fp32: per block sum_r (y_r - shift) and sum_r (y_r - shift)^2 over the rows the block
  *              WROTE -- BatchNorm statistics in the aggregation epilogue (gnn.py:47-48), finished by egnn_bn_stats_merge_f32;
  *              stat_shift: nullable [K] (any vector near the column means, e.g. BatchNorm's running_mean; exactness does
  *              not depend on it, only the conditioning of the variance)
- *   flags      bit 0: non-temporal index / value loads; bit 1: non-temporal Y stores; bit 2: write-through (sc1) Y stores;
- *              bits 8-11: waves-per-SIMD target of the kernel variant (0 = default) -- tuning knobs, results are identical */
+ *   flags      bit 1: non-temporal Y stores; bit 2: write-through (sc1) Y stores (tuning knobs, results are identical) */
 int egnn_spmm_csr_blk_f32(int64_t n_rows, int64_t n_src, int64_t K,
                           const int32_t* rowptr, const int32_t* col, const float* val, const float* src_scale, const float* bias,
                           const float* X, int64_t ldx, float* Y, int64_t ldy, int reduce,
                           int seg_max, int rows_per_blk, const int32_t* blk_ptr, int64_t n_blk, const int32_t* win,
+                          const int32_t* hub_seg, int64_t n_hub_seg, float* partial,
                           float* stat_part, const float* stat_shift, int flags, void* stream);
 int egnn_spmm_blk_window_i32(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int rows_per_blk,
                              const int32_t* blk_ptr, int64_t n_blk, int32_t* win, void* stream);

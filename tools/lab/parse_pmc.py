@@ -5,6 +5,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 d = sys.argv[1]
@@ -18,7 +19,8 @@ for f in sorted(glob.glob(os.path.join(d, "*.csv"))):
         group = g2 + "_" + group
     per = {}
     for r in csv.DictReader(open(f)):
-        kn = r["Kernel_Name"].split("(")[0].split("::")[-1].split("<")[0]
+        m = re.search(r"(spmm_\w+|bn_\w+)", r["Kernel_Name"])
+        kn = m.group(1) if m else r["Kernel_Name"][:40]
         k = per.setdefault(kn, {})
         k.setdefault("_disp", set()).add(r["Dispatch_Id"])
         k[r["Counter_Name"]] = k.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])

@@ -120,7 +120,14 @@ int main(int argc, char** argv) {
 
   int32_t *d_rp = to_dev(g.rowptr), *d_col = to_dev(g.col);
   float* d_val = to_dev(g.val);
-  int64_t *d_seg_all = to_dev(sp.seg_all), *d_seg_hub = to_dev(sp.seg_hub), *d_crow = to_dev(sp.crow), *d_cptr = to_dev(sp.cptr);
+  int64_t *d_seg_all = to_dev(sp.seg_all), *d_crow = to_dev(sp.crow), *d_cptr = to_dev(sp.cptr);
+  std::vector<int32_t> hseg32;
+  for (size_t i = 0; i + 2 < sp.seg_hub.size(); i += 3) {
+    hseg32.push_back((int32_t)sp.seg_hub[i]); hseg32.push_back((int32_t)sp.seg_hub[i + 1]);
+    hseg32.push_back((int32_t)(sp.seg_hub[i + 2] - g.n)); hseg32.push_back(0);
+  }
+  int32_t* d_hseg = to_dev(hseg32);
+  const int64_t n_hseg = (int64_t)hseg32.size() / 4;
   std::vector<float> hx((size_t)n * K);
   std::mt19937 rng(7);
   std::normal_distribution<float> nd(0.f, 1.f);
@@ -156,26 +163,22 @@ int main(int argc, char** argv) {
   }
   // full-matrix column statistics for the epilogue-stats variants
   const int64_t alg_bytes = egnn_spmm_algorithmic_bytes(n, n, K, g.nnz, 32, 1);
+  if (K % 4 != 0) { fprintf(stderr, "K must be a multiple of 4\n"); return 2; }
 
   std::vector<Variant> vars;
   vars.push_back({"seg_r01", 0, 0, 0, false, false, false});
-  for (int R : {32, 64, 128, 256, 512})
-    for (int fl : {0, 1, 1 | 4, 1 | 2})
+  for (int R : {32, 64, 128})
+    for (int fl : {0, 4})
       vars.push_back({"blk_R" + std::to_string(R) + "_f" + std::to_string(fl), 1, R, fl, false, false, false});
-  for (int occ : {4, 6})
-    vars.push_back({"blk_R128_f5_occ" + std::to_string(occ), 1, 128, 5 | (occ << 8), false, false, false});
-  for (int R : {64, 128, 256})
-    for (int occ : {4, 6, 8})
-      vars.push_back({"pipe_R" + std::to_string(R) + "_f5_occ" + std::to_string(occ), 1, R, 5 | 8 | (occ << 8), false, false, false});
-  vars.push_back({"pipe_R128_f0_occ4", 1, 128, 8 | (4 << 8), false, false, false});
-  vars.push_back({"blk_R128_f5_stats", 1, 128, 5, false, true, false});
+  vars.push_back({"blk_R32_f0_stats", 1, 32, 0, false, true, false});
+  vars.push_back({"blk_R64_f0_stats", 1, 64, 0, false, true, false});
   vars.push_back({"blk_R128_f0_stats", 1, 128, 0, false, true, false});
-  for (int R : {128, 256, 512, 1024}) {
-    vars.push_back({"lds_R" + std::to_string(R) + "_f0", 1, R, 0, true, false, false});
-    vars.push_back({"lds_R" + std::to_string(R) + "_f5", 1, R, 5, true, false, false});
-    if (g.n_comm > 0) vars.push_back({"ldsc_R" + std::to_string(R) + "_f5", 1, R, 5, true, false, true});
-  }
-  vars.push_back({"lds_R512_f5_stats", 1, 512, 5, true, true, false});
+  if (K % 32 == 0)
+    for (int R : {128, 256, 512}) {
+      vars.push_back({"lds_R" + std::to_string(R) + "_f0", 1, R, 0, true, false, false});
+      if (g.n_comm > 0) vars.push_back({"ldsc_R" + std::to_string(R) + "_f0", 1, R, 0, true, false, true});
+    }
+  if (K % 32 == 0) vars.push_back({"lds_R512_f0_stats", 1, 512, 0, true, true, false});
 
   std::vector<float> hy((size_t)n * K);
   for (const Variant& v : vars) {
@@ -219,11 +222,12 @@ int main(int argc, char** argv) {
         return egnn_spmm_csr_seg_f32(n, n, K, d_rp, d_col, 32, d_val, nullptr, nullptr, d_x, K, d_y, K, EGNN_SUM, d_seg_all,
                                      (int64_t)sp.seg_all.size() / 3, d_crow, d_cptr, (int64_t)sp.crow.size(), d_partial, sp.slots, st);
       int rc = egnn_spmm_csr_blk_f32(n, n, K, d_rp, d_col, d_val, nullptr, nullptr, d_x, K, d_y, K, EGNN_SUM, seg_max, v.R, d_blk, n_blk,
-                                     v.lds ? d_win : nullptr, v.stats ? d_stat : nullptr, v.stats ? d_shift : nullptr, v.flags, st);
+                                     v.lds ? d_win : nullptr, d_hseg, n_hseg, d_partial, v.stats ? d_stat : nullptr,
+                                     v.stats ? d_shift : nullptr, v.flags, st);
       if (rc) return rc;
-      if (!sp.crow.empty())
-        rc = egnn_spmm_csr_seg_f32(n, n, K, d_rp, d_col, 32, d_val, nullptr, nullptr, d_x, K, d_y, K, EGNN_SUM, d_seg_hub,
-                                   (int64_t)sp.seg_hub.size() / 3, d_crow, d_cptr, (int64_t)sp.crow.size(), d_partial, sp.slots, st);
+      if (!sp.crow.empty())   // combine step only (n_seg = 0): the hub segments were gathered by the block kernel's launch
+        rc = egnn_spmm_csr_seg_f32(n, n, K, d_rp, d_col, 32, d_val, nullptr, nullptr, d_x, K, d_y, K, EGNN_SUM, nullptr, 0, d_crow,
+                                   d_cptr, (int64_t)sp.crow.size(), d_partial, sp.slots, st);
       if (rc) return rc;
       if (v.stats)
         rc = egnn_bn_stats_merge_f32(d_stat, nb, K, d_y, K, d_crow, (int64_t)sp.crow.size(), d_shift, n, d_mean, d_var, st);
