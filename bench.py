@@ -333,21 +333,23 @@ def main():
         # HBM-side bytes per call from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in their own rocprofv3 runs by
         # tools/pmc_round.sh, calibrated on a copy of known size; profiles/r01_spmm_traffic.json) -- not re-measured here
         traffic = os.environ.get("EGNN_SPMM_TRAFFIC_BYTES")
-        tj = os.path.join(ROOT, "profiles", "r01_spmm_traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r02_spmm_traffic.json")
         if traffic is None and os.path.exists(tj):
             try:
                 traffic = json.load(open(tj)).get("hbm_bytes_per_call")
             except Exception:  # noqa: BLE001
                 traffic = None
         sched = getattr(ops, "_SPMM_SCHEDULE", "classes")
-        kern = ("spmm_short_rows_kernel + spmm_combine_kernel (egnn_spmm_csr_seg_f32" if sched == "segments"
-                else "spmm_{short_rows,rows,long_rows}_kernel (egnn_spmm_csr_f32")
+        kern = {"blocks": "spmm_blk_kernel + spmm_combine_kernel (egnn_spmm_csr_blk_f32 + combine",
+                "segments": "spmm_short_rows_kernel + spmm_combine_kernel (egnn_spmm_csr_seg_f32"}.get(
+                    sched, "spmm_{short_rows,rows,long_rows}_kernel (egnn_spmm_csr_f32")
         roofline = dict(bound="hbm", kernel=f"{kern}, K={K}, reduce=sum)",
                         achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4),
                         frac_of_measured_copy_peak=round(gbs / 6290.0, 4),
                         algorithmic_bytes_per_launch=roof["bytes"], avg_launch_us=round(roof["avg_s"] * 1e6, 2),
                         launches_timed=roof["launches"], traffic=float(traffic) if traffic else None,
-                        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (profiles/r01_spmm_traffic.json)" if traffic else None)
+                        traffic_source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same entry points, separate passes, calibrated on a 256 MiB copy "
+                                       "(profiles/r02_spmm_traffic.json; measured off-line, not in this run)" if traffic else None)
     roofline_mfma = None
     nsum = nce_probe.summary()
     if nsum:

@@ -345,9 +345,38 @@ __global__ __launch_bounds__(256) void spmm_blk_window_kernel(const int32_t* __r
   win[2 * row + 1] = lower(hi_id);
 }
 
-// mean / biased variance of the rows of Y from the per-block shifted sums of spmm_blk_kernel plus the rows the block
-// kernel skipped (hub rows, read back from Y): fixed order => deterministic.  8 columns per workgroup x 32 partial groups.
-__global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __restrict__ part, int64_t n_blk, int64_t C,
+// Statistics merge, stage 1: the [n_blk][2][C] block partials are folded into kStatSplits partial rows.  Workgroup
+// (column group of 32, split s): thread t adds column (t & 31) over blocks first + (t >> 5), + 8, ... of its split (128-byte
+// coalesced reads), the 8 row groups are added in index order.  Fixed order => deterministic.
+constexpr int kStatSplits = 64;
+__global__ __launch_bounds__(256) void bn_stats_fold_kernel(const float* __restrict__ part, int64_t n_blk, int64_t C,
+                                                            float* __restrict__ fold) {
+  __shared__ float sh[2][8][32];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t col = (int64_t)blockIdx.x * 32 + c;
+  const int s = blockIdx.y;
+  const int64_t per = (n_blk + kStatSplits - 1) / kStatSplits;
+  const int64_t b0 = s * per, b1 = b0 + per < n_blk ? b0 + per : n_blk;
+  float sa = 0.f, sb = 0.f;
+  if (col < C)
+    for (int64_t i = b0 + g; i < b1; i += 8) {
+      sa += part[(i * 2) * C + col];
+      sb += part[(i * 2 + 1) * C + col];
+    }
+  sh[0][g][c] = sa;
+  sh[1][g][c] = sb;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int which = threadIdx.x >> 5;
+    float t = 0.f;
+    for (int q = 0; q < 8; ++q) t += sh[which][q][c];
+    if (col < C) fold[((int64_t)s * 2 + which) * C + col] = t;
+  }
+}
+
+// stage 2: mean / biased variance from the folded partials plus the rows the block kernel skipped (hub rows, read back
+// from Y).  8 columns per workgroup x 32 groups; fixed order.
+__global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __restrict__ part, int64_t n_part, int64_t C,
                                                              const float* __restrict__ Y, int64_t ldy, const int64_t* __restrict__ extra_rows,
                                                              int64_t n_extra, const float* __restrict__ shift, int64_t n_total,
                                                              float* __restrict__ mean, float* __restrict__ var) {
@@ -357,7 +386,7 @@ __global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __rest
   float sa = 0.f, sb = 0.f;
   if (c < C) {
     const float sft = shift ? shift[c] : 0.f;
-    for (int64_t i = grp; i < n_blk; i += 32) {
+    for (int64_t i = grp; i < n_part; i += 32) {
       sa += part[(i * 2) * C + c];
       sb += part[(i * 2 + 1) * C + c];
     }
@@ -441,12 +470,22 @@ extern "C" int egnn_spmm_csr_blk_f32(int64_t n_rows, int64_t n_src, int64_t K, c
   return stats ? launch_blk<true, true, 16, 4>(a, (unsigned)grid, shm, st) : launch_blk<true, false, 16, 4>(a, (unsigned)grid, shm, st);
 }
 
+extern "C" size_t egnn_bn_stats_merge_ws_floats(int64_t C) { return (size_t)kStatSplits * 2 * (size_t)C; }
+
 extern "C" int egnn_bn_stats_merge_f32(const float* part, int64_t n_blk, int64_t C, const float* Y, int64_t ldy,
                                        const int64_t* extra_rows, int64_t n_extra, const float* shift, int64_t n_total, float* mean,
-                                       float* var, void* stream) {
+                                       float* var, float* ws, size_t ws_floats, void* stream) {
   EGNN_CHECK_ARG(n_blk >= 0 && C > 0 && n_extra >= 0 && n_total > 0 && mean && var);
   EGNN_CHECK_ARG((n_blk == 0 || part) && (n_extra == 0 || (Y && extra_rows && ldy >= C)));
-  hipLaunchKernelGGL(bn_stats_merge_kernel, dim3((unsigned)((C + 7) / 8)), dim3(256), 0, (hipStream_t)stream, part, n_blk, C, Y, ldy,
-                     extra_rows, n_extra, shift, n_total, mean, var);
+  hipStream_t st = (hipStream_t)stream;
+  int64_t n_part = n_blk;
+  if (n_blk > 2 * kStatSplits) {   // many blocks: fold them into kStatSplits partial rows first (two short launches)
+    if (ws == nullptr || ws_floats < egnn_bn_stats_merge_ws_floats(C)) return EGNN_EWORKSPACE;
+    hipLaunchKernelGGL(bn_stats_fold_kernel, dim3((unsigned)((C + 31) / 32), kStatSplits), dim3(256), 0, st, part, n_blk, C, ws);
+    part = ws;
+    n_part = kStatSplits;
+  }
+  hipLaunchKernelGGL(bn_stats_merge_kernel, dim3((unsigned)((C + 7) / 8)), dim3(256), 0, st, part, n_part, C, Y, ldy, extra_rows,
+                     n_extra, shift, n_total, mean, var);
   return egnn_launch_status();
 }

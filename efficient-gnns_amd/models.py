@@ -34,7 +34,12 @@ class _Student(nn.Module):
 
     def forward(self, x, adj_t):
         for conv, bn in zip(self.convs[:-1], self.bns):
-            x = conv(x, adj_t)
+            if (isinstance(conv, GCNConv) and isinstance(bn, nn.BatchNorm1d) and x.is_cuda and self.training
+                    and isinstance(adj_t, SparseTensor)):
+                # BatchNorm follows (gnn.py:47-48): its batch statistics come out of the aggregation's store epilogue
+                x = conv(x, adj_t, bn_stats_shift=bn.running_mean, want_bn_stats=True)
+            else:
+                x = conv(x, adj_t)
             if isinstance(bn, nn.BatchNorm1d) and x.is_cuda:   # fused BN + ReLU + dropout kernels (gnn.py:48-50)
                 x = ops.bn_act(x, bn, relu=True, p=self.dropout, training=self.training)
             elif hasattr(bn, "fused_act"):                      # dist.SyncBatchNorm1d on sharded runs (all-rank statistics)

@@ -96,7 +96,11 @@ class GCNConv(nn.Module):
         self._cached_adj_t = None
         self._cached_ax = None
 
-    def forward(self, x: Tensor, edge_index) -> Tensor:
+    def forward(self, x: Tensor, edge_index, edge_weight=None, bn_stats_shift: Tensor | None = None, want_bn_stats: bool = False) -> Tensor:
+        """``bn_stats_shift`` / ``want_bn_stats`` (extension, off by default): the caller applies a BatchNorm to the result next
+        and wants its column statistics formed in the aggregation's epilogue (``ops.spmm``)."""
+        if edge_weight is not None:
+            raise NotImplementedError("GCNConv with edge_weight is not used by the reference")
         agg_first = self.in_channels < self.out_channels
         if hasattr(edge_index, "gcn_normalized"):  # node-range shard (dist.ShardedAdj): halo exchange + local rows of A^
             if agg_first:
@@ -128,7 +132,8 @@ class GCNConv(nn.Module):
             return out + self.bias if self.bias is not None else out
         if agg_first:
             return ops.matmul(ops.spmm(norm, x, "sum"), self.weight, self.bias)
-        return ops.spmm(norm, ops.matmul(x, self.weight), "sum", bias=self.bias)  # bias added in the kernel's store
+        return ops.spmm(norm, ops.matmul(x, self.weight), "sum", bias=self.bias,  # bias added in the kernel's store
+                        bn_stats_shift=bn_stats_shift, want_bn_stats=want_bn_stats)
 
     def __repr__(self):
         return f"GCNConv({self.in_channels}, {self.out_channels})"

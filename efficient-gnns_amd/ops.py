@@ -35,14 +35,25 @@ def _rowmajor(x: Tensor) -> Tensor:
 # ------------------------------------------------------------------------------------------------
 # SpMM
 # ------------------------------------------------------------------------------------------------
-# 'segments' (default): egnn_spmm_csr_seg_f32; 'classes': short / mid / long row classes of egnn_spmm_csr_f32
-_SPMM_SCHEDULE = os.environ.get("EGNN_SPMM_SCHEDULE", "segments")
+# 'blocks' (default): egnn_spmm_csr_blk_f32; 'segments': egnn_spmm_csr_seg_f32; 'classes': short / mid / long row classes
+_SPMM_SCHEDULE = os.environ.get("EGNN_SPMM_SCHEDULE", "blocks")
+
+
+class HipStatsUnavailable(RuntimeError):
+    """spmm_raw(want_stats=True) on a shape / schedule whose kernel has no statistics epilogue (callers fall back to the
+    separate egnn_bn_stats_f32 pass)."""
 
 
 def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = None, use_plan: bool = True,
-             bias: Tensor | None = None, out: Tensor | None = None):
-    """Y = REDUCE(adj, X) on the GPU (egnn_spmm_csr_seg_f32 / egnn_spmm_csr_f32).  Returns (Y, argmax | None).
-    ``out``: optional [n_rows, K] destination with unit column stride (e.g. a column block of a wider matrix)."""
+             bias: Tensor | None = None, out: Tensor | None = None, stat_shift: Tensor | None = None, want_stats: bool = False):
+    """Y = REDUCE(adj, X) on the GPU.  Returns (Y, argmax | None), or (Y, None, (mean, biased var)) with ``want_stats``.
+
+    Schedules: 'blocks' (default; egnn_spmm_csr_blk_f32: one launch over hub segments + row blocks, int32 indices, then the
+    fixed-order combine of the hub rows), 'segments' (round-1 egnn_spmm_csr_seg_f32), 'classes' (egnn_spmm_csr_f32: also the
+    path of ``max`` and of shapes the float4 kernels do not take).
+    ``out``: optional [n_rows, K] destination with unit column stride (e.g. a column block of a wider matrix).
+    ``want_stats`` (sum / mean on the block schedule only): per-column mean and biased variance of Y over all rows, formed in
+    the aggregation's epilogue (BatchNorm statistics, gnn.py:47-48); ``stat_shift`` [K]: shift of the shifted sums."""
     _lib.require_gpu(x, adj._col)
     x = _rowmajor(x)
     n_rows, n_src = adj.sparse_sizes()
@@ -63,15 +74,58 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
             y.add_(bias)
         if arg is not None:
             arg.fill_(-1)
+        if want_stats:
+            raise HipStatsUnavailable()
         return y, arg
     rowptr, col, bits = adj._index_arrays()
     lib = _lib.load()
-    if (use_plan and _SPMM_SCHEDULE == "segments" and red != 2 and K % 4 == 0 and x.stride(0) % 4 == 0
-            and x.data_ptr() % 16 == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0
-            and (bias is None or bias.data_ptr() % 16 == 0)):
+    float4_ok = (use_plan and red != 2 and K % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+                 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0 and (bias is None or bias.data_ptr() % 16 == 0))
+    # the block schedule wins from two 128-byte column slices up (K = 256: 343 vs 385 us, K = 128: 167 vs 186 us on the
+    # arxiv-shaped graph); below that (the 40-class output layer) the 16-lane form of the segment kernel is faster (92 vs 113 us)
+    if float4_ok and _SPMM_SCHEDULE == "blocks" and bits == 32 and K >= 64 and n_src * x.stride(0) * 4 < 2 ** 31 and n_rows > 0:
+        from .sparse import BLK_ROWS, SEG_MAX
+        hseg, crow, cptr, slots = adj._blk_plan()
+        partial = adj._scratch("partial", (max(slots, 1), K))
+        loc = adj._struct.get("locality")          # opt-in: (rows_per_blk, win) of SparseTensor.stage_diagonal_blocks()
+        use_lds = loc is not None and n_rows == n_src and K % 32 == 0
+        rows_blk = loc[0] if use_lds else BLK_ROWS
+        n_blk = (n_rows + rows_blk - 1) // rows_blk
+        # Y rows are stored write-through (dropped from L2: they are not re-read here and would only evict gathered X
+        # lines) unless the statistics epilogue re-reads them
+        flags = 0 if want_stats else 4
+        stat_part = adj._scratch("stat", (n_blk, 2, K)) if want_stats else None
+        if stat_shift is not None:
+            stat_shift = stat_shift.detach().contiguous()
+        rc = lib.egnn_spmm_csr_blk_f32(n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(adj._value), _lib.ptr(src_scale),
+                                       _lib.ptr(bias), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), red, SEG_MAX, rows_blk, None, 0,
+                                       _lib.ptr(loc[1]) if use_lds else None, _lib.ptr(hseg), hseg.shape[0], _lib.ptr(partial),
+                                       _lib.ptr(stat_part), _lib.ptr(stat_shift) if want_stats else None, flags, _lib.stream())
+        if rc == 0:
+            if crow.numel() > 0:   # the hub rows: fixed-order sum of their partial slots (+ mean / bias)
+                rc = lib.egnn_spmm_csr_seg_f32(n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), bits, _lib.ptr(adj._value),
+                                               _lib.ptr(src_scale), _lib.ptr(bias), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0),
+                                               red, None, 0, _lib.ptr(crow), _lib.ptr(cptr), crow.numel(), _lib.ptr(partial), slots,
+                                               _lib.stream())
+                _lib.check(rc, "egnn_spmm_csr_seg_f32 (combine)")
+            if not want_stats:
+                return y, None
+            mean = torch.empty(K, dtype=torch.float32, device=x.device)
+            var = torch.empty(K, dtype=torch.float32, device=x.device)
+            nws = lib.egnn_bn_stats_merge_ws_floats(K)
+            ws = adj._scratch("statfold", (nws,))
+            _lib.check(lib.egnn_bn_stats_merge_f32(_lib.ptr(stat_part), n_blk, K, _lib.ptr(y), y.stride(0), _lib.ptr(crow), crow.numel(),
+                                                   _lib.ptr(stat_shift), n_rows, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(ws), nws,
+                                                   _lib.stream()), "egnn_bn_stats_merge_f32")
+            return y, None, (mean, var)
+        if rc != -4:   # EGNN_EALIGN: shape outside the block kernel's forms -> the schedules below
+            _lib.check(rc, "egnn_spmm_csr_blk_f32")
+    if want_stats:
+        raise HipStatsUnavailable()
+    if float4_ok and _SPMM_SCHEDULE in ("blocks", "segments"):
         # every row as ranges of <= 64 entries through the sub-group-per-row kernel (hub rows get the bulk's parallelism)
         seg, crow, cptr, slots = adj._seg_plan()
-        partial = torch.empty(max(slots, 1), K, dtype=torch.float32, device=x.device)
+        partial = adj._scratch("partial", (max(slots, 1), K))
         rc = lib.egnn_spmm_csr_seg_f32(n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), bits, _lib.ptr(adj._value), _lib.ptr(src_scale),
                                        _lib.ptr(bias), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), red, _lib.ptr(seg),
                                        seg.shape[0], _lib.ptr(crow), _lib.ptr(cptr), crow.numel(), _lib.ptr(partial), slots, _lib.stream())
@@ -115,15 +169,26 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
 
 class _SpMM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, adj, reduce, bias=None):
-        y, arg = spmm_raw(adj, x, reduce, bias=None if bias is None else bias.detach().contiguous())
+    def forward(ctx, x, adj, reduce, bias=None, stat_shift=None, want_stats=False):
+        b = None if bias is None else bias.detach().contiguous()
+        stats = None
+        if want_stats:
+            try:
+                y, arg, stats = spmm_raw(adj, x, reduce, bias=b, stat_shift=stat_shift, want_stats=True)
+            except HipStatsUnavailable:
+                y, arg = spmm_raw(adj, x, reduce, bias=b)
+        else:
+            y, arg = spmm_raw(adj, x, reduce, bias=b)
         ctx.adj, ctx.reduce, ctx.has_bias = adj, reduce, bias is not None
         if arg is not None:
             ctx.save_for_backward(arg)
-        return y
+        if stats is None:
+            return y, None, None
+        ctx.mark_non_differentiable(*stats)
+        return y, stats[0], stats[1]
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gm=None, _gv=None):
         adj, reduce = ctx.adj, ctx.reduce
         gy = _rowmajor(gy)
         if reduce in ("sum", "add"):
@@ -137,22 +202,36 @@ class _SpMM(torch.autograd.Function):
             K = gy.shape[1]
             gx = torch.zeros(n_src, K, dtype=torch.float32, device=gy.device)
             if adj.nnz() == 0:   # no stored entry: nothing receives gradient
-                return gx, None, None, (gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None)
+                return gx, None, None, (colsum(gy) if ctx.has_bias and ctx.needs_input_grad[3] else None), None, None
             _, col, bits = adj._index_arrays()
             rc = _lib.load().egnn_spmm_csr_max_bwd_f32(n_rows, K, _lib.ptr(col), bits, _lib.ptr(adj._value), _lib.ptr(arg),
                                                        _lib.ptr(gy), gy.stride(0), _lib.ptr(gx), gx.stride(0), _lib.stream())
             _lib.check(rc, "egnn_spmm_csr_max_bwd_f32")
-        gb = gy.sum(0) if ctx.has_bias and ctx.needs_input_grad[3] else None
-        return gx, None, None, gb
+        gb = colsum(gy) if ctx.has_bias and ctx.needs_input_grad[3] else None
+        return gx, None, None, gb, None, None
 
 
-def spmm(adj, x: Tensor, reduce: str = "sum", bias: Tensor | None = None) -> Tensor:
-    """adj @ x with the given reduction; ``bias`` ([K]) is added in the kernel's store (sum / mean only)."""
+def colsum(g: Tensor) -> Tensor:
+    """Column sums of a [n, C] gradient (bias gradients)."""
+    return g.sum(0)
+
+
+def spmm(adj, x: Tensor, reduce: str = "sum", bias: Tensor | None = None, bn_stats_shift: Tensor | None = None,
+         want_bn_stats: bool = False) -> Tensor:
+    """adj @ x with the given reduction; ``bias`` ([K]) is added in the kernel's store (sum / mean only).
+
+    ``want_bn_stats``: the caller will BatchNorm the result next (gnn.py:47-48): the column mean / biased variance are
+    formed in the aggregation's epilogue and attached to the returned tensor (``_egnn_bn_stats``) for ``ops.bn_act``;
+    ``bn_stats_shift``: shift of the shifted sums (the BatchNorm's running_mean).  Where the kernel in use has no such
+    epilogue nothing is attached and ``bn_act`` runs its own statistics pass."""
     if reduce not in _REDUCE:
         raise ValueError(f"unknown reduce '{reduce}'")
     if bias is not None and (reduce == "max" or (x.shape[1] % 4 == 0 and bias.data_ptr() % 16 != 0)):
-        return _SpMM.apply(x, adj, reduce, None) + bias
-    return _SpMM.apply(x, adj, reduce, bias)
+        return _SpMM.apply(x, adj, reduce, None)[0] + bias
+    y, mean, var = _SpMM.apply(x, adj, reduce, bias, bn_stats_shift, bool(want_bn_stats) and reduce != "max")
+    if mean is not None:
+        y._egnn_bn_stats = (mean, var)
+    return y
 
 
 class _TakeRows(torch.autograd.Function):
@@ -267,7 +346,7 @@ class _MatMul(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = gemm_raw(gy, x, True, False) if ctx.transposed else gemm_raw(x, gy, True, False)  # dW = dY^T X | X^T dY
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum(0)
+            gb = colsum(gy)
         return gx, gw, gb, None
 
 
@@ -300,7 +379,7 @@ class _LinearRows(torch.autograd.Function):
         if ctx.needs_input_grad[2]:
             gw = gemm_raw(gy, x, True, False, b_rows=idx)
         if ctx.has_bias and ctx.needs_input_grad[3]:
-            gb = gy.sum(0)
+            gb = colsum(gy)
         return gx, None, gw, gb
 
 
@@ -546,6 +625,7 @@ def bn_act(x: Tensor, bn: "torch.nn.BatchNorm1d", relu: bool = True, p: float = 
 
     Falls back to the torch operators (still on the GPU) for shapes the kernel does not take (C % 4 != 0, C > 1024)."""
     training = bn.training if training is None else training
+    x_in = x
     if not _bn_shape_ok(_rowmajor(x)) or not bn.track_running_stats or bn.weight is None:
         y = bn(x)
         y = torch.relu(y) if relu else y
@@ -555,12 +635,16 @@ def bn_act(x: Tensor, bn: "torch.nn.BatchNorm1d", relu: bool = True, p: float = 
     use_batch = training  # nn.BatchNorm1d: batch statistics in training mode, running statistics in eval mode
     if use_batch:
         lib, dev = _lib.load(), x.device
-        mean = torch.empty(C, dtype=torch.float32, device=dev)
-        var = torch.empty(C, dtype=torch.float32, device=dev)
-        nws = lib.egnn_bn_ws_floats(C)
-        ws = torch.empty(nws, dtype=torch.float32, device=dev)
-        _lib.check(lib.egnn_bn_stats_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(ws), nws, _lib.stream()),
-                   "egnn_bn_stats_f32")
+        pre = getattr(x_in, "_egnn_bn_stats", None)   # formed in the producing aggregation's epilogue (ops.spmm)
+        if pre is not None and pre[0].shape[0] == C:
+            mean, var = pre
+        else:
+            mean = torch.empty(C, dtype=torch.float32, device=dev)
+            var = torch.empty(C, dtype=torch.float32, device=dev)
+            nws = lib.egnn_bn_ws_floats(C)
+            ws = torch.empty(nws, dtype=torch.float32, device=dev)
+            _lib.check(lib.egnn_bn_stats_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(ws), nws, _lib.stream()),
+                       "egnn_bn_stats_f32")
         with torch.no_grad():
             bn.num_batches_tracked += 1
             m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)

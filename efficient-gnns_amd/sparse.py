@@ -24,6 +24,7 @@ import os
 SHORT_ROW_MAX = int(os.environ.get("EGNN_SHORT_ROW_MAX", "64"))    # rows up to this length share a wavefront
 LONG_ROW_THRESHOLD = int(os.environ.get("EGNN_LONG_ROW_MIN", "512"))  # rows above it get a 16-wave workgroup
 SEG_MAX = int(os.environ.get("EGNN_SPMM_SEG_MAX", "64"))   # entries per range of the segment schedule
+BLK_ROWS = int(os.environ.get("EGNN_SPMM_BLK_ROWS", "32"))  # rows per workgroup of the row-block schedule (multiple of 32)
 PLAN_CHUNK = int(os.environ.get("EGNN_PLAN_CHUNK", "1"))  # >1: length-sort short rows inside chunks of this many rows (measured slower: locality wins)
 
 
@@ -280,6 +281,63 @@ class SparseTensor:
                 seg = direct.contiguous()
             self._struct["segplan"] = (seg, multi.contiguous(), cptr.contiguous(), slots)
         return self._struct["segplan"]
+
+    def _blk_plan(self):
+        """Hub part of the row-block schedule (egnn_spmm_csr_blk_f32), cached per structure:
+        (hub_seg int32 [n_hseg,4] = (first entry, end entry, partial slot, 0), hub_rows int64, comb_ptr int64, slots).
+        Rows with more than SEG_MAX entries are cut into equal ranges of at most SEG_MAX entries (as in _seg_plan); every
+        other row is written directly by the block kernel and needs no list."""
+        if "blkplan" not in self._struct:
+            rp = self._rowptr
+            dev = rp.device
+            cnt = rp[1:] - rp[:-1]
+            multi = torch.nonzero(cnt > SEG_MAX).view(-1)
+            if multi.numel() > 0:
+                c = cnt[multi]
+                nseg = (c + SEG_MAX - 1) // SEG_MAX
+                cptr = torch.zeros(multi.numel() + 1, dtype=torch.int64, device=dev)
+                torch.cumsum(nseg, 0, out=cptr[1:])
+                slots = int(cptr[-1])
+                owner = torch.repeat_interleave(torch.arange(multi.numel(), device=dev), nseg)
+                k = torch.arange(slots, device=dev) - cptr[owner]
+                cs, ss, base = c[owner], nseg[owner], rp[multi][owner]
+                hseg = torch.stack([base + (k * cs) // ss, base + ((k + 1) * cs) // ss, torch.arange(slots, device=dev),
+                                    torch.zeros(slots, dtype=torch.int64, device=dev)], dim=1).to(torch.int32).contiguous()
+            else:
+                cptr = torch.zeros(1, dtype=torch.int64, device=dev)
+                slots = 0
+                hseg = torch.zeros(0, 4, dtype=torch.int32, device=dev)
+            self._struct["blkplan"] = (hseg, multi.contiguous(), cptr.contiguous(), slots)
+        return self._struct["blkplan"]
+
+    def stage_diagonal_blocks(self, rows_per_blk: int | None = 256) -> "SparseTensor":
+        """Opt-in for graphs whose node order has locality (communities stored contiguously): the row-block aggregation
+        stages every block's own X rows in LDS and serves the block's intra-block entries from there (csrc/spmm_blk.hip,
+        north_star's "LDS staging of neighbour feature tiles").  ``rows_per_blk``: 128 / 256 / 384 / 512; ``None`` switches it
+        off.  Measured on the synthetic community graph (41 % of the entries intra-block at 512 rows) it does NOT pay on
+        MI355X -- 373 vs 295 us at K = 256 (profiles/r02_spmm_lab.md) -- so nothing enables it by default."""
+        if rows_per_blk is None:
+            self._struct.pop("locality", None)
+            return self
+        if rows_per_blk % 128 != 0 or not 128 <= rows_per_blk <= 512 or self._sizes[0] != self._sizes[1]:
+            raise ValueError("stage_diagonal_blocks: square adjacency and rows_per_blk in {128, 256, 384, 512}")
+        rowptr, col, bits = self._index_arrays()
+        if bits != 32:
+            raise ValueError("stage_diagonal_blocks needs int32-addressable structure")
+        win = torch.empty(self._sizes[0], 2, dtype=torch.int32, device=self.device)
+        _lib.check(_lib.load().egnn_spmm_blk_window_i32(_lib.ptr(rowptr), _lib.ptr(col), self._sizes[0], rows_per_blk, None, 0, _lib.ptr(win),
+                                                        _lib.stream()), "egnn_spmm_blk_window_i32")
+        self._struct["locality"] = (rows_per_blk, win)
+        return self
+
+    def _scratch(self, key, shape, dtype=torch.float32) -> Tensor:
+        """Per-structure scratch buffers of the aggregation (hub partial slots, statistics partials): allocated once per
+        (purpose, shape, stream) instead of on every call; calls on one stream are ordered, so reuse is safe."""
+        k = ("scratch", key, tuple(shape), dtype, torch.cuda.current_stream().cuda_stream)
+        buf = self._struct.get(k)
+        if buf is None:
+            buf = self._struct[k] = torch.empty(*shape, dtype=dtype, device=self.device)
+        return buf
 
     def _inv_rowcount(self) -> Tensor:
         if "invcnt" not in self._struct:

@@ -29,7 +29,7 @@ def _patch_ops_with_oracle():
         rowptr, col, val = adj.csr()
         return OS.SparseTensor(rowptr=rowptr, col=col, value=val, sparse_sizes=adj.sparse_sizes())
 
-    ops.spmm = lambda adj, x, reduce="sum", bias=None: OS.matmul(to_oracle(adj), x, reduce) + (0 if bias is None else bias)
+    ops.spmm = lambda adj, x, reduce="sum", bias=None, **_: OS.matmul(to_oracle(adj), x, reduce) + (0 if bias is None else bias)
     ops.take_rows = lambda x, idx: x[idx]
     ops.matmul = lambda x, w, bias=None: x @ w if bias is None else x @ w + bias
     ops.linear = lambda x, w, b=None: F.linear(x, w, b)

@@ -153,7 +153,7 @@ def _host_layer_worker(q, gnn, mode):
         g = OS.gcn_norm_sparse(to_oracle(adj))
         return E.SparseTensor(rowptr=g.csr()[0], col=g.csr()[1], value=g.csr()[2], sparse_sizes=g.sparse_sizes())
     PN.gcn_norm = gcn_norm
-    ops.spmm = lambda adj, x, reduce="sum", bias=None: OS.matmul(to_oracle(adj), x, reduce) + (0 if bias is None else bias)
+    ops.spmm = lambda adj, x, reduce="sum", bias=None, **_: OS.matmul(to_oracle(adj), x, reduce) + (0 if bias is None else bias)
     ops.matmul = lambda x, w, bias=None: x @ w if bias is None else x @ w + bias
     ops.linear = lambda x, w, b=None: F.linear(x, w, b)
     ops.take_rows = lambda x, idx: x[idx]
@@ -197,6 +197,12 @@ def test_reference_train_loop_drives_the_host_layer_on_cpu(gnn, mode):
     q = ctx.SimpleQueue()
     p = ctx.Process(target=_host_layer_worker, args=(q, gnn, mode))
     p.start()
+    import time
+    t0 = time.time()
+    while q.empty():   # a child that died (e.g. a stand-in out of date with the host layer) must fail the test, not hang it
+        assert p.is_alive() or not q.empty(), f"worker exited with {p.exitcode} before reporting"
+        assert time.time() - t0 < 600, "worker timed out"
+        time.sleep(0.2)
     losses, out0, accs0, init = q.get()
     p.join(300)
     assert p.exitcode == 0

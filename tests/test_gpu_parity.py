@@ -183,6 +183,97 @@ def test_spmm_rectangular_mag_style_mean():
     close(p.matmul(x.to(DEV), reduce="mean"), o.matmul(x, reduce="mean"))
 
 
+@pytest.mark.parametrize("schedule", ["blocks", "segments", "classes"])
+@pytest.mark.parametrize("K", [64, 100, 128, 256])
+def test_spmm_schedules_agree_with_oracle(schedule, K, monkeypatch):
+    """The three schedules of the aggregation (row blocks + hub segments in one launch = the default; round-1 segments;
+    row classes) on a graph with empty rows, duplicates and hubs, values / src-scale / bias / mean."""
+    monkeypatch.setattr(ops, "_SPMM_SCHEDULE", schedule)
+    n = 1500
+    row, col = random_csr(n, n, 11, seed=K, hubs=((2, 2100), (1499, 700), (640, 65)), dup=True)
+    g = torch.Generator().manual_seed(K)
+    val = torch.rand(row.numel(), generator=g) + 0.1
+    o, p = make_pair(row, col, val, (n, n))
+    x = torch.randn(n, K, generator=g)
+    bias = torch.randn(K, generator=g)
+    for reduce in ("sum", "mean"):
+        y, _ = ops.spmm_raw(p, x.to(DEV), reduce, bias=bias.to(DEV))
+        close(y, o.matmul(x, reduce) + bias, msg=f"{schedule} K={K} {reduce}")
+    scale = torch.rand(n, generator=g) + 0.5
+    y, _ = ops.spmm_raw(p, x.to(DEV), "sum", src_scale=scale.to(DEV))
+    close(y, o.matmul(x * scale[:, None], "sum"), msg=f"{schedule} src_scale")
+    y1, _ = ops.spmm_raw(p, x.to(DEV), "sum")
+    y2, _ = ops.spmm_raw(p, x.to(DEV), "sum")
+    assert torch.equal(y1, y2), "fixed summation order => run-to-run bit-stable"
+
+
+@pytest.mark.parametrize("K,reduce", [(256, "sum"), (64, "mean"), (128, "sum")])
+def test_spmm_epilogue_statistics_match_a_pass_over_the_result(K, reduce):
+    """BatchNorm statistics formed in the aggregation's epilogue (arxiv_pyg/gnn.py:47-48): column mean / biased variance of
+    ALL rows of Y (block rows + hub rows) against torch on the result, for few and for many (> 128) row blocks."""
+    for n in (900, 9000):
+        row, col = random_csr(n, n, 9, seed=n + K, hubs=((1, 1300), (n - 1, 300)))
+        g = torch.Generator().manual_seed(K)
+        val = torch.rand(row.numel(), generator=g) + 0.1 if reduce == "sum" else None
+        o, p = make_pair(row, col, val, (n, n))
+        x = torch.randn(n, K, generator=g) + 0.7
+        bias = torch.randn(K, generator=g)
+        shift = (torch.randn(K, generator=g) * 0.1).to(DEV)
+        y, _, (mean, var) = ops.spmm_raw(p, x.to(DEV), reduce, bias=bias.to(DEV), stat_shift=shift, want_stats=True)
+        y_plain, _ = ops.spmm_raw(p, x.to(DEV), reduce, bias=bias.to(DEV))
+        assert torch.equal(y, y_plain), "the statistics epilogue must not change the result"
+        close(mean, y.double().mean(0), rtol=1e-5)
+        close(var, y.double().var(0, unbiased=False), rtol=2e-5)
+        y2, _, (mean2, var2) = ops.spmm_raw(p, x.to(DEV), reduce, bias=bias.to(DEV), stat_shift=None, want_stats=True)
+        close(mean2, y.double().mean(0), rtol=1e-5)
+        close(var2, y.double().var(0, unbiased=False), rtol=1e-4)
+        assert torch.equal(ops.spmm_raw(p, x.to(DEV), reduce, bias=bias.to(DEV), want_stats=True)[2][0], mean2), "deterministic"
+
+
+def test_gcn_layer_with_epilogue_statistics_trains_like_the_separate_pass(monkeypatch):
+    """GCN.forward hands BatchNorm the statistics of the aggregation epilogue: same losses / gradients as with the
+    separate egnn_bn_stats_f32 pass (within fp32 rounding of the two summation orders)."""
+    d = D.arxiv_like(scale=0.02, seed=4)
+    dev_args = (d.x.to(DEV), d.adj_t.to(DEV))
+    torch.manual_seed(0)
+    m1 = PM.GCN(d.num_features, 64, d.num_classes, 3, 0.0).to(DEV)
+    m2 = PM.GCN(d.num_features, 64, d.num_classes, 3, 0.0).to(DEV)
+    m2.load_state_dict(m1.state_dict())
+    m1.train(), m2.train()
+    out1 = m1(*dev_args)
+    monkeypatch.setattr(ops, "_SPMM_SCHEDULE", "segments")   # no statistics epilogue there: bn_act runs its own pass
+    out2 = m2(*dev_args)
+    close(out1, out2, rtol=1e-5)
+    close(m1.bns[1].running_var, m2.bns[1].running_var, rtol=1e-5)
+    out1.square().mean().backward()
+    out2.square().mean().backward()
+    for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        close(a.grad, b.grad, rtol=1e-4, atol_scale=1e-5, msg=k)
+
+
+@pytest.mark.parametrize("rows_per_blk", [128, 256, 512])
+def test_spmm_lds_staged_diagonal_blocks_opt_in(rows_per_blk):
+    """SparseTensor.stage_diagonal_blocks (LDS-DMA staging of a block's own source rows; opt-in) on the community graph in
+    community order: same result as the oracle, with hub rows, and the in-block ranges are exactly the entries whose column
+    lies in the row's block."""
+    d = D.arxiv_like(scale=0.05, seed=3, with_teacher=False, graph="local-sorted")
+    rowptr, col, _ = d.adj_t.csr()
+    n = d.num_nodes
+    o = OS.SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(n, n))
+    p = d.adj_t.to(DEV).stage_diagonal_blocks(rows_per_blk)
+    R, win = p._struct["locality"]
+    rows = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+    inblk = (col // R) == (rows // R)
+    cnt_in = torch.zeros(n, dtype=torch.int64).index_add_(0, rows, inblk.long())
+    w = win.cpu().long()
+    assert torch.equal(w[:, 1] - w[:, 0], cnt_in), "window ranges = the intra-block entries, bit-exact"
+    x = torch.randn(n, 96 if rows_per_blk == 128 else 256)
+    for reduce in ("sum", "mean"):
+        close(p.matmul(x.to(DEV), reduce), o.matmul(x, reduce), msg=reduce)
+    p.stage_diagonal_blocks(None)
+    close(p.matmul(x.to(DEV), "sum"), o.matmul(x, "sum"))
+
+
 def test_spmm_full_size_properties():
     """BASELINE.json size (N=169 343, ~2.3 M nnz): size-independent properties instead of the oracle."""
     d = D.arxiv_like(1.0, seed=0, with_teacher=False)

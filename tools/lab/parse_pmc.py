@@ -19,7 +19,7 @@ for f in sorted(glob.glob(os.path.join(d, "*.csv"))):
         group = g2 + "_" + group
     per = {}
     for r in csv.DictReader(open(f)):
-        m = re.search(r"(spmm_\w+|bn_\w+)", r["Kernel_Name"])
+        m = re.search(r"(spmm_\w+|bn_\w+|copyBuffer\w*)", r["Kernel_Name"])
         kn = m.group(1) if m else r["Kernel_Name"][:40]
         k = per.setdefault(kn, {})
         k.setdefault("_disp", set()).add(r["Dispatch_Id"])

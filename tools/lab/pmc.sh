@@ -22,7 +22,7 @@ for g in ${@:-$GROUPS_ALL}; do
   (cd /tmp && timeout 120 rocprofv3 --pmc ${G[$g]} --kernel-trace --output-format csv -d $d -o p -- $R/tools/lab/spmm_lab $R/tools/lab/data/$GRAPH.bin 256 --exact $VAR --pmc > $OUT/${GRAPH}_${VAR}_$g.log 2>&1)
   rc=$?
   f=$(find $d -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then grep -E "Counter_Name|spmm|bn_stats" $f > $OUT/${GRAPH}_${VAR}_$g.csv; fi
+  if [ -n "$f" ]; then grep -E "Counter_Name|spmm|bn_stats|copyBuffer" $f > $OUT/${GRAPH}_${VAR}_$g.csv; fi
   echo "pmc $GRAPH $VAR $g rc=$rc rows=$(wc -l < $OUT/${GRAPH}_${VAR}_$g.csv 2>/dev/null)"
   rm -rf $d
 done

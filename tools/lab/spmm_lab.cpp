@@ -137,6 +137,8 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_y, (size_t)n * K * 4));
   CK(hipMalloc(&d_partial, std::max<size_t>(sp.slots, 1) * K * 4));
   CK(hipMalloc(&d_stat, (size_t)(n / 32 + 2) * 2 * K * 4));
+  float* d_fold = nullptr;
+  CK(hipMalloc(&d_fold, egnn_bn_stats_merge_ws_floats(K) * 4));
   CK(hipMalloc(&d_mean, K * 4));
   CK(hipMalloc(&d_var, K * 4));
   std::vector<float> hshift(K, 0.05f);
@@ -170,6 +172,7 @@ int main(int argc, char** argv) {
   for (int R : {32, 64, 128})
     for (int fl : {0, 4})
       vars.push_back({"blk_R" + std::to_string(R) + "_f" + std::to_string(fl), 1, R, fl, false, false, false});
+  vars.push_back({"default", 1, 32, 4, false, false, false});   // what ops.spmm_raw launches (EGNN_SPMM_BLK_ROWS = 32, sc1 stores)
   vars.push_back({"blk_R32_f0_stats", 1, 32, 0, false, true, false});
   vars.push_back({"blk_R64_f0_stats", 1, 64, 0, false, true, false});
   vars.push_back({"blk_R128_f0_stats", 1, 128, 0, false, true, false});
@@ -180,6 +183,14 @@ int main(int argc, char** argv) {
     }
   if (K % 32 == 0) vars.push_back({"lds_R512_f0_stats", 1, 512, 0, true, true, false});
 
+  if (pmc) {   // calibration for FETCH_SIZE / WRITE_SIZE: two 256 MiB device-to-device copies (known bytes) in the same pass
+    void *ca = nullptr, *cb = nullptr;
+    CK(hipMalloc(&ca, 256u << 20));
+    CK(hipMalloc(&cb, 256u << 20));
+    CK(hipMemsetAsync(ca, 1, 256u << 20, st));
+    for (int i = 0; i < 2; ++i) CK(hipMemcpyAsync(cb, ca, 256u << 20, hipMemcpyDeviceToDevice, st));
+    CK(hipStreamSynchronize(st));
+  }
   std::vector<float> hy((size_t)n * K);
   for (const Variant& v : vars) {
     if (only && (exact ? v.name != only : v.name.find(only) == std::string::npos)) continue;
@@ -230,7 +241,8 @@ int main(int argc, char** argv) {
                                    d_cptr, (int64_t)sp.crow.size(), d_partial, sp.slots, st);
       if (rc) return rc;
       if (v.stats)
-        rc = egnn_bn_stats_merge_f32(d_stat, nb, K, d_y, K, d_crow, (int64_t)sp.crow.size(), d_shift, n, d_mean, d_var, st);
+        rc = egnn_bn_stats_merge_f32(d_stat, nb, K, d_y, K, d_crow, (int64_t)sp.crow.size(), d_shift, n, d_mean, d_var, d_fold,
+                                     egnn_bn_stats_merge_ws_floats(K), st);
       return rc;
     };
     CK(hipMemsetAsync(d_y, 0xFF, (size_t)n * K * 4, st));  // NaN pattern: an unwritten row cannot pass the check
