@@ -55,6 +55,10 @@ def parse():
     ap.add_argument("--cpu-epochs", type=int, default=10, help="CPU-oracle epochs timed for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-warmup", type=int, default=3, help="untimed CPU-oracle warm-up epochs (BASELINE.md section 3: >= 3)")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size GPU-vs-oracle parity step")
+    ap.add_argument("--graph", default="on", choices=["on", "off"],
+                    help="on: the epoch (train step + eval) is captured once as a hipGraph and replayed (models.GraphedEpoch); "
+                         "off: eager launches")
+    ap.add_argument("--probe-epochs", type=int, default=5, help="eager epochs with per-kernel HIP-event brackets for the roofline objects")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the node-range sharded (multi-GPU) code path even with one rank: RCCL init, halo plan, "
@@ -84,7 +88,8 @@ def build_problem(M, data, device, args, hp, dropout=None):
         groups += [{"params": sp.parameters(), "lr": MODEL["lr"]}, {"params": tp.parameters(), "lr": MODEL["lr"]}]
     # the single-kernel (fused) implementation of the same torch.optim.Adam update (gnn.py:308-312); EGNN_ADAM=foreach
     # selects PyTorch's default multi-kernel path
-    opt = torch.optim.Adam(groups, fused=(os.environ.get("EGNN_ADAM", "fused") == "fused"))
+    on_gpu = torch.device(device).type == "cuda"
+    opt = torch.optim.Adam(groups, fused=(on_gpu and os.environ.get("EGNN_ADAM", "fused") == "fused"), capturable=on_gpu)
     return model, sp, tp, opt
 
 
@@ -295,8 +300,18 @@ def main():
     seed_all(args.seed)
     model, sp, tp, opt = build_problem(PM, d, device, args, hp)
 
-    for _ in range(args.warmup):
-        epoch(PM, model, d, opt, args, hp, sp, tp, edge_index)
+    graphed, graph_note = None, "off"
+    if args.graph == "on":
+        try:   # capture the epoch once (its constructor runs the warm-up steps); any capture problem falls back to eager launches
+            graphed = PM.GraphedEpoch(model, d.x, d.adj_t, d.y, d.split_idx["train"], opt, args.training, hp, d.teacher_out_feat,
+                                      d.teacher_logits, sp, tp, edge_index, split_idx=d.split_idx, warmup=max(args.warmup, 3))
+            graph_note = "hipGraph replay of train step + eval (models.GraphedEpoch)"
+        except Exception as e:  # noqa: BLE001
+            graph_note = f"capture failed, eager launches: {type(e).__name__}: {str(e)[:200]}"
+            graphed = None
+    if graphed is None:
+        for _ in range(args.warmup):
+            epoch(PM, model, d, opt, args, hp, sp, tp, edge_index)
     # keep generation-2 garbage collections (a ~40 ms walk over the ~170k objects the imports leave behind) out of the
     # training loop: freeze what survived set-up, as a long-running trainer would
     import gc
@@ -306,25 +321,38 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     train_ms = eval_ms = 0.0
     from efficient_gnns_amd import _lib as _egnn_lib
+    if graphed is not None:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            losses, accs = graphed.step()      # one replay + one device->host read per epoch
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    # per-kernel brackets (HIP events on the launch stream) need eager launches: with a graph the timed region above has no
+    # per-kernel events, so the roofline objects are measured on `probe_epochs` eager epochs of the same problem right after
+    # it; without a graph they are measured over the timed region itself
+    n_probe = args.probe_epochs if graphed is not None else args.steps
     with SpmmProbe(ops) as probe, NceProbe(_egnn_lib.load()) as nce_probe:
         probe.active = True
         nce_probe.active = True
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+        t1 = time.perf_counter()
+        for _ in range(n_probe):
             ev[0].record()
-            losses = PM.train_step(model, d.x, d.adj_t, d.y, d.split_idx["train"], opt, args.training, hp,
-                                   d.teacher_out_feat, d.teacher_logits, sp, tp, edge_index)
+            l2 = PM.train_step(model, d.x, d.adj_t, d.y, d.split_idx["train"], opt, args.training, hp,
+                               d.teacher_out_feat, d.teacher_logits, sp, tp, edge_index)
             ev[1].record()
-            _, accs = PM.evaluate(model, d.x, d.adj_t, d.y, d.split_idx)
+            _, a2 = PM.evaluate(model, d.x, d.adj_t, d.y, d.split_idx)
             ev[2].record()
             ev[2].synchronize()
             train_ms += ev[0].elapsed_time(ev[1])
             eval_ms += ev[1].elapsed_time(ev[2])
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        eager_elapsed = time.perf_counter() - t1
         probe.active = False
         nce_probe.active = False
+    if graphed is None:
+        elapsed, losses, accs = eager_elapsed, l2, a2
     K = MODEL["hidden"]
     roof = probe.summary(K)
     roofline = None
@@ -357,8 +385,8 @@ def main():
         roofline_mfma = dict(bound="mfma", kernel="nce_fwd_kernel + nce_bwd_kernel x2 + split-K reduce (egnn_nce_fwd_f32, egnn_nce_bwd_f32): "
                                                   "the G-CRD loss, largest share of the step", achieved=round(tf, 1), peak=157.3,
                              unit="TFLOP/s", frac=round(tf / 157.3, 4), dtype="f32 (v_mfma_f32_32x32x2_f32)",
-                             flops_per_step=int(nsum["flops"] / max(1, args.steps)),
-                             ms_per_step=round(1e3 * nsum["secs"] / max(1, args.steps), 3), calls_timed=nsum["calls"])
+                             flops_per_step=int(nsum["flops"] / max(1, n_probe)),
+                             ms_per_step=round(1e3 * nsum["secs"] / max(1, n_probe), 3), calls_timed=nsum["calls"])
     cpu = cpu_baseline(args, data, hp) if args.cpu_epochs > 0 else None
 
     out = dict(
@@ -377,7 +405,10 @@ def main():
                     memoise_first_layer_aggregation=os.environ.get("EGNN_GCN_MEMOISE_AX", "0") == "1",
                     cache_constant_row_gathers=os.environ.get("EGNN_CACHE_CONST_ROWS", "0") == "1"),
         roofline=roofline, roofline_mfma=roofline_mfma, cpu_baseline=cpu, parity=parity,
-        phases_ms=dict(train_step=round(train_ms / args.steps, 3), eval=round(eval_ms / args.steps, 3)),
+        launch=graph_note,
+        eager=dict(epochs_per_s=round(n_probe / eager_elapsed, 3), epochs=n_probe,
+                   note="eager launches with per-kernel event brackets (where the roofline objects are measured)"),
+        phases_ms=dict(train_step=round(train_ms / max(1, n_probe), 3), eval=round(eval_ms / max(1, n_probe), 3)),
         last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs],
     )
     if cpu:

@@ -23,6 +23,7 @@ SIGNATURES = {
     "egnn_spmm_csr_seg_f32": (_i32, [_i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p]),
     "egnn_spmm_csr_blk_f32": (_i32, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i64, _p,
                                      _p, _p, _i32, _p]),
+    "egnn_spmm_blk_stat_rows": (_i64, [_i64, _i32, _i32]),
     "egnn_spmm_blk_window_i32": (_i32, [_p, _p, _i64, _i32, _p, _i64, _p, _p]),
     "egnn_bn_stats_merge_ws_floats": (_sz, [_i64]),
     "egnn_bn_stats_merge_f32": (_i32, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _sz, _p]),
@@ -66,12 +67,12 @@ SIGNATURES = {
     "egnn_segment_sum_f32": (_i32, [_p, _p, _i64, _p, _p]),
     "egnn_bn_ws_floats": (_sz, [_i64]),
     "egnn_bn_stats_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),
-    "egnn_bn_act_fwd_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _i64, _p]),
-    "egnn_bn_act_bwd_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _i32, _p, _p, _p, _i64,
+    "egnn_bn_act_fwd_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _i64, _p]),
+    "egnn_bn_act_bwd_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _i32, _p, _p, _p, _i64,
                                    _p, _sz, _p]),
     "egnn_bn_merge_shards_f32": (_i32, [_p, _i32, _i64, _p, _p, _p, _p]),
-    "egnn_bn_act_bwd_reduce_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _p, _sz, _p]),
-    "egnn_bn_act_bwd_apply_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _f32, _p, _i64, _p]),
+    "egnn_bn_act_bwd_reduce_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _p, _p, _sz, _p]),
+    "egnn_bn_act_bwd_apply_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _p, _f32, _p, _i64, _p]),
 }
 
 _lib = None

@@ -17,10 +17,18 @@ __all__ = ["kd_criterion", "fitnet_criterion", "at_criterion", "gpw_criterion", 
            "loss_kd_only", "ppi_kd_criterion"]
 
 
+# Optional override of the sampled-row source: ``callable(n, max_samples, device) -> int64 device tensor | None``.
+# models.GraphedEpoch installs one that returns a STATIC device buffer (refilled from the same NumPy draw before every
+# replay), because a captured hipGraph cannot contain the host-side draw + upload.
+_ROW_SAMPLER = None
+
+
 def _sample_rows(n: int, max_samples: int, device):
     """criterion.py:62-65,134-137: host NumPy global RNG, exactly one draw; None = keep every row.
     (Making the draw earlier in the step -- before the forward, or at the end of the previous step -- was measured:
     no gain, the step is GPU-bound around it.)"""
+    if _ROW_SAMPLER is not None:
+        return _ROW_SAMPLER(n, max_samples, device)
     if max_samples < n:
         pick = np.random.choice(n, max_samples, replace=False)
         return torch.from_numpy(pick).to(device=device, dtype=torch.int64, non_blocking=True)

@@ -19,6 +19,7 @@ struct BnParams {
   const float* mean; const float* var; float eps;
   const float* gamma; const float* beta;
   int relu; float p; unsigned long long seed;
+  const unsigned long long* seed_dev;   // nullable: added to `seed` (a per-step value kept on the device: hipGraph replays)
 };
 
 // counter-based uniform in [0,1): splitmix64 of (seed + element index)
@@ -37,7 +38,7 @@ __device__ __forceinline__ void bn_elem(const BnParams& q, float x, float mean, 
   const float pre = g * xhat + b;
   gate = (q.relu && !(pre > 0.f)) ? 0.f : 1.f;
   if (q.p > 0.f) {
-    const float u = uniform01(q.seed, (unsigned long long)(row * q.C + c));
+    const float u = uniform01(q.seed + (q.seed_dev ? *q.seed_dev : 0ull), (unsigned long long)(row * q.C + c));
     gate = u >= q.p ? gate / (1.f - q.p) : 0.f;
   }
 }
@@ -307,24 +308,24 @@ extern "C" int egnn_bn_stats_f32(const float* x, int64_t ld, int64_t n, int64_t 
 }
 
 extern "C" int egnn_bn_act_fwd_f32(const float* x, int64_t ld, int64_t n, int64_t C, const float* mean, const float* var, float eps,
-                                   const float* gamma, const float* beta, int relu, float p, uint64_t seed, float* y,
-                                   int64_t ldy, void* stream) {
+                                   const float* gamma, const float* beta, int relu, float p, uint64_t seed,
+                                   const uint64_t* seed_dev, float* y, int64_t ldy, void* stream) {
   EGNN_CHECK_ARG(n > 0 && x && mean && var && y && ld >= C && ldy >= C && p >= 0.f && p < 1.f);
   if (!shape_ok(x, ld, C) || !shape_ok(y, ldy, C)) return EGNN_EALIGN;
-  const BnParams q{x, ld, n, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed};
+  const BnParams q{x, ld, n, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed, (const unsigned long long*)seed_dev};
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(row_blocks(n)), dim3(256), 0, (hipStream_t)stream, q, y, ldy);
   return egnn_launch_status();
 }
 
 extern "C" int egnn_bn_act_bwd_reduce_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
                                           const float* mean, const float* var, float eps, const float* gamma, const float* beta,
-                                          int relu, float p, uint64_t seed, float* dgamma, float* dbeta, float* ws,
-                                          size_t ws_floats, void* stream) {
+                                          int relu, float p, uint64_t seed, const uint64_t* seed_dev, float* dgamma, float* dbeta,
+                                          float* ws, size_t ws_floats, void* stream) {
   EGNN_CHECK_ARG(n > 0 && x && dy && mean && var && dgamma && dbeta && ws && ld >= C && ld_dy >= C);
   if (!shape_ok(x, ld, C) || !shape_ok(dy, ld_dy, C)) return EGNN_EALIGN;
   if (ws_floats < egnn_bn_ws_floats(C)) return EGNN_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
-  const BnParams q{x, ld, n, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed};
+  const BnParams q{x, ld, n, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed, (const unsigned long long*)seed_dev};
   const int64_t want = (n + 3) / 4;
   const int nb = (int)(want < kStatBlocks ? want : kStatBlocks);
   hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nb), dim3(256), 0, st, q, dy, ld_dy, ws);
@@ -334,11 +335,11 @@ extern "C" int egnn_bn_act_bwd_reduce_f32(const float* x, int64_t ld, const floa
 
 extern "C" int egnn_bn_act_bwd_apply_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
                                          const float* mean, const float* var, float eps, const float* gamma, const float* beta,
-                                         int relu, float p, uint64_t seed, const float* sum_dbeta, const float* sum_dgamma,
-                                         float inv_count, float* dx, int64_t ld_dx, void* stream) {
+                                         int relu, float p, uint64_t seed, const uint64_t* seed_dev, const float* sum_dbeta,
+                                         const float* sum_dgamma, float inv_count, float* dx, int64_t ld_dx, void* stream) {
   EGNN_CHECK_ARG(n > 0 && x && dy && mean && var && sum_dbeta && sum_dgamma && dx && ld >= C && ld_dy >= C && ld_dx >= C);
   if (!shape_ok(x, ld, C) || !shape_ok(dy, ld_dy, C) || !shape_ok(dx, ld_dx, C)) return EGNN_EALIGN;
-  const BnParams q{x, ld, n, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed};
+  const BnParams q{x, ld, n, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed, (const unsigned long long*)seed_dev};
   hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(row_blocks(n)), dim3(256), 0, (hipStream_t)stream, q, dy, ld_dy, sum_dbeta,
                      sum_dgamma, inv_count, dx, ld_dx);
   return egnn_launch_status();
@@ -346,12 +347,12 @@ extern "C" int egnn_bn_act_bwd_apply_f32(const float* x, int64_t ld, const float
 
 extern "C" int egnn_bn_act_bwd_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
                                    const float* mean, const float* var, float eps, const float* gamma, const float* beta, int relu,
-                                   float p, uint64_t seed, int batch_stats, float* dgamma, float* dbeta, float* dx, int64_t ld_dx,
-                                   float* ws, size_t ws_floats, void* stream) {
+                                   float p, uint64_t seed, const uint64_t* seed_dev, int batch_stats, float* dgamma, float* dbeta,
+                                   float* dx, int64_t ld_dx, float* ws, size_t ws_floats, void* stream) {
   EGNN_CHECK_ARG(dx && ld_dx >= C);
-  const int rc = egnn_bn_act_bwd_reduce_f32(x, ld, dy, ld_dy, n, C, mean, var, eps, gamma, beta, relu, p, seed, dgamma, dbeta, ws,
-                                            ws_floats, stream);
+  const int rc = egnn_bn_act_bwd_reduce_f32(x, ld, dy, ld_dy, n, C, mean, var, eps, gamma, beta, relu, p, seed, seed_dev, dgamma, dbeta,
+                                            ws, ws_floats, stream);
   if (rc != EGNN_OK) return rc;
-  return egnn_bn_act_bwd_apply_f32(x, ld, dy, ld_dy, n, C, mean, var, eps, gamma, beta, relu, p, seed, dbeta, dgamma,
+  return egnn_bn_act_bwd_apply_f32(x, ld, dy, ld_dy, n, C, mean, var, eps, gamma, beta, relu, p, seed, seed_dev, dbeta, dgamma,
                                    batch_stats ? 1.f / (float)n : 0.f, dx, ld_dx, stream);
 }

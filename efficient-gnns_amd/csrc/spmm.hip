@@ -518,7 +518,7 @@ int launch_segments(SpmmArgs<IdxT> a, const int64_t* seg, int64_t n_seg, const i
     a.logG = ilog2_ceil(kv < 64 ? kv : 64);
     a.NS = (int)((kv + (1 << a.logG) - 1) >> a.logG);
   }
-  if (a.logG != 3 && a.logG != 4) return EGNN_EALIGN;
+  if (n_seg > 0 && a.logG != 3 && a.logG != 4) return EGNN_EALIGN;   // the sub-group kernel's forms; the combine step takes any K % 4 == 0
   a.map_mode = (a.NS <= 8 && 8 % a.NS == 0) ? 1 : (a.NS % 8 == 0 ? 2 : 0);
   a.seg = seg;
   a.P = partial;

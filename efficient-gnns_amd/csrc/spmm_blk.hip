@@ -16,9 +16,11 @@
 //     workgroups, the block's X rows are streamed into LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip,
 //     asynchronous) WHILE the sub-groups gather the rows' out-of-block entries from L2 / fabric; after one barrier the
 //     in-block entries -- a contiguous sub-range of every row, columns being sorted -- are read from LDS (ds_read_b128);
-//   * optional BatchNorm statistics in the epilogue (`stat_part` != NULL, /root/reference/arxiv_pyg/gnn.py:47-48): the
-//     workgroup re-reads the block of Y it has just written (its own L2-resident lines) and leaves shifted column sums
-//     per block, merged in a fixed order by egnn_bn_stats_merge_f32 -- the separate full pass over Y disappears.
+//   * optional BatchNorm statistics in the epilogue (`stat_part` != NULL, /root/reference/arxiv_pyg/gnn.py:47-48): every
+//     wave leaves the shifted column sums of the rows it stored (registers -> a swizzle tree over its sub-groups; no
+//     barrier, no second pass over Y), folded in a fixed order by egnn_bn_stats_merge_f32 -- the separate full pass over
+//     Y disappears.  (Measured alternatives: a workgroup-level reduction costs a barrier per 32 rows, +25 % kernel time;
+//     re-reading the block from L2 likewise.)
 // Accumulation order is fixed by the schedule => run-to-run bit-stable.
 #include "common.h"
 
@@ -48,7 +50,7 @@ struct BlkArgs {
   const int32_t* hseg;     // [n_hseg][4]: (first entry, end entry, partial slot, 0) of the hub-row segments
   int64_t n_hseg;
   float* P;                // [slots][K] partial sums of the hub segments
-  float* stat_part;        // [n_blk][2][K]
+  float* stat_part;        // [n_blk * waves per workgroup][2][K]
   const float* stat_shift; // [K] nullable
   int NS, map_mode;
   uint32_t x_bytes;
@@ -158,7 +160,6 @@ __device__ __forceinline__ void store_row4(float* p, const float4& v, int flags)
 template <bool LDS, bool STATS, int WAVES, int ROWS>
 __global__ __launch_bounds__(WAVES * 64) void spmm_blk_kernel(const BlkArgs a) {
   extern __shared__ float4 sX[];  // LDS variant: rows_per_blk source rows (this slice) + one all-zero row
-  __shared__ float s_stat[2][WAVES * 2][32];
   constexpr int NSUB = WAVES * 8;
   const int lane = egnn_lane();
   const int wave = egnn_wave_id();
@@ -207,6 +208,14 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_blk_kernel(const BlkArgs a) {
   if (row1 > (int)a.n_rows) row1 = (int)a.n_rows;
   const int nrows = row1 - row0;
   float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+  float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};   // STATS: sum (y - shift), sum (y - shift)^2 of my rows
+  auto tally = [&](const float4& y) {
+    float4 sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.stat_shift) sh = *reinterpret_cast<const float4*>(a.stat_shift + col0);
+    const float d0 = y.x - sh.x, d1 = y.y - sh.y, d2 = y.z - sh.z, d3 = y.w - sh.w;
+    st1[0] += d0; st1[1] += d1; st1[2] += d2; st1[3] += d3;
+    st2[0] = fmaf(d0, d0, st2[0]); st2[1] = fmaf(d1, d1, st2[1]); st2[2] = fmaf(d2, d2, st2[2]); st2[3] = fmaf(d3, d3, st2[3]);
+  };
 
   if constexpr (LDS) {
     // phase 0: start streaming the block's X rows into LDS (8 rows = 1 KiB per wave instruction, lane-contiguous)
@@ -259,8 +268,9 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_blk_kernel(const BlkArgs a) {
       }
       if (colok) {
         const float inv = a.mean ? 1.f / (float)(cnt_[j] > 0 ? cnt_[j] : 1) : 1.f;
-        store_row4(a.Y + (int64_t)row * a.ldy + col0,
-                   make_float4(acc[j][0] * inv + bias.x, acc[j][1] * inv + bias.y, acc[j][2] * inv + bias.z, acc[j][3] * inv + bias.w), a.flags);
+        const float4 y = make_float4(acc[j][0] * inv + bias.x, acc[j][1] * inv + bias.y, acc[j][2] * inv + bias.z, acc[j][3] * inv + bias.w);
+        store_row4(a.Y + (int64_t)row * a.ldy + col0, y, a.flags);
+        if constexpr (STATS) tally(y);
       }
     }
   } else {
@@ -276,39 +286,29 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_blk_kernel(const BlkArgs a) {
       if (colok) {
         if (a.bias) bias = *reinterpret_cast<const float4*>(a.bias + col0);   // L1-resident; not held across the gathers
         const float inv = a.mean ? 1.f / (float)(cnt > 0 ? cnt : 1) : 1.f;
-        store_row4(a.Y + (int64_t)row * a.ldy + col0,
-                   make_float4(acc[0] * inv + bias.x, acc[1] * inv + bias.y, acc[2] * inv + bias.z, acc[3] * inv + bias.w), a.flags);
+        const float4 y = make_float4(acc[0] * inv + bias.x, acc[1] * inv + bias.y, acc[2] * inv + bias.z, acc[3] * inv + bias.w);
+        store_row4(a.Y + (int64_t)row * a.ldy + col0, y, a.flags);
+        if constexpr (STATS) tally(y);
       }
     }
   }
 
   if constexpr (STATS) {
-    // The block of Y this workgroup has just written is re-read from its own L2 (write-through L1 of the same CU): thread t
-    // sums column (t & 31) of this slice over rows (t >> 5), (t >> 5) + WAVES*2, ...; the row groups are then added in
-    // index order -- fixed order, no atomics.  Hub rows are not this kernel's (egnn_bn_stats_merge_f32 adds them).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int colc = slice * 32 + c;
-    float s1 = 0.f, s2 = 0.f;
-    if (colc < (int)a.K) {
-      const float sft = a.stat_shift ? a.stat_shift[colc] : 0.f;
-      for (int r = g; r < nrows; r += WAVES * 2) {
-        const int row = row0 + r;
-        if (a.rowptr[row + 1] - a.rowptr[row] > a.seg_max) continue;
-        const float d = __builtin_nontemporal_load(a.Y + (int64_t)row * a.ldy + colc) - sft;
-        s1 += d;
-        s2 = fmaf(d, d, s2);
+    // per-WAVE partials, no barrier and no second pass: the 8 sub-groups of a wave hold the same 4 columns in lanes of
+    // equal `li`; they are added by xor-swizzles over lane bits 3..5 (a fixed tree) and lanes 0..7 write the wave's
+    // [2][32 columns of this slice] shifted sums.  egnn_bn_stats_merge_f32 folds the partials in index order.
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        st1[q] += __shfl_xor(st1[q], o);
+        st2[q] += __shfl_xor(st2[q], o);
       }
     }
-    s_stat[0][g][c] = s1;
-    s_stat[1][g][c] = s2;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      const int which = threadIdx.x >> 5;
-      float t = 0.f;
-      for (int q = 0; q < WAVES * 2; ++q) t += s_stat[which][q][c];
-      if (colc < (int)a.K) a.stat_part[((int64_t)blk * 2 + which) * a.K + colc] = t;
+    if (lane < 8 && colok) {
+      float* sp = a.stat_part + ((int64_t)(blk * WAVES + wave) * 2) * a.K + col0;
+      *reinterpret_cast<float4*>(sp) = make_float4(st1[0], st1[1], st1[2], st1[3]);
+      *reinterpret_cast<float4*>(sp + a.K) = make_float4(st2[0], st2[1], st2[2], st2[3]);
     }
   }
 }
@@ -419,6 +419,11 @@ int launch_blk(const BlkArgs& a, unsigned grid, size_t shm, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int64_t egnn_spmm_blk_stat_rows(int64_t n_rows, int rows_per_blk, int lds) {
+  if (n_rows <= 0 || rows_per_blk <= 0) return 0;
+  return (n_rows + rows_per_blk - 1) / rows_per_blk * (lds ? 16 : 4);   // one partial row per wave of every row block
+}
 
 extern "C" int egnn_spmm_blk_window_i32(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int rows_per_blk,
                                         const int32_t* blk_ptr, int64_t n_blk, int32_t* win, void* stream) {

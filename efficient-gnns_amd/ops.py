@@ -94,7 +94,8 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
         # Y rows are stored write-through (dropped from L2: they are not re-read here and would only evict gathered X
         # lines) unless the statistics epilogue re-reads them
         flags = 0 if want_stats else 4
-        stat_part = adj._scratch("stat", (n_blk, 2, K)) if want_stats else None
+        n_stat = lib.egnn_spmm_blk_stat_rows(n_rows, rows_blk, int(use_lds)) if want_stats else 0
+        stat_part = adj._scratch("stat", (n_stat, 2, K)) if want_stats else None
         if stat_shift is not None:
             stat_shift = stat_shift.detach().contiguous()
         rc = lib.egnn_spmm_csr_blk_f32(n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(adj._value), _lib.ptr(src_scale),
@@ -114,7 +115,7 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
             var = torch.empty(K, dtype=torch.float32, device=x.device)
             nws = lib.egnn_bn_stats_merge_ws_floats(K)
             ws = adj._scratch("statfold", (nws,))
-            _lib.check(lib.egnn_bn_stats_merge_f32(_lib.ptr(stat_part), n_blk, K, _lib.ptr(y), y.stride(0), _lib.ptr(crow), crow.numel(),
+            _lib.check(lib.egnn_bn_stats_merge_f32(_lib.ptr(stat_part), n_stat, K, _lib.ptr(y), y.stride(0), _lib.ptr(crow), crow.numel(),
                                                    _lib.ptr(stat_shift), n_rows, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(ws), nws,
                                                    _lib.stream()), "egnn_bn_stats_merge_f32")
             return y, None, (mean, var)
@@ -583,6 +584,11 @@ def nce_block_bwd(fhat: Tensor, t_all: Tensor, diag_off: int, scale: float, Z: T
 # ------------------------------------------------------------------------------------------------
 # fused BatchNorm1d (+ ReLU + dropout)
 # ------------------------------------------------------------------------------------------------
+# Optional per-step dropout seed kept ON THE DEVICE (int64 [1]): the kernels add it to the per-call host seed.  A captured
+# hipGraph of the train step (models.GraphedEpoch) refreshes it before every replay, so that replays draw fresh masks.
+_DROPOUT_SEED_DEV: Tensor | None = None
+
+
 def _bn_shape_ok(x: Tensor) -> bool:
     C = x.shape[1]
     return x.is_cuda and C % 4 == 0 and C <= 1024 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
@@ -594,11 +600,14 @@ class _BnAct(torch.autograd.Function):
         x = _rowmajor(x)
         n, C = x.shape
         y = torch.empty(n, C, dtype=torch.float32, device=x.device)
+        seed_dev = _DROPOUT_SEED_DEV if p > 0 else None
         rc = _lib.load().egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
-                                             _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(y), y.stride(0), _lib.stream())
+                                             _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(seed_dev), _lib.ptr(y), y.stride(0),
+                                             _lib.stream())
         _lib.check(rc, "egnn_bn_act_fwd_f32")
         ctx.save_for_backward(x, gamma, beta, mean, var)
         ctx.cfg = (float(eps), int(relu), float(p), int(seed), int(batch_stats))
+        ctx.seed_dev = seed_dev
         return y
 
     @staticmethod
@@ -614,7 +623,7 @@ class _BnAct(torch.autograd.Function):
         nws = lib.egnn_bn_ws_floats(C)
         ws = torch.empty(nws, dtype=torch.float32, device=dev)
         rc = lib.egnn_bn_act_bwd_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), eps,
-                                     _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, batch_stats, _lib.ptr(dgamma), _lib.ptr(dbeta),
+                                     _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), batch_stats, _lib.ptr(dgamma), _lib.ptr(dbeta),
                                      _lib.ptr(dx), dx.stride(0), _lib.ptr(ws), nws, _lib.stream())
         _lib.check(rc, "egnn_bn_act_bwd_f32")
         return dx, dgamma, dbeta, None, None, None, None, None, None, None
@@ -687,7 +696,7 @@ class _SyncBnAct(torch.autograd.Function):
         y = torch.empty(n, C, dtype=torch.float32, device=dev)
         if n > 0:
             rc = lib.egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
-                                         _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(y), y.stride(0), _lib.stream())
+                                         _lib.ptr(beta), int(relu), float(p), int(seed), None, _lib.ptr(y), y.stride(0), _lib.stream())
             _lib.check(rc, "egnn_bn_act_fwd_f32")
         ctx.save_for_backward(x, gamma, beta, mean, var, total)
         ctx.cfg = (float(eps), int(relu), float(p), int(seed), group)
@@ -707,7 +716,7 @@ class _SyncBnAct(torch.autograd.Function):
             nws = lib.egnn_bn_ws_floats(C)
             ws = torch.empty(nws, dtype=torch.float32, device=dev)
             rc = lib.egnn_bn_act_bwd_reduce_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var),
-                                                eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(sums[C:]), _lib.ptr(sums),
+                                                eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, None, _lib.ptr(sums[C:]), _lib.ptr(sums),
                                                 _lib.ptr(ws), nws, _lib.stream())
             _lib.check(rc, "egnn_bn_act_bwd_reduce_f32")
         local = sums.clone()                                          # parameter grads stay local (the flat all-reduce sums them)
@@ -716,7 +725,7 @@ class _SyncBnAct(torch.autograd.Function):
         dx = torch.empty_like(x)
         if n > 0:
             rc = lib.egnn_bn_act_bwd_apply_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var),
-                                               eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(sums), _lib.ptr(sums[C:]),
+                                               eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, None, _lib.ptr(sums), _lib.ptr(sums[C:]),
                                                1.0, _lib.ptr(dx), dx.stride(0), _lib.stream())
             _lib.check(rc, "egnn_bn_act_bwd_apply_f32")
         return dx, local[C:], local[:C], None, None, None, None, None

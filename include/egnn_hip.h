@@ -109,8 +109,9 @@ int egnn_spmm_csr_seg_f32(int64_t n_rows, int64_t n_src, int64_t K,
  *              source inside row r's own block.  When given (square adjacency, X rows in node order, rows_per_blk a multiple
  *              of 128, <= 512) the block's X rows are streamed into LDS (LDS-DMA) while the out-of-block entries are
  *              gathered, and the in-block entries read LDS instead of L2 (graphs in a locality order).
- *   stat_part  nullable [n_blk,2,K] fp32: per block sum_r (y_r - shift) and sum_r (y_r - shift)^2 over the rows the block
- *              WROTE -- BatchNorm statistics in the aggregation epilogue (gnn.py:47-48), finished by egnn_bn_stats_merge_f32;
+ *   stat_part  nullable [egnn_spmm_blk_stat_rows(n_rows, rows_per_blk, win != NULL), 2, K] fp32: per WAVE of every row block
+ *              sum_r (y_r - shift) and sum_r (y_r - shift)^2 over the rows that wave stored -- BatchNorm statistics in the
+ *              aggregation epilogue (gnn.py:47-48), finished by egnn_bn_stats_merge_f32 (n_blk = that row count);
  *              stat_shift: nullable [K] (any vector near the column means, e.g. BatchNorm's running_mean; exactness does
  *              not depend on it, only the conditioning of the variance)
  *   flags      bit 1: non-temporal Y stores; bit 2: write-through (sc1) Y stores (tuning knobs, results are identical) */
@@ -120,6 +121,7 @@ int egnn_spmm_csr_blk_f32(int64_t n_rows, int64_t n_src, int64_t K,
                           int seg_max, int rows_per_blk, const int32_t* blk_ptr, int64_t n_blk, const int32_t* win,
                           const int32_t* hub_seg, int64_t n_hub_seg, float* partial,
                           float* stat_part, const float* stat_shift, int flags, void* stream);
+int64_t egnn_spmm_blk_stat_rows(int64_t n_rows, int rows_per_blk, int lds);
 int egnn_spmm_blk_window_i32(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int rows_per_blk,
                              const int32_t* blk_ptr, int64_t n_blk, int32_t* win, void* stream);
 /* mean[c], var[c] (biased) of n_total rows of Y: the block partials of egnn_spmm_csr_blk_f32 plus the rows listed in
@@ -351,7 +353,9 @@ int egnn_gat_attention_fwd_f32(const int64_t* rowptr, const int64_t* col, const 
  * the torch operators for such shapes).
  *   egnn_bn_stats_f32     mean[c], biased var[c] over the n rows (training statistics)
  *   egnn_bn_act_fwd_f32   y = drop_p(relu?(gamma * (x - mean) * rsqrt(var + eps) + beta)); the dropout mask is a
- *                         counter-based hash of (seed, row*C + c): keep if u >= p, kept values scaled 1/(1-p)
+ *                         counter-based hash of (seed + *seed_dev, row*C + c): keep if u >= p, kept values scaled 1/(1-p);
+ *                         seed_dev: nullable device scalar added to `seed` -- a per-step value that lives on the device,
+ *                         so that a captured hipGraph of the step draws a fresh mask on every replay
  *   egnn_bn_act_bwd_f32   recomputes xhat / ReLU sign / mask from x and seed; dgamma, dbeta [C]; dx [n,C];
  *                         batch_stats != 0: mean/var are this batch's statistics (training backward, the
  *                         -(sum d + xhat sum d xhat)/n terms apply); 0: running statistics (eval-mode graph)
@@ -364,12 +368,12 @@ size_t egnn_bn_ws_floats(int64_t C);
 int egnn_bn_stats_f32(const float* x, int64_t ld, int64_t n, int64_t C, float* mean, float* var, float* ws, size_t ws_floats,
                       void* stream);
 int egnn_bn_act_fwd_f32(const float* x, int64_t ld, int64_t n, int64_t C, const float* mean, const float* var, float eps,
-                        const float* gamma, const float* beta, int relu, float p, uint64_t seed, float* y, int64_t ldy,
-                        void* stream);
+                        const float* gamma, const float* beta, int relu, float p, uint64_t seed, const uint64_t* seed_dev,
+                        float* y, int64_t ldy, void* stream);
 int egnn_bn_act_bwd_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C, const float* mean,
                         const float* var, float eps, const float* gamma, const float* beta, int relu, float p, uint64_t seed,
-                        int batch_stats, float* dgamma, float* dbeta, float* dx, int64_t ld_dx, float* ws, size_t ws_floats,
-                        void* stream);
+                        const uint64_t* seed_dev, int batch_stats, float* dgamma, float* dbeta, float* dx, int64_t ld_dx, float* ws,
+                        size_t ws_floats, void* stream);
 
 /* Merge the per-shard statistics of a sharded batch: stats [world, 2C+1] = (mean[C] | biased var[C] | rows) per shard
  * (all-gathered over RCCL), combined in shard order with the pairwise update of Chan et al. (identical on every rank);
@@ -377,11 +381,12 @@ int egnn_bn_act_bwd_f32(const float* x, int64_t ld, const float* dy, int64_t ld_
 int egnn_bn_merge_shards_f32(const float* stats, int world, int64_t C, float* mean, float* var, float* total, void* stream);
 int egnn_bn_act_bwd_reduce_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
                                const float* mean, const float* var, float eps, const float* gamma, const float* beta, int relu,
-                               float p, uint64_t seed, float* dgamma, float* dbeta, float* ws, size_t ws_floats, void* stream);
+                               float p, uint64_t seed, const uint64_t* seed_dev, float* dgamma, float* dbeta, float* ws,
+                               size_t ws_floats, void* stream);
 int egnn_bn_act_bwd_apply_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
                               const float* mean, const float* var, float eps, const float* gamma, const float* beta, int relu,
-                              float p, uint64_t seed, const float* sum_dbeta, const float* sum_dgamma, float inv_count,
-                              float* dx, int64_t ld_dx, void* stream);
+                              float p, uint64_t seed, const uint64_t* seed_dev, const float* sum_dbeta, const float* sum_dgamma,
+                              float inv_count, float* dx, int64_t ld_dx, void* stream);
 
 #ifdef __cplusplus
 }

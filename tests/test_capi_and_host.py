@@ -174,8 +174,8 @@ def test_c_abi_argument_errors_are_reported_before_any_launch():
     assert lib.egnn_nce_bwd_ws_floats(0, 4, 4) == 0 and lib.egnn_nce_bwd_ws_floats(128, 128, 16) >= 128 * 16
     assert lib.egnn_nce_saves_exp(0.075, 1) == 1 and lib.egnn_nce_saves_exp(0.075, 0) == 0 and lib.egnn_nce_saves_exp(0.01, 1) == 0
     # BatchNorm halves: null pointers
-    assert lib.egnn_bn_act_bwd_reduce_f32(None, 4, p, 4, 4, 4, p, p, 1e-5, p, p, 1, 0.0, 0, p, p, p, 1 << 20, None) < 0
-    assert lib.egnn_bn_act_bwd_apply_f32(p, 4, p, 4, 4, 4, p, p, 1e-5, p, p, 1, 0.0, 0, None, p, 1.0, p, 4, None) < 0
+    assert lib.egnn_bn_act_bwd_reduce_f32(None, 4, p, 4, 4, 4, p, p, 1e-5, p, p, 1, 0.0, 0, None, p, p, p, 1 << 20, None) < 0
+    assert lib.egnn_bn_act_bwd_apply_f32(p, 4, p, 4, 4, 4, p, p, 1e-5, p, p, 1, 0.0, 0, None, None, p, 1.0, p, 4, None) < 0
 
 
 def test_segment_plan_covers_every_entry_exactly_once():

@@ -1199,7 +1199,7 @@ def test_sharded_batchnorm_pieces_on_simulated_shards():
     eps, relu, p, seed = 1e-5, 1, 0.0, 0
     dg_ref, db_ref, dx_ref = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty_like(x)
     _lib.check(lib.egnn_bn_act_bwd_f32(_lib.ptr(x), C, _lib.ptr(dy), C, n, C, _lib.ptr(mean), _lib.ptr(var), eps, _lib.ptr(gamma), _lib.ptr(beta),
-                                       relu, p, seed, 1, _lib.ptr(dg_ref), _lib.ptr(db_ref), _lib.ptr(dx_ref), C, _lib.ptr(ws), nws,
+                                       relu, p, seed, None, 1, _lib.ptr(dg_ref), _lib.ptr(db_ref), _lib.ptr(dx_ref), C, _lib.ptr(ws), nws,
                                        _lib.stream()), "bwd")
     total = torch.zeros(2 * C, device=DEV)                           # [dbeta | dgamma] summed over the shards
     for w in range(world):
@@ -1207,7 +1207,7 @@ def test_sharded_batchnorm_pieces_on_simulated_shards():
         if xs.shape[0]:
             part = torch.empty(2 * C, device=DEV)
             _lib.check(lib.egnn_bn_act_bwd_reduce_f32(_lib.ptr(xs), C, _lib.ptr(ds), C, xs.shape[0], C, _lib.ptr(mean), _lib.ptr(var), eps,
-                                                      _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(part[C:]), _lib.ptr(part),
+                                                      _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, None, _lib.ptr(part[C:]), _lib.ptr(part),
                                                       _lib.ptr(ws), nws, _lib.stream()), "reduce")
             total += part
     close(total[:C], db_ref, rtol=1e-4, atol_scale=1e-5)
@@ -1217,7 +1217,7 @@ def test_sharded_batchnorm_pieces_on_simulated_shards():
         xs, ds = x[cuts[w]:cuts[w + 1]], dy[cuts[w]:cuts[w + 1]]
         if xs.shape[0]:
             _lib.check(lib.egnn_bn_act_bwd_apply_f32(_lib.ptr(xs), C, _lib.ptr(ds), C, xs.shape[0], C, _lib.ptr(mean), _lib.ptr(var), eps,
-                                                     _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(total), _lib.ptr(total[C:]),
+                                                     _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, None, _lib.ptr(total), _lib.ptr(total[C:]),
                                                      1.0 / n, _lib.ptr(dx[cuts[w]:cuts[w + 1]]), C, _lib.stream()), "apply")
     close(dx, dx_ref, rtol=1e-4, atol_scale=1e-5)
 
@@ -1239,3 +1239,69 @@ def test_ppi_epochs_match_reference_train_loop_golden(golden_ppi_train, mode):
     recs = [PM.ppi_train_epoch(model, teacher if mode == "kd" else None, graphs, opt, mode, hp) for _ in range(3)]
     np.testing.assert_allclose(np.array(recs), G[f"{mode}_epoch_losses"], rtol=2e-4, atol=1e-6)
     np.testing.assert_allclose(PM.ppi_test(model, graphs), float(G[f"{mode}_f1"]), atol=5e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gnn,mode", [("gcn", "nce"), ("sage", "kd"), ("gcn", "gpw")])
+def test_graphed_epoch_replays_equal_eager_steps(gnn, mode):
+    """models.GraphedEpoch (train step + eval captured once as a hipGraph) against the eager train_step / evaluate from the same
+    state and the same NumPy draws: with dropout 0 every replay must reproduce the eager losses and accuracies."""
+    d = D.arxiv_like(scale=0.02, seed=6)
+    dev = torch.device(DEV)
+    x, adj, y = d.x.to(dev), d.adj_t.to(dev), d.y.to(dev)
+    split = {k: v.to(dev) for k, v in d.split_idx.items()}
+    tf, tl = ops.pad_pitch(d.teacher_out_feat.to(dev)), d.teacher_logits.to(dev)
+    hp = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=256, kernel="cosine", proj_dim=32)
+
+    def build():
+        torch.manual_seed(0)
+        m = (PM.GCN if gnn == "gcn" else PM.SAGE)(d.num_features, 64, d.num_classes, 3, 0.0).to(dev)
+        sp, tp = PM.make_projection(64, 32).to(dev), PM.make_projection(750, 32).to(dev)
+        opt = torch.optim.Adam([{"params": m.parameters()}, {"params": sp.parameters()}, {"params": tp.parameters()}], lr=0.01,
+                               fused=True, capturable=True)
+        return m, sp, tp, opt
+    warm, steps = 2, 4
+    m1, sp1, tp1, o1 = build()
+    np.random.seed(1)
+    for _ in range(warm):
+        PM.train_step(m1, x, adj, y, split["train"], o1, mode, hp, tf, tl, sp1, tp1)
+    np.random.seed(2)
+    ref = []
+    for _ in range(steps):
+        l = PM.train_step(m1, x, adj, y, split["train"], o1, mode, hp, tf, tl, sp1, tp1)
+        _, a = PM.evaluate(m1, x, adj, y, split)
+        ref.append(l + a)
+    m2, sp2, tp2, o2 = build()
+    np.random.seed(1)
+    ge = PM.GraphedEpoch(m2, x, adj, y, split["train"], o2, mode, hp, tf, tl, sp2, tp2, split_idx=split, warmup=warm)
+    np.random.seed(2)
+    got = []
+    for _ in range(steps):
+        l, a = ge.step()
+        got.append(l + a)
+    np.testing.assert_allclose(np.array(got), np.array(ref), rtol=2e-5, atol=1e-7)
+    assert PC._ROW_SAMPLER is None and ops._DROPOUT_SEED_DEV is None, "the capture hooks must not leak into eager code"
+
+
+@pytest.mark.gpu
+def test_graphed_epoch_draws_fresh_dropout_masks_and_samples():
+    """Replays are not frozen: the device-side dropout seed and the sampled-row buffer change before every replay."""
+    d = D.arxiv_like(scale=0.02, seed=7)
+    dev = torch.device(DEV)
+    x, adj, y = d.x.to(dev), d.adj_t.to(dev), d.y.to(dev)
+    split = {k: v.to(dev) for k, v in d.split_idx.items()}
+    tf, tl = ops.pad_pitch(d.teacher_out_feat.to(dev)), d.teacher_logits.to(dev)
+    hp = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=128, kernel="cosine", proj_dim=32)
+    torch.manual_seed(0)
+    m = PM.GCN(d.num_features, 64, d.num_classes, 3, 0.5).to(dev)
+    sp, tp = PM.make_projection(64, 32).to(dev), PM.make_projection(750, 32).to(dev)
+    opt = torch.optim.Adam([{"params": m.parameters(), "lr": 0.0}, {"params": sp.parameters(), "lr": 0.0},
+                            {"params": tp.parameters(), "lr": 0.0}], fused=True, capturable=True)   # lr 0: only the randomness moves
+    ge = PM.GraphedEpoch(m, x, adj, y, split["train"], opt, "nce", hp, tf, tl, sp, tp, split_idx=None, warmup=2)
+    seen = {ge.step()[0] for _ in range(4)}
+    assert len(seen) == 4 and all(np.isfinite(v).all() for v in map(np.array, seen)), seen
+    picks = []
+    for _ in range(3):
+        ge.step()
+        picks.append(ge._pick_dev.clone())
+    assert not torch.equal(picks[0], picks[1]) and not torch.equal(picks[1], picks[2])

@@ -136,7 +136,7 @@ int main(int argc, char** argv) {
   float *d_y = nullptr, *d_partial = nullptr, *d_stat = nullptr, *d_mean = nullptr, *d_var = nullptr, *d_shift = nullptr;
   CK(hipMalloc(&d_y, (size_t)n * K * 4));
   CK(hipMalloc(&d_partial, std::max<size_t>(sp.slots, 1) * K * 4));
-  CK(hipMalloc(&d_stat, (size_t)(n / 32 + 2) * 2 * K * 4));
+  CK(hipMalloc(&d_stat, (size_t)(n / 32 + 2) * 16 * 2 * K * 4));
   float* d_fold = nullptr;
   CK(hipMalloc(&d_fold, egnn_bn_stats_merge_ws_floats(K) * 4));
   CK(hipMalloc(&d_mean, K * 4));
@@ -241,7 +241,7 @@ int main(int argc, char** argv) {
                                    d_cptr, (int64_t)sp.crow.size(), d_partial, sp.slots, st);
       if (rc) return rc;
       if (v.stats)
-        rc = egnn_bn_stats_merge_f32(d_stat, nb, K, d_y, K, d_crow, (int64_t)sp.crow.size(), d_shift, n, d_mean, d_var, d_fold,
+        rc = egnn_bn_stats_merge_f32(d_stat, nb * (v.lds ? 16 : 4), K, d_y, K, d_crow, (int64_t)sp.crow.size(), d_shift, n, d_mean, d_var, d_fold,
                                      egnn_bn_stats_merge_ws_floats(K), st);
       return rc;
     };
