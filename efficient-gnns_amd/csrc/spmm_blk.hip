@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void spmm_blk_window_kernel(const int32_t* __r
 // Statistics merge, stage 1: the [n_blk][2][C] block partials are folded into kStatSplits partial rows.  Workgroup
 // (column group of 32, split s): thread t adds column (t & 31) over blocks first + (t >> 5), + 8, ... of its split (128-byte
 // coalesced reads), the 8 row groups are added in index order.  Fixed order => deterministic.
-constexpr int kStatSplits = 64;
+constexpr int kStatSplits = 512;
 __global__ __launch_bounds__(256) void bn_stats_fold_kernel(const float* __restrict__ part, int64_t n_blk, int64_t C,
                                                             float* __restrict__ fold) {
   __shared__ float sh[2][8][32];
@@ -358,11 +358,21 @@ __global__ __launch_bounds__(256) void bn_stats_fold_kernel(const float* __restr
   const int64_t per = (n_blk + kStatSplits - 1) / kStatSplits;
   const int64_t b0 = s * per, b1 = b0 + per < n_blk ? b0 + per : n_blk;
   float sa = 0.f, sb = 0.f;
-  if (col < C)
-    for (int64_t i = b0 + g; i < b1; i += 8) {
+  if (col < C) {
+    int64_t i = b0 + g;
+    for (; i + 24 < b1; i += 32) {   // four independent loads per sum in flight
+      const float a0 = part[(i * 2) * C + col], a1 = part[((i + 8) * 2) * C + col], a2 = part[((i + 16) * 2) * C + col],
+                  a3 = part[((i + 24) * 2) * C + col];
+      const float c0 = part[(i * 2 + 1) * C + col], c1 = part[((i + 8) * 2 + 1) * C + col], c2 = part[((i + 16) * 2 + 1) * C + col],
+                  c3 = part[((i + 24) * 2 + 1) * C + col];
+      sa += a0; sa += a1; sa += a2; sa += a3;
+      sb += c0; sb += c1; sb += c2; sb += c3;
+    }
+    for (; i < b1; i += 8) {
       sa += part[(i * 2) * C + col];
       sb += part[(i * 2 + 1) * C + col];
     }
+  }
   sh[0][g][c] = sa;
   sh[1][g][c] = sb;
   __syncthreads();

@@ -126,7 +126,7 @@ int egnn_spmm_blk_window_i32(const int32_t* rowptr, const int32_t* col, int64_t 
                              const int32_t* blk_ptr, int64_t n_blk, int32_t* win, void* stream);
 /* mean[c], var[c] (biased) of n_total rows of Y: the block partials of egnn_spmm_csr_blk_f32 plus the rows listed in
  * extra_rows (the hub rows, whose Y rows the combine step wrote), read from Y.  Fixed summation order (deterministic).
- * ws: egnn_bn_stats_merge_ws_floats(C) floats (needed when n_blk > 128: the partials are folded in two short launches). */
+ * ws: egnn_bn_stats_merge_ws_floats(C) floats (needed when n_blk > 1024: the partials are folded in two short launches). */
 size_t egnn_bn_stats_merge_ws_floats(int64_t C);
 int egnn_bn_stats_merge_f32(const float* stat_part, int64_t n_blk, int64_t C, const float* Y, int64_t ldy,
                             const int64_t* extra_rows, int64_t n_extra, const float* stat_shift, int64_t n_total,

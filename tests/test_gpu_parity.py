@@ -211,7 +211,7 @@ def test_spmm_schedules_agree_with_oracle(schedule, K, monkeypatch):
 def test_spmm_epilogue_statistics_match_a_pass_over_the_result(K, reduce):
     """BatchNorm statistics formed in the aggregation's epilogue (arxiv_pyg/gnn.py:47-48): column mean / biased variance of
     ALL rows of Y (block rows + hub rows) against torch on the result, for few and for many (> 128) row blocks."""
-    for n in (900, 9000):
+    for n in (900, 40000):   # 40000 rows: 5000 wave partials, the two-launch fold of egnn_bn_stats_merge_f32
         row, col = random_csr(n, n, 9, seed=n + K, hubs=((1, 1300), (n - 1, 300)))
         g = torch.Generator().manual_seed(K)
         val = torch.rand(row.numel(), generator=g) + 0.1 if reduce == "sum" else None
@@ -248,6 +248,8 @@ def test_gcn_layer_with_epilogue_statistics_trains_like_the_separate_pass(monkey
     out1.square().mean().backward()
     out2.square().mean().backward()
     for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        if k in ("convs.0.bias", "convs.1.bias"):
+            continue   # a bias in front of BatchNorm has a mathematically zero gradient: what is left is rounding noise
         close(a.grad, b.grad, rtol=1e-4, atol_scale=1e-5, msg=k)
 
 
@@ -1275,6 +1277,7 @@ def test_graphed_epoch_replays_equal_eager_steps(gnn, mode):
     np.random.seed(1)
     ge = PM.GraphedEpoch(m2, x, adj, y, split["train"], o2, mode, hp, tf, tl, sp2, tp2, split_idx=split, warmup=warm)
     np.random.seed(2)
+    ge.redraw()    # the randomness of a replay is drawn one step ahead: re-draw it under the new seed
     got = []
     for _ in range(steps):
         l, a = ge.step()
