@@ -273,6 +273,26 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_blk_kernel(const BlkArgs a) {
         if constexpr (STATS) tally(y);
       }
     }
+  } else if constexpr (ROWS == 1) {
+    // rows_per_blk == 32: every sub-group owns exactly one row -- no loop, nothing but the row's accumulators is live
+    // during the gathers (the statistics are formed from y after the store)
+    const int r = subw;
+    if (r < nrows) {
+      const int row = row0 + r;
+      const int start = a.rowptr[row], end = a.rowptr[row + 1];
+      const int cnt = end - start;
+      if (cnt <= a.seg_max) {  // else hub row: written by the combine kernel
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        gather_range(a, rsrc, start, end, li, lane_off, row_bytes, acc);
+        if (colok) {
+          if (a.bias) bias = *reinterpret_cast<const float4*>(a.bias + col0);
+          const float inv = a.mean ? 1.f / (float)(cnt > 0 ? cnt : 1) : 1.f;
+          const float4 y = make_float4(acc[0] * inv + bias.x, acc[1] * inv + bias.y, acc[2] * inv + bias.z, acc[3] * inv + bias.w);
+          store_row4(a.Y + (int64_t)row * a.ldy + col0, y, a.flags);
+          if constexpr (STATS) tally(y);
+        }
+      }
+    }
   } else {
     for (int rb = 0; rb < nrows; rb += NSUB) {
       const int r = rb + subw;
@@ -480,7 +500,11 @@ extern "C" int egnn_spmm_csr_blk_f32(int64_t n_rows, int64_t n_src, int64_t K, c
   if (grid > 0x7fffffffLL) return EGNN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const bool stats = stat_part != nullptr;
-  if (!lds) return stats ? launch_blk<false, true, 4, 1>(a, (unsigned)grid, 0, st) : launch_blk<false, false, 4, 1>(a, (unsigned)grid, 0, st);
+  if (!lds) {   // ROWS = 1: the one-row-per-sub-group form (rows_per_blk == 32, the host default); ROWS = 0: the row loop
+    if (rows_per_blk == 32)
+      return stats ? launch_blk<false, true, 4, 1>(a, (unsigned)grid, 0, st) : launch_blk<false, false, 4, 1>(a, (unsigned)grid, 0, st);
+    return stats ? launch_blk<false, true, 4, 0>(a, (unsigned)grid, 0, st) : launch_blk<false, false, 4, 0>(a, (unsigned)grid, 0, st);
+  }
   const size_t shm = (size_t)(rows_per_blk + 1) * 128;
   return stats ? launch_blk<true, true, 16, 4>(a, (unsigned)grid, shm, st) : launch_blk<true, false, 16, 4>(a, (unsigned)grid, shm, st);
 }

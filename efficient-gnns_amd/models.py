@@ -15,7 +15,7 @@ from torch import nn
 
 from . import criterion as C
 from . import ops
-from .nn import GATConv, GCNConv, RGCNConv, SAGEConv
+from .nn import DGLGATConv, GATConv, GCNConv, RGCNConv, SAGEConv
 from .sparse import SparseTensor
 
 
@@ -355,6 +355,86 @@ class GAT(nn.Module):
             x = F.dropout(x, p=self.dropout, training=self.training)
             self.out_feat = x
         return self.convs[-1](x, adj_t) + ops.linear(x, self.lins[-1].weight, self.lins[-1].bias)
+
+
+class ElementWiseLinear(nn.Module):
+    """/root/reference/arxiv_dgl/models.py:11-45 (state_dict keys ``weight`` / ``bias``)."""
+
+    def __init__(self, size, weight=True, bias=True, inplace=False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(size)) if weight else None
+        self.bias = nn.Parameter(torch.zeros(size)) if bias else None
+        self.inplace = inplace
+
+    def forward(self, x):
+        if self.weight is not None:
+            x = x * self.weight
+        if self.bias is not None:
+            x = x + self.bias
+        return x
+
+
+class ArxivGAT(nn.Module):
+    """The arxiv GAT teacher (/root/reference/arxiv_dgl/models.py:239-313; ``gat.py`` builds it 3 layers x 250 x 3 heads,
+    expt ``gat-3L250x3h``) for inference on the kernels -- same attribute names (``convs``, ``norms``, ``bias_last``), so the
+    reference's ``checkpoints/<expt>/<seed>.pt['model_state_dict']`` loads.  ``self.feat`` = the last hidden features: the
+    [N, 750] tensor the student reads as ``teacher_out_feat`` (arxiv_pyg/gnn.py:278)."""
+
+    def __init__(self, in_feats, n_classes, n_hidden, n_layers, n_heads, activation, dropout=0.0, input_drop=0.0, attn_drop=0.0,
+                 edge_drop=0.0, use_attn_dst=True, use_symmetric_norm=False):
+        super().__init__()
+        self.in_feats, self.n_hidden, self.n_classes, self.n_layers, self.num_heads = in_feats, n_hidden, n_classes, n_layers, n_heads
+        self.convs, self.norms = nn.ModuleList(), nn.ModuleList()
+        for i in range(n_layers):
+            in_hidden = n_heads * n_hidden if i > 0 else in_feats
+            out_hidden = n_hidden if i < n_layers - 1 else n_classes
+            num_heads = n_heads if i < n_layers - 1 else 1
+            self.convs.append(DGLGATConv(in_hidden, out_hidden, num_heads=num_heads, attn_drop=attn_drop, edge_drop=edge_drop,
+                                         use_attn_dst=use_attn_dst, use_symmetric_norm=use_symmetric_norm, residual=True))
+            if i < n_layers - 1:
+                self.norms.append(nn.BatchNorm1d(n_heads * out_hidden))
+        self.bias_last = ElementWiseLinear(n_classes, weight=False, bias=True, inplace=True)
+        self.input_drop, self.dropout, self.activation = nn.Dropout(input_drop), nn.Dropout(dropout), activation
+        self.feat = None
+
+    def forward(self, graph, feat):
+        h = self.input_drop(feat)
+        for i in range(self.n_layers):
+            h = self.convs[i](graph, h)
+            if i < self.n_layers - 1:
+                h = h.flatten(1)
+                bn = self.norms[i]
+                if h.is_cuda and not self.training and ops.bn_shape_ok(h) and getattr(self.activation, "__name__", "") == "relu":
+                    h = ops.bn_act(h, bn, relu=True, p=0.0, training=False)      # BatchNorm (running statistics) + ReLU fused
+                else:
+                    h = self.dropout(self.activation(bn(h)))
+                self.feat = h
+        return self.bias_last(h.mean(1))
+
+
+def add_labels(feat, labels, idx, n_classes):
+    """gat.py:104-107: one-hot labels of ``idx`` appended to the features (zeros elsewhere)."""
+    onehot = torch.zeros([feat.shape[0], n_classes], dtype=feat.dtype, device=feat.device)
+    onehot[idx, labels[idx, 0]] = 1
+    return torch.cat([feat, onehot], dim=-1)
+
+
+@torch.no_grad()
+def teacher_evaluate(model, graph, feat, labels, train_idx, val_idx, test_idx, n_classes, use_labels=True, n_label_iters=0):
+    """The producer of the teacher artefacts (gat.py:151-183 ``evaluate``): eval-mode forward with the train labels as input
+    features and ``n_label_iters`` label-reuse rounds (soft predictions written back for the unlabelled nodes, :162-166).
+    Returns (pred [N, C] -> ``logits/<expt>/<seed>.pt``, model.feat [N, heads * hidden] -> ``features/<expt>/<seed>.pt``;
+    ``data.save_teacher_artifacts`` writes them in the reference's layout, gat.py:243-251)."""
+    model.eval()
+    if use_labels:
+        feat = add_labels(feat, labels, train_idx, n_classes)
+    pred = model(graph, feat)
+    if n_label_iters > 0:
+        unlabel_idx = torch.cat([val_idx, test_idx])
+        for _ in range(n_label_iters):
+            feat[unlabel_idx, -n_classes:] = F.softmax(pred[unlabel_idx], dim=-1)
+            pred = model(graph, feat)
+    return pred, model.feat
 
 
 class TeacherNet(nn.Module):

@@ -254,6 +254,109 @@ class GATConv(nn.Module):
         return f"GATConv({self.in_channels}, {self.out_channels}, heads={self.heads})"
 
 
+class DGLGATConv(nn.Module):
+    """The arxiv GAT teacher's layer (/root/reference/arxiv_dgl/models.py:95-236 -- the reference's own module over DGL
+    message passing) for INFERENCE on the gfx950 kernels: the producer of the ``features/`` / ``logits/`` artefacts the
+    student path reads (gat.py:243-258).  Same parameter names and initialisation as the reference
+    (``fc``, ``attn_l``, ``attn_r`` (absent with ``use_attn_dst=False``), ``res_fc``), so its checkpoints load.
+
+    ``forward(adj, feat)``: ``adj`` = ``SparseTensor`` whose row i lists the sources of the edges j -> i (the DGL graph after
+    gat.py:56-71 ``preprocess``: ``utils.dgl_bidirected_with_self_loops``).  x W on the fp32 MFMA, ``el`` / ``er`` as one more
+    small GEMM, ``u_add_v`` + LeakyReLU + ``edge_softmax`` fused in ``egnn_gat_attention_fwd_f32``, ``u_mul_e`` + ``sum`` as
+    one valued SpMM per head; symmetric normalisation (out-degree^-1/2 on the sources, in-degree^1/2 on the result) and the
+    residual projection as in the reference.  Returns [N, H, F].  Training the teacher is out of scope: training-mode drops
+    (``edge_drop`` / ``attn_drop`` / ``feat_drop``) raise."""
+
+    def __init__(self, in_feats, out_feats, num_heads=1, feat_drop=0.0, attn_drop=0.0, edge_drop=0.0, negative_slope=0.2,
+                 use_attn_dst=True, residual=False, activation=None, allow_zero_in_degree=False, use_symmetric_norm=False):
+        super().__init__()
+        self._num_heads, self._in_feats, self._out_feats = num_heads, in_feats, out_feats
+        self._allow_zero_in_degree, self._use_symmetric_norm = allow_zero_in_degree, use_symmetric_norm
+        self.fc = nn.Linear(in_feats, out_feats * num_heads, bias=False)
+        self.attn_l = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        if use_attn_dst:
+            self.attn_r = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        else:
+            self.register_buffer("attn_r", None)
+        self.feat_drop_p, self.attn_drop_p, self.edge_drop = feat_drop, attn_drop, edge_drop
+        self.negative_slope = negative_slope
+        if residual:
+            self.res_fc = nn.Linear(in_feats, num_heads * out_feats, bias=False)
+        else:
+            self.register_buffer("res_fc", None)
+        self._activation = activation
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        nn.init.xavier_normal_(self.fc.weight, gain=gain)
+        nn.init.xavier_normal_(self.attn_l, gain=gain)
+        if isinstance(self.attn_r, nn.Parameter):
+            nn.init.xavier_normal_(self.attn_r, gain=gain)
+        if isinstance(self.res_fc, nn.Linear):
+            nn.init.xavier_normal_(self.res_fc.weight, gain=gain)
+
+    @staticmethod
+    def _degrees(adj: SparseTensor):
+        """(in-degree^1/2, out-degree^-1/2) of the message graph, both clamped at 1 (models.py:183-186,219-223); cached."""
+        st = adj._struct
+        if "dgl_norm" not in st:
+            rowptr, col, _ = adj.csr()
+            n = adj.sparse_size(0)
+            in_deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32).clamp(min=1)
+            out_deg = torch.bincount(col, minlength=adj.sparse_size(1)).to(torch.float32).clamp(min=1)
+            st["dgl_norm"] = (in_deg.pow(0.5).view(n, 1), out_deg.pow(-0.5).view(-1, 1), bool((rowptr[1:] == rowptr[:-1]).any()))
+        return st["dgl_norm"]
+
+    def forward(self, adj: SparseTensor, feat: Tensor) -> Tensor:
+        if torch.is_grad_enabled() and (feat.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("DGLGATConv runs the teacher's inference forward (torch.no_grad()); teacher training is out of scope")
+        if self.training and (self.edge_drop > 0 or self.attn_drop_p > 0 or self.feat_drop_p > 0):
+            raise NotImplementedError("training-mode edge / attention / feature drop: teacher training is out of scope (use .eval())")
+        _lib.require_gpu(feat)
+        n, H, F_ = feat.shape[0], self._num_heads, self._out_feats
+        in_sqrt, out_rsqrt, has_isolated = self._degrees(adj)
+        if has_isolated and not self._allow_zero_in_degree:
+            raise AssertionError("zero in-degree node (arxiv_dgl/models.py:167-169)")
+        feat_src = ops.linear(feat, self.fc.weight)                               # [n, H*F]
+        # el[i,h] = <feat_src[i,h,:], attn_l[h,:]> (and er) as ONE GEMM with a block-diagonal [H*F, 2H] matrix
+        blk = torch.zeros(H * F_, 2 * H, dtype=torch.float32, device=feat.device)
+        rows = torch.arange(H * F_, device=feat.device)
+        blk[rows, rows // F_] = self.attn_l.detach().reshape(-1)
+        if self.attn_r is not None:
+            blk[rows, H + rows // F_] = self.attn_r.detach().reshape(-1)
+        alpha = ops.matmul(feat_src, blk)                                         # [n, 2H]; er = 0 without attn_r (copy_u)
+        el, er = alpha[:, :H].contiguous(), alpha[:, H:].contiguous()
+        if self._use_symmetric_norm:
+            # the reference scales the SOURCE features (and with them el) by out-degree^-1/2 but forms er from the unscaled
+            # destination features (models.py:178-200: feat_dst is bound before the scaling)
+            feat_src = feat_src * out_rsqrt
+            el = el * out_rsqrt
+        rowptr, col, _ = adj.csr()
+        nnz = adj.nnz()
+        att = torch.empty(H, nnz, dtype=torch.float32, device=feat.device)        # head-major: att[h] is a value array
+        _lib.check(_lib.load().egnn_gat_attention_fwd_f32(_lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(el), _lib.ptr(er), n, nnz, H,
+                                                          float(self.negative_slope), _lib.ptr(att), _lib.stream()),
+                   "egnn_gat_attention_fwd_f32")
+        Fp = (F_ + 3) // 4 * 4                                                      # head blocks on 16-byte boundaries (F = 250 -> 252)
+        src_heads = feat_src if Fp == F_ else torch.nn.functional.pad(feat_src.view(n, H, F_), (0, Fp - F_)).reshape(n, H * Fp)
+        out = torch.empty(n, H * Fp, dtype=torch.float32, device=feat.device)
+        plain = adj.set_value(None) if adj.has_value() else adj
+        for h in range(H):
+            ops.spmm_raw(plain.set_value(att[h]), src_heads[:, h * Fp:(h + 1) * Fp], "sum", out=out[:, h * Fp:(h + 1) * Fp])
+        rst = out.view(n, H, Fp)[:, :, :F_]
+        if self._use_symmetric_norm:
+            rst = rst * in_sqrt.view(n, 1, 1)
+        if self.res_fc is not None:
+            rst = rst + ops.linear(feat, self.res_fc.weight).view(n, -1, F_)
+        if self._activation is not None:
+            rst = self._activation(rst)
+        return rst
+
+    def __repr__(self):
+        return f"DGLGATConv({self._in_feats}, {self._out_feats}, heads={self._num_heads})"
+
+
 _RGCN_REL_CACHE = _TensorKeyedCache(capacity=8)
 
 

@@ -33,3 +33,19 @@ def softmax(src: Tensor, index: Tensor, ptr=None, num_nodes: int | None = None) 
     """Segment softmax over entries grouped by ``index``: exp(src - max) / (sum + 1e-16)."""
     from .ops_edge import segment_softmax
     return segment_softmax(src, index, num_nodes)
+
+
+def dgl_bidirected_with_self_loops(adj_t):
+    """The message graph of the arxiv GAT teacher (/root/reference/arxiv_dgl/gat.py:56-71 ``preprocess``):
+    ``dgl.to_bidirected`` (union with the reversed edges, duplicates merged), ``remove_self_loop().add_self_loop()`` (exactly
+    one loop per node) -- as a ``SparseTensor`` whose row i lists the sources of the edges into i, columns ascending."""
+    import torch
+    from .sparse import SparseTensor
+    sym = adj_t.to_symmetric()
+    rowptr, col, _ = sym.csr()
+    n = sym.sparse_size(0)
+    row = sym.storage.row()
+    keep = row != col
+    loops = torch.arange(n, dtype=col.dtype, device=col.device)
+    r, c = torch.cat([row[keep], loops]), torch.cat([col[keep], loops])
+    return SparseTensor(row=r, col=c, sparse_sizes=(n, n))   # sorted by (row, col) in the constructor

@@ -14,7 +14,8 @@ reference executes on its hot path:
   * ``models.py``     ``GCN`` / ``SAGE`` / projection heads and the train / eval step
                       (``arxiv_pyg/gnn.py:23-218``); the PPI teacher models ``GAT`` / ``TeacherNet`` and the PPI
                       epoch / micro-F1 loops (``ppi_pyg/gnn.py:23-117,185-288``); ``RGCN`` forward / inference
-                      (``mag_pyg/gnn.py:71-168``)
+                      (``mag_pyg/gnn.py:71-168``); the arxiv GAT teacher ``ArxivGAT`` / ``nn.DGLGATConv`` and the artefact-producing
+                      ``teacher_evaluate`` with label reuse (``arxiv_dgl/models.py:95-313``, ``arxiv_dgl/gat.py:104-107,151-183``)
 
 Third-party arithmetic (PyG, torch-sparse, torch-scatter) is NOT vendored by the reference and is not
 installable here; it is restated from the published algorithm of the versions contemporary with the
@@ -26,7 +27,9 @@ PARITY PINNING STATUS
     ``ppi_pyg/criterion.py`` and ``arxiv_pyg/gnn.py`` in the build container
     (``tests/golden/make_golden.py``), with only the un-installable third-party imports shimmed; likewise
     the PPI ``GAT`` / ``TeacherNet`` / ``train()`` / ``test()`` bodies (``ppi_pyg/gnn.py``) and the MAG
-    ``RGCNConv`` / ``RGCN`` forward and inference (``mag_pyg/gnn.py``);
+    ``RGCNConv`` / ``RGCN`` forward and inference (``mag_pyg/gnn.py``), and the arxiv ``GAT`` / ``GATConv`` teacher forward
+    (``arxiv_dgl/models.py``, DGL's message-passing built-ins shimmed; the golden caught that ``er`` is formed from the
+    UNSCALED destination features under ``use_symmetric_norm``);
   * the PyG / torch-sparse operator semantics underneath (``GCNConv``, ``SAGEConv``, ``GATConv``,
     ``MessagePassing.propagate``, ``SparseTensor``, ``utils.softmax``) are "parity unpinned": the reference holds no tests, fixtures or golden vectors
     for them and the packages cannot be imported; they are pinned only by

@@ -296,3 +296,83 @@ def ppi_test(model, graphs):
     if tp + fp == 0:
         return 0
     return 2 * tp / (2 * tp + fp + fn)
+
+
+# ------------------------------------------------------------------------------------------------
+# the arxiv GAT teacher that PRODUCES the artefacts of the hot path
+# ------------------------------------------------------------------------------------------------
+class ElementWiseLinear(nn.Module):
+    """arxiv_dgl/models.py:11-45 (only the bias-only, in-place form the GAT uses)."""
+
+    def __init__(self, size, weight=True, bias=True, inplace=False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(size)) if weight else None
+        self.bias = nn.Parameter(torch.zeros(size)) if bias else None
+        self.inplace = inplace
+
+    def forward(self, x):
+        if self.weight is not None:
+            x = x * self.weight
+        if self.bias is not None:
+            x = x + self.bias
+        return x
+
+
+class ArxivGAT(nn.Module):
+    """arxiv_dgl/models.py:239-313: [GATConv(residual) -> flatten heads -> BatchNorm1d -> activation -> dropout] x (L-1), a
+    one-head... (n_heads of the hidden layers, 1 head for the last), mean over the heads of the last layer, ``bias_last``.
+    ``self.feat`` = the last hidden features (what ``gat.py:250-251`` saves as the teacher's feature artefact)."""
+
+    def __init__(self, in_feats, n_classes, n_hidden, n_layers, n_heads, activation, dropout=0.0, input_drop=0.0, attn_drop=0.0,
+                 edge_drop=0.0, use_attn_dst=True, use_symmetric_norm=False):
+        super().__init__()
+        from .nn import DGLGATConv
+        self.in_feats, self.n_hidden, self.n_classes, self.n_layers, self.num_heads = in_feats, n_hidden, n_classes, n_layers, n_heads
+        self.convs, self.norms = nn.ModuleList(), nn.ModuleList()
+        for i in range(n_layers):
+            in_hidden = n_heads * n_hidden if i > 0 else in_feats
+            out_hidden = n_hidden if i < n_layers - 1 else n_classes
+            num_heads = n_heads if i < n_layers - 1 else 1
+            self.convs.append(DGLGATConv(in_hidden, out_hidden, num_heads=num_heads, attn_drop=attn_drop, edge_drop=edge_drop,
+                                         use_attn_dst=use_attn_dst, use_symmetric_norm=use_symmetric_norm, residual=True))
+            if i < n_layers - 1:
+                self.norms.append(nn.BatchNorm1d(n_heads * out_hidden))
+        self.bias_last = ElementWiseLinear(n_classes, weight=False, bias=True, inplace=True)
+        self.input_drop, self.dropout, self.activation = nn.Dropout(input_drop), nn.Dropout(dropout), activation
+        self.feat = None
+
+    def forward(self, graph, feat):
+        h = self.input_drop(feat)
+        for i in range(self.n_layers):
+            h = self.convs[i](graph, h)
+            if i < self.n_layers - 1:
+                h = h.flatten(1)
+                h = self.norms[i](h)
+                h = self.activation(h)
+                h = self.dropout(h)
+                self.feat = h
+        return self.bias_last(h.mean(1))
+
+
+def add_labels(feat, labels, idx, n_classes):
+    """gat.py:104-107: one-hot labels of ``idx`` appended to the features (zeros elsewhere)."""
+    onehot = torch.zeros([feat.shape[0], n_classes], dtype=feat.dtype, device=feat.device)
+    onehot[idx, labels[idx, 0]] = 1
+    return torch.cat([feat, onehot], dim=-1)
+
+
+@torch.no_grad()
+def teacher_evaluate(model, graph, feat, labels, train_idx, val_idx, test_idx, n_classes, use_labels=True, n_label_iters=0):
+    """The producer of the teacher artefacts, gat.py:151-183 (``evaluate``): eval-mode forward with the train labels as input
+    features and ``n_label_iters`` label-reuse rounds (predicted soft labels written back for the unlabelled nodes).
+    Returns (pred [N, C] = what ``logits/<expt>/<seed>.pt`` holds, model.feat [N, heads*hidden] = ``features/...``)."""
+    model.eval()
+    if use_labels:
+        feat = add_labels(feat, labels, train_idx, n_classes)
+    pred = model(graph, feat)
+    if n_label_iters > 0:
+        unlabel_idx = torch.cat([val_idx, test_idx])
+        for _ in range(n_label_iters):
+            feat[unlabel_idx, -n_classes:] = F.softmax(pred[unlabel_idx], dim=-1)
+            pred = model(graph, feat)
+    return pred, model.feat

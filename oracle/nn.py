@@ -182,3 +182,78 @@ class RGCNConv(MessagePassing):
 
     def message(self, x_j, edge_type: int):
         return self.rel_lins[edge_type](x_j)
+
+
+class DGLGATConv(nn.Module):
+    """The arxiv GAT teacher's layer, /root/reference/arxiv_dgl/models.py:95-236 (the reference's OWN module on top of DGL
+    message passing), restated on a ``SparseTensor`` whose row i lists the sources j of the edges j -> i (the DGL graph
+    after ``gat.py:56-71``: bidirected, self loops replaced).  Same parameter names (``fc``, ``attn_l``, ``attn_r``,
+    ``res_fc``) and initialisation (xavier_normal, relu gain) as the reference; returns [N, H, F].
+
+    DGL semantics restated (third party, parity unpinned): ``u_add_v('el','er','e')`` = el[src] + er[dst] per edge,
+    ``copy_u``; ``edge_softmax`` = softmax over the incoming edges of each destination, per head; ``update_all(u_mul_e,
+    sum)`` = sum over incoming edges of ft[src] * a; ``out_degrees`` / ``in_degrees`` = edges leaving / entering a node.
+    Inference semantics: ``edge_drop`` acts in training mode only (models.py:205-210) and teacher training is out of scope."""
+
+    def __init__(self, in_feats, out_feats, num_heads=1, feat_drop=0.0, attn_drop=0.0, edge_drop=0.0, negative_slope=0.2,
+                 use_attn_dst=True, residual=False, activation=None, allow_zero_in_degree=False, use_symmetric_norm=False):
+        super().__init__()
+        self._num_heads, self._in_feats, self._out_feats = num_heads, in_feats, out_feats
+        self._allow_zero_in_degree, self._use_symmetric_norm = allow_zero_in_degree, use_symmetric_norm
+        self.fc = nn.Linear(in_feats, out_feats * num_heads, bias=False)
+        self.attn_l = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        if use_attn_dst:
+            self.attn_r = nn.Parameter(torch.empty(1, num_heads, out_feats))
+        else:
+            self.register_buffer("attn_r", None)
+        self.feat_drop, self.attn_drop, self.edge_drop = nn.Dropout(feat_drop), nn.Dropout(attn_drop), edge_drop
+        self.negative_slope = negative_slope
+        if residual:
+            self.res_fc = nn.Linear(in_feats, num_heads * out_feats, bias=False)
+        else:
+            self.register_buffer("res_fc", None)
+        self._activation = activation
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        nn.init.xavier_normal_(self.fc.weight, gain=gain)
+        nn.init.xavier_normal_(self.attn_l, gain=gain)
+        if isinstance(self.attn_r, nn.Parameter):
+            nn.init.xavier_normal_(self.attn_r, gain=gain)
+        if isinstance(self.res_fc, nn.Linear):
+            nn.init.xavier_normal_(self.res_fc.weight, gain=gain)
+
+    def forward(self, adj: SparseTensor, feat: Tensor) -> Tensor:
+        if self.training and (self.edge_drop > 0 or self.attn_drop.p > 0 or self.feat_drop.p > 0):
+            raise NotImplementedError("DGLGATConv restates the teacher's inference (eval-mode) forward")
+        n, H, F_ = feat.shape[0], self._num_heads, self._out_feats
+        rowptr, col, _ = adj.csr()
+        in_deg = rowptr[1:] - rowptr[:-1]
+        if not self._allow_zero_in_degree and bool((in_deg == 0).any()):
+            raise AssertionError("zero in-degree node (models.py:167-169)")
+        dst = torch.repeat_interleave(torch.arange(n), in_deg)
+        src = col
+        h = self.feat_drop(feat)
+        feat_src = self.fc(h).view(n, H, F_)
+        feat_dst = feat_src                                           # non-block graph (models.py:178-180): bound BEFORE the scaling below
+        if self._use_symmetric_norm:
+            out_deg = torch.bincount(src, minlength=n).float().clamp(min=1)
+            feat_src = feat_src * torch.pow(out_deg, -0.5).view(n, 1, 1)
+        el = (feat_src * self.attn_l).sum(dim=-1)                     # [n, H]: from the SCALED source features
+        e = el[src]
+        if self.attn_r is not None:
+            e = e + (feat_dst * self.attn_r).sum(dim=-1)[dst]         # from the UNSCALED ones (models.py:182-200, pinned by the golden)
+        e = torch.nn.functional.leaky_relu(e, self.negative_slope)    # [E, H]
+        m = torch.full((n, H), float("-inf")).scatter_reduce(0, dst.view(-1, 1).expand(-1, H), e, "amax", include_self=True)
+        ex = torch.exp(e - m[dst])
+        a = ex / torch.zeros(n, H).index_add_(0, dst, ex)[dst]        # dgl.ops.edge_softmax
+        a = self.attn_drop(a)
+        rst = torch.zeros(n, H, F_).index_add_(0, dst, feat_src[src] * a.unsqueeze(-1))
+        if self._use_symmetric_norm:
+            rst = rst * torch.pow(in_deg.float().clamp(min=1), 0.5).view(n, 1, 1)
+        if self.res_fc is not None:
+            rst = rst + self.res_fc(h).view(n, -1, F_)
+        if self._activation is not None:
+            rst = self._activation(rst)
+        return rst

@@ -48,6 +48,32 @@ def golden_ppi_train():
 
 
 @pytest.fixture(scope="session")
+def golden_arxiv_gat():
+    return np.load(os.path.join(GOLDEN, "arxiv_gat.npz"), allow_pickle=False)
+
+
+ARXIV_GAT_CONFIGS = {"norm_noattn": dict(use_attn_dst=False, use_symmetric_norm=True, n_label_iters=1),
+                     "plain": dict(use_attn_dst=True, use_symmetric_norm=False, n_label_iters=0),
+                     "norm_attn": dict(use_attn_dst=True, use_symmetric_norm=True, n_label_iters=2)}
+
+
+def arxiv_gat_case(G, M, SparseTensor, name, device="cpu"):
+    """Model (``M.ArxivGAT`` with the golden's parameters), message graph and inputs of tests/golden/arxiv_gat.npz."""
+    import torch.nn.functional as F
+    cfg = ARXIV_GAT_CONFIGS[name]
+    x, labels = as_t(G["in_x"], device), as_t(G["in_labels"], device)
+    n, C = x.shape[0], 6
+    adj = SparseTensor(row=as_t(G["in_dst"], device), col=as_t(G["in_src"], device), sparse_sizes=(n, n))
+    model = M.ArxivGAT(x.shape[1] + C, C, 5, 3, 3, F.relu, dropout=0.75, input_drop=0.25, attn_drop=0.0, edge_drop=0.3,
+                       use_attn_dst=cfg["use_attn_dst"], use_symmetric_norm=cfg["use_symmetric_norm"]).to(device)
+    pre = f"{name}__param__"
+    sd = {k[len(pre):]: as_t(G[k], device) for k in G.files if k.startswith(pre)}
+    missing = model.load_state_dict(sd, strict=True)
+    idx = tuple(as_t(G[k], device) for k in ("in_train", "in_val", "in_test"))
+    return model, adj, x, labels, idx, C, cfg["n_label_iters"]
+
+
+@pytest.fixture(scope="session")
 def golden_train():
     return np.load(os.path.join(GOLDEN, "train_arxiv.npz"), allow_pickle=False)
 

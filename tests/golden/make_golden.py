@@ -13,6 +13,9 @@ What is executed for real (imported from /root/reference, unmodified):
   * ppi_pyg/gnn.py           -> GAT and TeacherNet (the frozen teacher the PPI student step runs, :208-209), GCN,
                                 train() (kd with the teacher forward inside every step, supervised) and test() (micro-F1)
   * mag_pyg/gnn.py           -> RGCNConv (a MessagePassing subclass of the reference's own), RGCN.forward / .inference
+  * arxiv_dgl/models.py      -> GATConv / GAT (the arxiv GAT teacher: eval-mode forward that produces the features/ and logits/
+                                artefacts; ``dgl`` message-passing built-ins shimmed from the DGL docs), with the label-reuse loop
+                                of arxiv_dgl/gat.py:151-166 restated inline (gat.py imports matplotlib / ogb at module top)
 
 What is shimmed (third-party packages that are neither vendored by the reference nor installable
 here -- SURVEY.md 8c): ``torch_geometric`` (GCNConv, SAGEConv, utils.softmax, utils.subgraph,
@@ -34,6 +37,7 @@ os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -411,6 +415,146 @@ def make_mag_rgcn_goldens():
     print("mag_rgcn.npz: RGCN forward + inference")
 
 
+# ------------------------------------------------------------------------------------------------
+# arxiv_dgl: the GAT teacher that produces the student's input artefacts
+class _DGLGraph:
+    """The slice of a homogeneous ``dgl.DGLGraph`` that arxiv_dgl/models.py touches, restated from the DGL 0.5/0.6 docs
+    (third party, not installable here): edges (src[e], dst[e]); ``srcdata`` / ``dstdata`` / ``ndata`` are ONE frame on a
+    non-block graph; ``apply_edges(f)`` / ``update_all(msg, reduce)`` run the built-in functions below."""
+    is_block = False
+
+    def __init__(self, src, dst, n):
+        self.src, self.dst, self.n = src, dst, n
+        self.ndata = {}
+        self.srcdata = self.dstdata = self.ndata
+        self.edata = {}
+
+    def local_scope(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            nd, ed = dict(self.ndata), dict(self.edata)
+            try:
+                yield
+            finally:
+                self.ndata.clear(), self.ndata.update(nd)
+                self.edata.clear(), self.edata.update(ed)
+        return scope()
+
+    def in_degrees(self):
+        return torch.bincount(self.dst, minlength=self.n)
+
+    def out_degrees(self):
+        return torch.bincount(self.src, minlength=self.n)
+
+    def number_of_edges(self):
+        return self.src.numel()
+
+    def number_of_dst_nodes(self):
+        return self.n
+
+    def apply_edges(self, f):
+        f(self)
+
+    def update_all(self, msg, red):
+        msg(self)
+        red(self)
+
+
+def install_dgl_shim():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    def u_add_v(a, b, out):
+        return lambda g: g.edata.__setitem__(out, g.srcdata[a][g.src] + g.dstdata[b][g.dst])
+
+    def copy_u(a, out):
+        return lambda g: g.edata.__setitem__(out, g.srcdata[a][g.src])
+
+    def u_mul_e(a, b, out):
+        return lambda g: g.edata.__setitem__(out, g.srcdata[a][g.src] * g.edata[b])
+
+    def fsum(m, out):
+        def red(g):
+            e = g.edata[m]
+            g.dstdata[out] = torch.zeros((g.n,) + tuple(e.shape[1:]), dtype=e.dtype).index_add_(0, g.dst, e)
+        return red
+
+    def edge_softmax(graph, e, eids=None):
+        dst = graph.dst if eids is None else graph.dst[eids]
+        shape = (graph.n,) + tuple(e.shape[1:])
+        idx = dst.view(-1, *([1] * (e.dim() - 1))).expand_as(e)
+        mx = torch.full(shape, float("-inf"), dtype=e.dtype).scatter_reduce(0, idx, e, "amax", include_self=True)
+        ex = torch.exp(e - mx[dst])
+        return ex / torch.zeros(shape, dtype=e.dtype).index_add_(0, dst, ex)[dst]
+
+    fn = mod("dgl.function", u_add_v=u_add_v, copy_u=copy_u, u_mul_e=u_mul_e, sum=fsum)
+    base = mod("dgl._ffi.base", DGLError=RuntimeError)
+    ffi = mod("dgl._ffi", base=base)
+    putils = mod("dgl.nn.pytorch.utils", Identity=torch.nn.Identity)
+    pyt = mod("dgl.nn.pytorch", utils=putils, GraphConv=None)
+    dnn = mod("dgl.nn", pytorch=pyt)
+    dops = mod("dgl.ops", edge_softmax=edge_softmax)
+    dut = mod("dgl.utils", expand_as_pair=lambda x: x if isinstance(x, tuple) else (x, x))
+    mod("dgl", function=fn, _ffi=ffi, nn=dnn, ops=dops, utils=dut)
+
+
+def make_arxiv_gat_goldens():
+    """arxiv_dgl/models.py's own ``GAT`` / ``GATConv`` (eval-mode forward: the producer of features/ and logits/ artefacts)
+    in the three configurations of gat.py:375-389 (use_norm, no_attn_dst, label reuse) on a toy graph, plus the label-reuse
+    evaluation loop of gat.py:151-183 (restated inline: gat.py itself imports matplotlib / ogb datasets at module top)."""
+    install_dgl_shim()
+    models = load_ref("arxiv_dgl/models.py", "ref_arxiv_dgl_models")
+    g = torch.Generator().manual_seed(41)
+    n, F_in, C, hidden, heads = 57, 11, 6, 5, 3
+    # bidirected edges without duplicates, self loops replaced (gat.py:56-71)
+    a = torch.rand(n, n, generator=g) < 0.08
+    a = (a | a.t())
+    a.fill_diagonal_(True)
+    dst, src = torch.nonzero(a, as_tuple=True)        # row-major: edges grouped by destination, sources ascending
+    graph = _DGLGraph(src, dst, n)
+    x = torch.randn(n, F_in, generator=g)
+    labels = torch.randint(0, C, (n, 1), generator=g)
+    perm = torch.randperm(n, generator=g)
+    train_idx, val_idx, test_idx = perm[:30], perm[30:42], perm[42:]
+    out = {"in_src": t2n(src), "in_dst": t2n(dst), "in_x": t2n(x), "in_labels": t2n(labels), "in_train": t2n(train_idx),
+           "in_val": t2n(val_idx), "in_test": t2n(test_idx)}
+    for name, cfg in (("norm_noattn", dict(use_attn_dst=False, use_symmetric_norm=True, n_label_iters=1)),
+                      ("plain", dict(use_attn_dst=True, use_symmetric_norm=False, n_label_iters=0)),
+                      ("norm_attn", dict(use_attn_dst=True, use_symmetric_norm=True, n_label_iters=2))):
+        torch.manual_seed(7)
+        model = models.GAT(F_in + C, C, hidden, 3, heads, F.relu, dropout=0.75, input_drop=0.25, attn_drop=0.0, edge_drop=0.3,
+                           use_attn_dst=cfg["use_attn_dst"], use_symmetric_norm=cfg["use_symmetric_norm"])
+        with torch.no_grad():   # non-trivial BatchNorm running statistics and last-layer bias
+            for bn in model.norms:
+                bn.running_mean.normal_(0, 0.3, generator=g)
+                bn.running_var.uniform_(0.5, 1.5, generator=g)
+                bn.weight.uniform_(0.5, 1.5, generator=g)
+                bn.bias.normal_(0, 0.2, generator=g)
+            model.bias_last.bias.normal_(0, 0.5, generator=g)
+        model.eval()
+        for k, v in model.state_dict().items():
+            out[f"{name}__param__{k}"] = t2n(v)
+        with torch.no_grad():
+            # gat.py:104-107 add_labels + :151-168 evaluate(), with the reference's model object
+            onehot = torch.zeros([n, C])
+            onehot[train_idx, labels[train_idx, 0]] = 1
+            feat = torch.cat([x, onehot], dim=-1)
+            pred = model(graph, feat)
+            unlabel_idx = torch.cat([val_idx, test_idx])
+            for _ in range(cfg["n_label_iters"]):
+                feat[unlabel_idx, -C:] = F.softmax(pred[unlabel_idx], dim=-1)
+                pred = model(graph, feat)
+            conv0 = model.convs[0](graph, feat)
+        out[f"{name}__pred"], out[f"{name}__feat"], out[f"{name}__conv0"] = t2n(pred), t2n(model.feat), t2n(conv0)
+    np.savez_compressed(os.path.join(HERE, "arxiv_gat.npz"), **out)
+    print("arxiv_gat.npz: arxiv_dgl GAT teacher forward x 3 configs (+ label reuse)")
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "needs /root/reference (build container only)"
     torch.set_num_threads(1)  # reproducible reduction order in the recorded numbers
@@ -420,3 +564,4 @@ if __name__ == "__main__":
     make_ppi_teacher_goldens()
     make_mag_rgcn_goldens()
     make_ppi_train_goldens()
+    make_arxiv_gat_goldens()

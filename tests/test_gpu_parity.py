@@ -21,7 +21,7 @@ import oracle.models as OM
 import oracle.nn as ON
 import oracle.sparse as OS
 import oracle.utils as OU
-from conftest import as_t, mag_rgcn_case, ppi_train_case
+from conftest import ARXIV_GAT_CONFIGS, arxiv_gat_case, as_t, mag_rgcn_case, ppi_train_case
 from test_oracle_golden import criterion_cases, run_training, noise_driven
 
 pytestmark = pytest.mark.gpu
@@ -1282,7 +1282,14 @@ def test_graphed_epoch_replays_equal_eager_steps(gnn, mode):
     for _ in range(steps):
         l, a = ge.step()
         got.append(l + a)
-    np.testing.assert_allclose(np.array(got), np.array(ref), rtol=2e-5, atol=1e-7)
+    got, ref = np.array(got), np.array(ref)
+    np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=2e-5, atol=1e-7)
+    # accuracies: eval-mode logits after Adam steps are rounding-noise sensitive (biases in front of BatchNorm, see
+    # tests/golden/make_golden.py); allow a couple of argmax flips, report how far the parameters really are
+    worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)) for a, b in zip(m2.parameters(), m1.parameters()))
+    n_small = min(v.numel() for v in split.values())
+    np.testing.assert_allclose(got[:, 3:], ref[:, 3:], atol=3.0 / n_small, err_msg=f"max relative parameter distance {worst:.2e}")
+    assert worst < 1e-3, worst
     assert PC._ROW_SAMPLER is None and ops._DROPOUT_SEED_DEV is None, "the capture hooks must not leak into eager code"
 
 
@@ -1308,3 +1315,47 @@ def test_graphed_epoch_draws_fresh_dropout_masks_and_samples():
         ge.step()
         picks.append(ge._pick_dev.clone())
     assert not torch.equal(picks[0], picks[1]) and not torch.equal(picks[1], picks[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(ARXIV_GAT_CONFIGS))
+def test_arxiv_gat_teacher_matches_reference_golden(golden_arxiv_gat, name):
+    """The arxiv GAT teacher on the kernels (models.ArxivGAT / nn.DGLGATConv / teacher_evaluate) against the golden recorded
+    from the reference's own arxiv_dgl/models.py (three gat.py configurations incl. label reuse)."""
+    G = golden_arxiv_gat
+    model, adj, x, labels, (tr, va, te), C, iters = arxiv_gat_case(G, PM, E.SparseTensor, name, DEV)
+    pred, feat = PM.teacher_evaluate(model, adj, x, labels, tr, va, te, C, use_labels=True, n_label_iters=iters)
+    close(pred, G[f"{name}__pred"], rtol=2e-5, atol_scale=2e-6)
+    close(feat, G[f"{name}__feat"], rtol=2e-5, atol_scale=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_attn_dst,sym", [(False, True), (True, False)])
+def test_arxiv_gat_teacher_vs_oracle_and_artifact_files(use_attn_dst, sym, tmp_path):
+    """Teacher pipeline at a larger size with the script-of-record width (3 heads x 250: head blocks that are not float4
+    aligned): message graph (gat.py:56-71), forward + one label-reuse round, artefact files in the reference's layout read back
+    the way arxiv_pyg/gnn.py:278-279 does."""
+    import torch.nn.functional as F
+    from efficient_gnns_amd.utils import dgl_bidirected_with_self_loops
+    d = D.arxiv_like(scale=0.02, seed=9, with_teacher=False)
+    n, C = d.num_nodes, d.num_classes
+    padj = dgl_bidirected_with_self_loops(d.adj_t.to(DEV))
+    rowptr, col, _ = padj.csr()
+    rows = torch.repeat_interleave(torch.arange(n), (rowptr[1:] - rowptr[:-1]).cpu())
+    assert int(((rows == col.cpu()).long()).sum()) == n, "exactly one self loop per node"
+    oadj = OS.SparseTensor(rowptr=rowptr.cpu(), col=col.cpu(), sparse_sizes=(n, n))
+    torch.manual_seed(3)
+    om = OM.ArxivGAT(d.num_features + C, C, 250, 3, 3, F.relu, dropout=0.75, input_drop=0.25, edge_drop=0.3,
+                     use_attn_dst=use_attn_dst, use_symmetric_norm=sym)
+    pm = PM.ArxivGAT(d.num_features + C, C, 250, 3, 3, F.relu, dropout=0.75, input_drop=0.25, edge_drop=0.3,
+                     use_attn_dst=use_attn_dst, use_symmetric_norm=sym).to(DEV)
+    pm.load_state_dict(om.state_dict())
+    tr, va, te = (d.split_idx[k] for k in ("train", "valid", "test"))
+    po, fo = OM.teacher_evaluate(om, oadj, d.x.clone(), d.y, tr, va, te, C, True, 1)
+    pp, fp = PM.teacher_evaluate(pm, padj, d.x.to(DEV), d.y.to(DEV), tr.to(DEV), va.to(DEV), te.to(DEV), C, True, 1)
+    close(pp, po, rtol=1e-4, atol_scale=2e-5)
+    close(fp, fo, rtol=1e-4, atol_scale=2e-5)
+    assert fp.shape == (n, 750) and float(fp.min()) >= 0.0          # post-ReLU features, the [N,750] the student reads
+    D.save_teacher_artifacts(str(tmp_path), "gat-3L250x3h", 0, fp, pp)
+    f2, l2 = D.load_teacher_artifacts(str(tmp_path), "gat-3L250x3h", 0, num_nodes=n, device=DEV)
+    assert torch.equal(f2, fp) and torch.equal(l2, pp)

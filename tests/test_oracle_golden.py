@@ -7,7 +7,7 @@ import oracle.criterion as OC
 import oracle.models as OM
 import oracle.sparse as OS
 import oracle.utils as OU
-from conftest import as_t, mag_rgcn_case, ppi_train_case
+from conftest import ARXIV_GAT_CONFIGS, arxiv_gat_case, as_t, mag_rgcn_case, ppi_train_case
 
 RT, AT = 1e-6, 1e-7
 
@@ -219,3 +219,25 @@ def test_oracle_ppi_epochs_match_reference_train_loop(golden_ppi_train, mode):
     recs = [OM.ppi_train_epoch(model, teacher if mode == "kd" else None, graphs, opt, mode, hp) for _ in range(3)]
     np.testing.assert_allclose(np.array(recs), G[f"{mode}_epoch_losses"], rtol=2e-5, atol=1e-7)
     np.testing.assert_allclose(OM.ppi_test(model, graphs), float(G[f"{mode}_f1"]), atol=2e-3)
+
+
+@pytest.mark.parametrize("name", sorted(ARXIV_GAT_CONFIGS))
+def test_oracle_arxiv_gat_teacher_matches_reference_bodies(golden_arxiv_gat, name):
+    """oracle.ArxivGAT / DGLGATConv / teacher_evaluate against the reference's own arxiv_dgl/models.py GAT (eval-mode forward,
+    label reuse as in gat.py:151-166) recorded by tests/golden/make_golden.py: predictions (= the logits artefact), the last
+    hidden features (= the features artefact) and the raw first layer."""
+    G = golden_arxiv_gat
+    model, adj, x, labels, (tr, va, te), C, iters = arxiv_gat_case(G, OM, OS.SparseTensor, name)
+    model.eval()
+    pred, feat = OM.teacher_evaluate(model, adj, x, labels, tr, va, te, C, use_labels=True, n_label_iters=iters)
+    np.testing.assert_allclose(pred.numpy(), G[f"{name}__pred"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(feat.numpy(), G[f"{name}__feat"], rtol=2e-5, atol=1e-6)
+    # first layer on the final (label-reused) input features
+    f = OM.add_labels(x, labels, tr, C)
+    p = model(adj, f)
+    un = torch.cat([va, te])
+    for _ in range(iters):
+        f[un, -C:] = torch.softmax(p[un], dim=-1)
+        p = model(adj, f)
+    with torch.no_grad():
+        np.testing.assert_allclose(model.convs[0](adj, f).numpy(), G[f"{name}__conv0"], rtol=2e-5, atol=1e-6)
