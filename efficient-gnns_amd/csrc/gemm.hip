@@ -5,7 +5,27 @@
 
 using namespace egnn_gemm;
 
+// gemm_skinny.hip: one dimension <= 64 (the class count), the other the node count -- HBM-bound shapes.  Return 1 = not taken.
+int egnn_skinny_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, int w_kmajor, const float* bias, float* Y, int64_t ldy,
+                    int64_t M, int64_t N, int64_t K, float alpha, hipStream_t st);
+int egnn_skinny_dx(const float* G, int64_t ldg, const float* B, int64_t ldb, int b_kmajor, float* Y, int64_t ldy, int64_t M, int64_t Nbig,
+                   int64_t Ks, float alpha, hipStream_t st);
+size_t egnn_skinny_dw_ws_floats(int64_t R, int64_t Ns, int64_t Nb);
+int egnn_skinny_dw(const float* S, int64_t lds_, const float* Bg, int64_t ldb, int64_t R, int64_t Ns, int64_t Nb, float alpha, float* C,
+                   int64_t c_ld_s, int64_t c_ld_b, float* ws, size_t ws_floats, hipStream_t st);
+
 namespace {
+
+// which skinny form (if any) a plain GEMM call takes: 1 fwd, 2 dx, 3 dw with the narrow matrix = A, 4 dw with the narrow matrix = B
+int skinny_kind(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, bool has_bias) {
+  if (!trans_a && N <= 64 && M >= 4096 && K % 16 == 0 && K >= 16 && K <= 1024) return 1;
+  if (!trans_a && K <= 64 && N % 64 == 0 && N >= 64 && N <= 1024 && M >= 4096 && !has_bias) return 2;
+  if (trans_a && !trans_b && K >= 4096 && !has_bias) {
+    if (M <= 64 && N % 64 == 0 && N >= 64) return 3;
+    if (N <= 64 && M % 64 == 0 && M >= 64) return 4;
+  }
+  return 0;
+}
 
 struct GemmArgs {
   int64_t M, N, K;
@@ -105,6 +125,16 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   EGNN_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N));
   // fused row gathers: rows of an [M,K]-stored A (the operand of x[idx] @ W^T) or of a [K,N]-stored B (dW = dY^T x[idx])
   EGNN_CHECK_ARG(!(a_rows && b_rows) && !(a_rows && trans_a) && !(b_rows && trans_b));
+  hipStream_t st0 = (hipStream_t)stream;
+  if (!a_rows && !b_rows) {   // class-count-wide shapes: dedicated HBM-bound kernels (gemm_skinny.hip); rc 1 = shape not taken
+    const int kind = skinny_kind(trans_a, trans_b, M, N, K, bias != nullptr);
+    int rc = 1;
+    if (kind == 1) rc = egnn_skinny_fwd(A, lda, B, ldb, trans_b, bias, C, ldc, M, N, K, alpha, st0);
+    else if (kind == 2) rc = egnn_skinny_dx(A, lda, B, ldb, trans_b, C, ldc, M, N, K, alpha, st0);
+    else if (kind == 3) rc = egnn_skinny_dw(A, lda, B, ldb, K, M, N, alpha, C, ldc, 1, ws, ws_bytes / sizeof(float), st0);
+    else if (kind == 4) rc = egnn_skinny_dw(B, ldb, A, lda, K, N, M, alpha, C, 1, ldc, ws, ws_bytes / sizeof(float), st0);
+    if (rc != 1) return rc;
+  }
   if (split_k < 1) split_k = 1;
   int64_t ksteps = (K + BK - 1) / BK;
   if (split_k > ksteps) split_k = (int)(ksteps > 0 ? ksteps : 1);
@@ -132,6 +162,15 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, g);
   }
   return egnn_launch_status();
+}
+
+extern "C" size_t egnn_gemm_ws_floats(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int split_k) {
+  size_t need = split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N : 0;
+  const int kind = skinny_kind(trans_a, trans_b, M, N, K, false);
+  size_t sk = 0;
+  if (kind == 3) sk = egnn_skinny_dw_ws_floats(K, M, N);
+  else if (kind == 4) sk = egnn_skinny_dw_ws_floats(K, N, M);
+  return need > sk ? need : sk;
 }
 
 extern "C" int egnn_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A,

@@ -91,11 +91,11 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
         use_lds = loc is not None and n_rows == n_src and K % 32 == 0
         rows_blk = loc[0] if use_lds else BLK_ROWS
         n_blk = (n_rows + rows_blk - 1) // rows_blk
-        # Y rows are stored write-through (dropped from L2: they are not re-read here and would only evict gathered X
-        # lines) unless the statistics epilogue re-reads them
-        flags = 0 if want_stats else 4
+        # Y rows are stored write-through (dropped from L2: they are not re-read here and would only evict gathered X lines)
+        flags = 4
         n_stat = lib.egnn_spmm_blk_stat_rows(n_rows, rows_blk, int(use_lds)) if want_stats else 0
-        stat_part = adj._scratch("stat", (n_stat, 2, K)) if want_stats else None
+        n_hub = crow.numel()
+        stat_part = adj._scratch("stat", (n_stat + n_hub, 2, K)) if want_stats else None   # one partial row per wave + per hub row
         if stat_shift is not None:
             stat_shift = stat_shift.detach().contiguous()
         rc = lib.egnn_spmm_csr_blk_f32(n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(adj._value), _lib.ptr(src_scale),
@@ -103,19 +103,17 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
                                        _lib.ptr(loc[1]) if use_lds else None, _lib.ptr(hseg), hseg.shape[0], _lib.ptr(partial),
                                        _lib.ptr(stat_part), _lib.ptr(stat_shift) if want_stats else None, flags, _lib.stream())
         if rc == 0:
-            if crow.numel() > 0:   # the hub rows: fixed-order sum of their partial slots (+ mean / bias)
-                rc = lib.egnn_spmm_csr_seg_f32(n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), bits, _lib.ptr(adj._value),
-                                               _lib.ptr(src_scale), _lib.ptr(bias), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0),
-                                               red, None, 0, _lib.ptr(crow), _lib.ptr(cptr), crow.numel(), _lib.ptr(partial), slots,
-                                               _lib.stream())
-                _lib.check(rc, "egnn_spmm_csr_seg_f32 (combine)")
+            if n_hub > 0:   # the hub rows: fixed-order sum of their partial slots (+ mean / bias, + their statistics rows)
+                _lib.check(lib.egnn_spmm_combine_f32(n_rows, K, _lib.ptr(rowptr), bits, _lib.ptr(bias), _lib.ptr(y), y.stride(0), red,
+                                                     _lib.ptr(crow), _lib.ptr(cptr), n_hub, _lib.ptr(partial), _lib.ptr(stat_part), n_stat,
+                                                     _lib.ptr(stat_shift) if want_stats else None, _lib.stream()), "egnn_spmm_combine_f32")
             if not want_stats:
                 return y, None
             mean = torch.empty(K, dtype=torch.float32, device=x.device)
             var = torch.empty(K, dtype=torch.float32, device=x.device)
             nws = lib.egnn_bn_stats_merge_ws_floats(K)
             ws = adj._scratch("statfold", (nws,))
-            _lib.check(lib.egnn_bn_stats_merge_f32(_lib.ptr(stat_part), n_stat, K, _lib.ptr(y), y.stride(0), _lib.ptr(crow), crow.numel(),
+            _lib.check(lib.egnn_bn_stats_merge_f32(_lib.ptr(stat_part), n_stat + n_hub, K, None, 0, None, 0,
                                                    _lib.ptr(stat_shift), n_rows, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(ws), nws,
                                                    _lib.stream()), "egnn_bn_stats_merge_f32")
             return y, None, (mean, var)
@@ -310,10 +308,12 @@ def gemm_raw(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False,
         # reductions over many rows into a small output (dW = X^T dY): spread K over the chip
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
         split_k = 1 if tiles >= 128 or K < 4096 else max(1, min(64, 512 // max(tiles, 1), K // 1024))
-    ws = None
-    if split_k > 1:
-        ws = torch.empty(split_k * M * N, dtype=torch.float32, device=a.device)
     lib = _lib.load()
+    ws = None
+    nws = lib.egnn_gemm_ws_floats(int(trans_a), int(trans_b), M, N, K, split_k) if (a_rows is None and b_rows is None) else \
+        (split_k * M * N if split_k > 1 else 0)
+    if nws > 0:
+        ws = torch.empty(nws, dtype=torch.float32, device=a.device)
     if a_rows is None and b_rows is None:
         rc = lib.egnn_gemm_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.ptr(a), a.stride(0), _lib.ptr(b),
                                b.stride(0), _lib.ptr(bias), _lib.ptr(c), c.stride(0), split_k, _lib.ptr(ws),

@@ -103,7 +103,7 @@ int egnn_spmm_csr_seg_f32(int64_t n_rows, int64_t n_src, int64_t K,
  * EGNN_EALIGN).
  *   hub_seg    [n_hub_seg,4] int32 (first entry, end entry, partial slot, 0): the entry ranges (<= seg_max entries each) of
  *              the rows with MORE than seg_max entries; their sums go to partial[slot,:] ([slots,K] fp32, 16-byte aligned)
- *              and the caller finishes those rows with the combine step of egnn_spmm_csr_seg_f32 (n_seg = 0, comb_* lists).
+ *              and the caller finishes those rows with egnn_spmm_combine_f32.
  *              Rows with at most seg_max entries are written here, completely.
  *   win        nullable [n_rows,2] int32 from egnn_spmm_blk_window_i32: entries [win[2r], win[2r+1]) of row r have their
  *              source inside row r's own block.  When given (square adjacency, X rows in node order, rows_per_blk a multiple
@@ -131,6 +131,14 @@ size_t egnn_bn_stats_merge_ws_floats(int64_t C);
 int egnn_bn_stats_merge_f32(const float* stat_part, int64_t n_blk, int64_t C, const float* Y, int64_t ldy,
                             const int64_t* extra_rows, int64_t n_extra, const float* stat_shift, int64_t n_total,
                             float* mean, float* var, float* ws, size_t ws_floats, void* stream);
+
+/* The combine step on its own -- the hub rows of egnn_spmm_csr_blk_f32: Y[r] = (sum of partial slots comb_ptr[i] .. comb_ptr[i+1]-1
+ * of row r = comb_rows[i], added in slot order) * (1 / rowcount for EGNN_MEAN) + bias.  K % 4 == 0, 16-byte aligned rows.
+ * stat_part != NULL: row (stat_base + i) of the [*, 2, K] statistics partials receives (y - shift) and (y - shift)^2 of
+ * combined row i (one partial row per hub row, folded by egnn_bn_stats_merge_f32 together with the block kernel's). */
+int egnn_spmm_combine_f32(int64_t n_rows, int64_t K, const void* rowptr, int index_bits, const float* bias, float* Y, int64_t ldy,
+                          int reduce, const int64_t* comb_rows, const int64_t* comb_ptr, int64_t n_comb, const float* partial,
+                          float* stat_part, int64_t stat_base, const float* stat_shift, void* stream);
 
 /* Backward of EGNN_MAX: dX[col[argmax[i,k]], k] += val * dY[i,k].  dX must be zero-filled by the
  * caller.  Uses float atomics (the only entry point that does); max-aggregation is never exercised
@@ -196,6 +204,9 @@ int egnn_gcn_norm_values_i64(const int64_t* rowptr_out, const int64_t* col_out, 
  * split_k > 1 writes split_k partial products into `ws` ([split_k, M, N] floats) and reduces them in
  * a fixed order (deterministic); ws may be NULL when split_k <= 1.
  * ---------------------------------------------------------------------------------------------- */
+/* Workspace floats a call with these arguments needs (split-K partials; the row-chunk partials of the class-count-wide dW
+ * form of csrc/gemm_skinny.hip).  0 = none. */
+size_t egnn_gemm_ws_floats(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int split_k);
 int egnn_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha,
                   const float* A, int64_t lda, const float* B, int64_t ldb,
                   const float* bias, float* C, int64_t ldc,

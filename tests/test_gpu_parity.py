@@ -351,6 +351,32 @@ def test_gemm_all_layouts(M, N, K, ta, tb):
     close(out, ref, rtol=1e-5, atol_scale=2e-6, msg=f"{M}x{N}x{K} ta={ta} tb={tb}")
 
 
+@pytest.mark.parametrize("M,N,K", [(5000, 40, 256), (4099, 64, 128), (9001, 7, 64), (6000, 48, 16)])
+@pytest.mark.parametrize("tb", [False, True])
+def test_gemm_skinny_output_layer_forms(M, N, K, tb):
+    """Class-count-wide shapes on the dedicated 16x16x4-MFMA kernels (csrc/gemm_skinny.hip): x W3 (+ bias), dX = dOut W3^T and
+    dW3 = X^T dOut (both weight layouts: GCNConv [in,out], nn.Linear [out,in]) against fp64 torch."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(*((N, K) if tb else (K, N)), generator=g)
+    bias = torch.randn(N, generator=g)
+    ref = x.double() @ (w.double().t() if tb else w.double()) + bias.double()
+    y = ops.gemm_raw(x.to(DEV), w.to(DEV), False, tb, bias.to(DEV))
+    close(y, ref, rtol=1e-5, atol_scale=1e-6)
+    y2 = ops.gemm_raw(x.to(DEV), w.to(DEV), False, tb, None, alpha=0.5)
+    close(y2, 0.5 * (ref - bias.double()), rtol=1e-5, atol_scale=1e-6)
+    # dX = dY op(W)': [M,N] x [N,K] -> [M,K] (needs K % 64 == 0 for the skinny form, else the general kernel: both must be right)
+    gy = torch.randn(M, N, generator=g)
+    dx = ops.gemm_raw(gy.to(DEV), w.to(DEV), False, not tb)
+    close(dx, gy.double() @ (w.double() if tb else w.double().t()), rtol=1e-5, atol_scale=1e-6)
+    # dW: both orientations of a^T b with the node count as the reduction
+    dw_a = ops.gemm_raw(x.to(DEV), gy.to(DEV), True, False)      # [K, N]  (GCNConv weight gradient)
+    close(dw_a, x.double().t() @ gy.double(), rtol=2e-5, atol_scale=2e-6)
+    dw_b = ops.gemm_raw(gy.to(DEV), x.to(DEV), True, False)      # [N, K]  (nn.Linear weight gradient)
+    close(dw_b, gy.double().t() @ x.double(), rtol=2e-5, atol_scale=2e-6)
+    assert torch.equal(dw_a, ops.gemm_raw(x.to(DEV), gy.to(DEV), True, False)), "fixed reduction order => bit-stable"
+
+
 def test_gemm_split_k_and_asymmetric_operand():
     # A = I with an asymmetric B catches row/column transposes of the MFMA fragment layout
     n = 160
@@ -1286,7 +1312,8 @@ def test_graphed_epoch_replays_equal_eager_steps(gnn, mode):
     np.testing.assert_allclose(got[:, :3], ref[:, :3], rtol=2e-5, atol=1e-7)
     # accuracies: eval-mode logits after Adam steps are rounding-noise sensitive (biases in front of BatchNorm, see
     # tests/golden/make_golden.py); allow a couple of argmax flips, report how far the parameters really are
-    worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-12)) for a, b in zip(m2.parameters(), m1.parameters()))
+    worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+                for (k, a), (_, b) in zip(m2.named_parameters(), m1.named_parameters()) if not noise_driven(k, 3))
     n_small = min(v.numel() for v in split.values())
     np.testing.assert_allclose(got[:, 3:], ref[:, 3:], atol=3.0 / n_small, err_msg=f"max relative parameter distance {worst:.2e}")
     assert worst < 1e-3, worst

@@ -93,7 +93,9 @@ def main():
     n_tr = 90941
     shapes = [("xW1 NN", n, 256, 128, False, False), ("xW2 NN", n, 256, 256, False, False), ("xW3 NN", n, 40, 256, False, False),
               ("proj_s NT", n_tr, 256, 256, False, True), ("proj_t NT", n_tr, 256, 750, False, True),
-              ("dX NT", n, 256, 256, False, True), ("dW TN", 256, 256, n, True, False), ("dWt TN", 256, 750, n_tr, True, False)]
+              ("dX NT", n, 256, 256, False, True), ("dW TN", 256, 256, n, True, False), ("dWt TN", 256, 750, n_tr, True, False),
+              # the class-count-wide backward forms of the output layer (csrc/gemm_skinny.hip)
+              ("dX3 NT", n, 256, 40, False, True), ("dW3 TN", 256, 40, n, True, False)]
     for label, M, N, K, ta, tb in (shapes if want('gemm') else ()):
         a = torch.randn((K, M) if ta else (M, K), device=DEV)
         b = torch.randn((N, K) if tb else (K, N), device=DEV)

@@ -236,12 +236,13 @@ int main(int argc, char** argv) {
                                      v.lds ? d_win : nullptr, d_hseg, n_hseg, d_partial, v.stats ? d_stat : nullptr,
                                      v.stats ? d_shift : nullptr, v.flags, st);
       if (rc) return rc;
-      if (!sp.crow.empty())   // combine step only (n_seg = 0): the hub segments were gathered by the block kernel's launch
-        rc = egnn_spmm_csr_seg_f32(n, n, K, d_rp, d_col, 32, d_val, nullptr, nullptr, d_x, K, d_y, K, EGNN_SUM, nullptr, 0, d_crow,
-                                   d_cptr, (int64_t)sp.crow.size(), d_partial, sp.slots, st);
+      const int64_t n_stat = v.stats ? egnn_spmm_blk_stat_rows(n, v.R, v.lds) : 0;
+      if (!sp.crow.empty())   // the hub rows: fixed-order sum of the partial slots the block kernel's launch filled
+        rc = egnn_spmm_combine_f32(n, K, d_rp, 32, nullptr, d_y, K, EGNN_SUM, d_crow, d_cptr, (int64_t)sp.crow.size(), d_partial,
+                                   v.stats ? d_stat : nullptr, n_stat, v.stats ? d_shift : nullptr, st);
       if (rc) return rc;
       if (v.stats)
-        rc = egnn_bn_stats_merge_f32(d_stat, nb * (v.lds ? 16 : 4), K, d_y, K, d_crow, (int64_t)sp.crow.size(), d_shift, n, d_mean, d_var, d_fold,
+        rc = egnn_bn_stats_merge_f32(d_stat, n_stat + (int64_t)sp.crow.size(), K, nullptr, 0, nullptr, 0, d_shift, n, d_mean, d_var, d_fold,
                                      egnn_bn_stats_merge_ws_floats(K), st);
       return rc;
     };
