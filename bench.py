@@ -60,6 +60,9 @@ def parse():
                          "off: eager launches")
     ap.add_argument("--probe-epochs", type=int, default=5, help="eager epochs with per-kernel HIP-event brackets for the roofline objects")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--workload", default="arxiv", choices=["arxiv", "mag"],
+                    help="arxiv: BASELINE.json configs[1] (the headline); mag: configs[4], the MAG-shaped SAGE-mean + KD run on "
+                         "node-range shards (sharded code path; with --gpus 1 use --force-sharded)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the node-range sharded (multi-GPU) code path even with one rank: RCCL init, halo plan, "
                          "SyncBN, row-block G-CRD -- a 1-GPU check of the path the N>1 runs take")
@@ -282,7 +285,7 @@ def main():
     import efficient_gnns_amd.models as PM
     import efficient_gnns_amd.ops as ops
 
-    if world > 1 or args.force_sharded:
+    if world > 1 or args.force_sharded or args.workload == "mag":
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
         import efficient_gnns_amd.dist as dist_mod

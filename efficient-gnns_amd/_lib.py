@@ -22,12 +22,12 @@ SIGNATURES = {
     "egnn_spmm_csr_f32": (_i32, [_i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p, _i64, _p, _i64, _p, _i64, _p]),
     "egnn_spmm_csr_seg_f32": (_i32, [_i64, _i64, _i64, _p, _p, _i32, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _i64, _p, _p, _i64, _p, _i64, _p]),
     "egnn_spmm_csr_blk_f32": (_i32, [_i64, _i64, _i64, _p, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _i32, _p, _i64, _p, _p, _i64, _p,
-                                     _p, _p, _i32, _p]),
+                                     _p, _i64, _p, _p, _i32, _p]),
     "egnn_spmm_blk_stat_rows": (_i64, [_i64, _i32, _i32]),
     "egnn_spmm_blk_window_i32": (_i32, [_p, _p, _i64, _i32, _p, _i64, _p, _p]),
     "egnn_bn_stats_merge_ws_floats": (_sz, [_i64]),
     "egnn_bn_stats_merge_f32": (_i32, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _sz, _p]),
-    "egnn_spmm_combine_f32": (_i32, [_i64, _i64, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i64, _p, _p, _i64, _p, _p]),
+    "egnn_spmm_combine_f32": (_i32, [_i64, _i64, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p]),
     "egnn_spmm_csr_max_bwd_f32": (_i32, [_i64, _i64, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p]),
     "egnn_spmm_algorithmic_bytes": (_i64, [_i64, _i64, _i64, _i64, _i32, _i32]),
     "egnn_csr_from_coo_ws_bytes": (_sz, [_i64, _i64, _i32]),

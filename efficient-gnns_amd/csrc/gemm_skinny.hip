@@ -26,11 +26,30 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
                                                          float* __restrict__ Y, int64_t ldy, int64_t M, int N, int K, float alpha) {
   extern __shared__ float sW[];
   constexpr int NP = NT * 16, LDW = NP + 4;
-  for (int i = threadIdx.x; i < K * NP; i += 256) {
-    const int k = i / NP, n = i % NP;
-    float v = 0.f;
-    if (n < N) v = w_kmajor ? W[(int64_t)n * ldw + k] : W[(int64_t)k * ldw + n];
-    sW[k * LDW + n] = v;
+  if (!w_kmajor && N % 4 == 0 && ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15u) == 0) {
+    // [K,N] row-major: 16-byte loads, four in flight per thread (a scalar loop spends the workgroup's life in load latency)
+    const int nq = N / 4, total = K * nq;
+    for (int i0 = threadIdx.x; i0 < total; i0 += 1024) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256;
+        v[u] = i < total ? *reinterpret_cast<const float4*>(W + (int64_t)(i / nq) * ldw + (i % nq) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 256;
+        if (i < total) *reinterpret_cast<float4*>(sW + (i / nq) * LDW + (i % nq) * 4) = v[u];
+      }
+    }
+    for (int i = threadIdx.x; i < K * (NP - N); i += 256) sW[(i / (NP - N)) * LDW + N + i % (NP - N)] = 0.f;
+  } else {
+    for (int i = threadIdx.x; i < K * NP; i += 256) {
+      const int k = w_kmajor ? i % K : i / NP, n = w_kmajor ? i / K : i % NP;   // k-major W: consecutive threads walk k (coalesced)
+      float v = 0.f;
+      if (n < N) v = w_kmajor ? W[(int64_t)n * ldw + k] : W[(int64_t)k * ldw + n];
+      sW[k * LDW + n] = v;
+    }
   }
   __syncthreads();
   const int lane = egnn_lane(), wave = egnn_wave_id();
@@ -90,64 +109,72 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Y[M,Nbig] = G[M,Ks] Wt,  Ks <= 64 (Ks % 4 == 0), Nbig % 64 == 0.   Wt given as B[k][n]: b_kmajor = 0 -> stored [Ks, Nbig];
-// b_kmajor = 1 -> stored [Nbig, Ks].  Output-write-bound: a wave owns 64 rows x 64 columns; column tile j of a wave holds
-// the columns {4 * (lane & 15) + j}, so the four tiles' accumulators of one row form a float4 (16-byte coalesced stores).
+// Y[M,Nbig] = G[M,Ks] Wt,  Ks <= 64, Nbig % 64 == 0.   Wt given as B[k][n]: b_kmajor = 0 -> stored [Ks, Nbig];
+// b_kmajor = 1 -> stored [Nbig, Ks].  Output-write-bound.  A wave owns ONE 64-column block for `rblocks` consecutive
+// 64-row blocks: its B fragments (Ks/4 steps x 4 column tiles; tile j = the columns {4 * (lane & 15) + j}) are loaded once
+// into registers and reused; per row block it streams G (4-byte loads, L1-resident after the first touch of a row) and
+// stores float4s (the four tiles' accumulators of one row are four consecutive columns: 16-byte coalesced stores).
+template <int KSTEPS>
 __global__ __launch_bounds__(256) void skinny_dx_kernel(const float* __restrict__ G, int64_t ldg, const float* __restrict__ B,
                                                         int64_t ldb, int b_kmajor, float* __restrict__ Y, int64_t ldy, int64_t M,
-                                                        int Nbig, int Ks, float alpha) {
-  extern __shared__ float sB[];   // [KP][Nbig], KP = Ks rounded up to 4 (rows past Ks are zero)
-  const int KP = (Ks + 3) / 4 * 4;
-  for (int i = threadIdx.x; i < KP * Nbig; i += 256) {
-    const int k = i / Nbig, n = i % Nbig;
-    float v = 0.f;
-    if (k < Ks) v = b_kmajor ? B[(int64_t)n * ldb + k] : B[(int64_t)k * ldb + n];
-    sB[i] = v;
-  }
-  __syncthreads();
+                                                        int Nbig, int Ks, float alpha, int rblocks) {
   const int lane = egnn_lane(), wave = egnn_wave_id();
   const int r16 = lane & 15, q = lane >> 4;
-  const int ncb = Nbig / 64;                       // 64-column blocks
-  const int64_t item = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t rb = item / ncb;
+  const int ncb = Nbig / 64;
+  const int64_t item = (int64_t)blockIdx.x * 4 + wave;   // (row super-block, column block)
+  const int64_t sb = item / ncb;
   const int cb = (int)(item % ncb);
-  const int64_t m0 = rb * 64;
-  if (m0 >= M) return;
-  const float* gp[4];
+  const int64_t mbeg = sb * 64 * rblocks;
+  if (mbeg >= M) return;
+  float4 bf[KSTEPS];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    int64_t r = m0 + t * 16 + r16;
-    if (r >= M) r = M - 1;
-    gp[t] = G + r * ldg;
+  for (int s = 0; s < KSTEPS; ++s) {
+    const int k = 4 * s + q;
+    bf[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < Ks) {
+      const int n = cb * 64 + 4 * r16;
+      if (!b_kmajor) bf[s] = *reinterpret_cast<const float4*>(B + (int64_t)k * ldb + n);
+      else bf[s] = make_float4(B[(int64_t)n * ldb + k], B[(int64_t)(n + 1) * ldb + k], B[(int64_t)(n + 2) * ldb + k], B[(int64_t)(n + 3) * ldb + k]);
+    }
   }
-  f4 acc[4][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int n = 0; n < 4; ++n) acc[t][n] = f4{0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < KP; k0 += 4) {             // one MFMA step: k = k0 + q
-    const int k = k0 + q;
-    float a[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a[t] = k < Ks ? gp[t][k] : 0.f;
-    const float4 b = *reinterpret_cast<const float4*>(sB + (int64_t)k * Nbig + cb * 64 + 4 * r16);   // columns 4*r16 .. +3
+  for (int rbi = 0; rbi < rblocks; ++rbi) {
+    const int64_t m0 = mbeg + (int64_t)rbi * 64;
+    if (m0 >= M) break;
+    const float* gp[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      acc[t][0] = mfma16(a[t], b.x, acc[t][0]);
-      acc[t][1] = mfma16(a[t], b.y, acc[t][1]);
-      acc[t][2] = mfma16(a[t], b.z, acc[t][2]);
-      acc[t][3] = mfma16(a[t], b.w, acc[t][3]);
+      int64_t r = m0 + t * 16 + r16;
+      if (r >= M) r = M - 1;
+      gp[t] = G + r * ldg + q;
     }
+    f4 acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[t][n] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {               // one MFMA step: k = 4s + q
+      float a[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = (4 * s + q < Ks) ? gp[t][4 * s] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc[t][0] = mfma16(a[t], bf[s].x, acc[t][0]);
+        acc[t][1] = mfma16(a[t], bf[s].y, acc[t][1]);
+        acc[t][2] = mfma16(a[t], bf[s].z, acc[t][2]);
+        acc[t][3] = mfma16(a[t], bf[s].w, acc[t][3]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + t * 16 + 4 * q + r;
+        if (row < M)
+          *reinterpret_cast<float4*>(Y + row * ldy + cb * 64 + 4 * r16) =
+              make_float4(alpha * acc[t][0][r], alpha * acc[t][1][r], alpha * acc[t][2][r], alpha * acc[t][3][r]);
+      }
   }
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int64_t row = m0 + t * 16 + 4 * q + r;
-      if (row < M)
-        *reinterpret_cast<float4*>(Y + row * ldy + cb * 64 + 4 * r16) =
-            make_float4(alpha * acc[t][0][r], alpha * acc[t][1][r], alpha * acc[t][2][r], alpha * acc[t][3][r]);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -271,13 +298,18 @@ int egnn_skinny_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, in
 int egnn_skinny_dx(const float* G, int64_t ldg, const float* B, int64_t ldb, int b_kmajor, float* Y, int64_t ldy, int64_t M, int64_t Nbig,
                    int64_t Ks, float alpha, hipStream_t st) {
   if (Ks > 64 || Ks < 1 || Nbig % 64 != 0 || Nbig < 64 || Nbig > 1024 || M < 4096 || ldy % 4 != 0 || !egnn_aligned16(Y)) return 1;
-  const size_t shm = (size_t)((Ks + 3) / 4 * 4) * Nbig * sizeof(float);
-  if (shm > 160 * 1024 - 2048) return 1;
-  if (shm > 65536 && hipFuncSetAttribute((const void*)skinny_dx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
-    return EGNN_ELAUNCH;
-  const int64_t items = (M + 63) / 64 * (Nbig / 64);
-  hipLaunchKernelGGL(skinny_dx_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), shm, st, G, ldg, B, ldb, b_kmajor, Y, ldy, M, (int)Nbig,
-                     (int)Ks, alpha);
+  if (!b_kmajor && (ldb % 4 != 0 || !egnn_aligned16(B))) return 1;
+  const int rblocks = 4;                                        // 256 rows per wave: the B fragments are loaded once per wave
+  const int64_t items = (M + 64 * rblocks - 1) / (64 * rblocks) * (Nbig / 64);
+  const unsigned grid = (unsigned)((items + 3) / 4);
+  const int ksteps = (int)((Ks + 3) / 4);
+#define EGNN_SK_DX(KS) hipLaunchKernelGGL(skinny_dx_kernel<KS>, dim3(grid), dim3(256), 0, st, G, ldg, B, ldb, b_kmajor, Y, ldy, M, (int)Nbig, (int)Ks, alpha, rblocks)
+  if (ksteps <= 4) EGNN_SK_DX(4);
+  else if (ksteps <= 8) EGNN_SK_DX(8);
+  else if (ksteps <= 10) EGNN_SK_DX(10);
+  else if (ksteps <= 12) EGNN_SK_DX(12);
+  else EGNN_SK_DX(16);
+#undef EGNN_SK_DX
   return egnn_launch_status();
 }
 

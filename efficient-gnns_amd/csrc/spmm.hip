@@ -37,6 +37,8 @@ struct SpmmArgs {
   int64_t n_list;
   const int64_t* seg;   // segment schedule (short-row kernel only): [n_list,3] = (first entry, end entry, destination)
   float* P;             // partial sums of the rows that were cut into several segments: [slots, K], ld = K
+  const float* addend;      // combine kernel only: nullable [n_rows][ld_add], added to every combined row
+  int64_t ld_add;
   float* stat_part;         // combine kernel only: [*, 2, K] rows stat_base + i receive (y - shift), (y - shift)^2 of combined row i
   const float* stat_shift;  // [K] nullable
   int64_t stat_base;
@@ -415,7 +417,8 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(const SpmmArgs<IdxT> 
       const float inv = a.mean ? 1.f / (float)(cnt > 0 ? cnt : 1) : 1.f;
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
       if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + cv * 4);
-      const float4 y = make_float4(s.x * inv + b.x, s.y * inv + b.y, s.z * inv + b.z, s.w * inv + b.w);
+      float4 y = make_float4(s.x * inv + b.x, s.y * inv + b.y, s.z * inv + b.z, s.w * inv + b.w);
+      if (a.addend) { const float4 ad = *reinterpret_cast<const float4*>(a.addend + row * a.ld_add + cv * 4); y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w; }
       *reinterpret_cast<float4*>(a.Y + row * a.ldy + cv * 4) = y;
       if (a.stat_part) {   // BatchNorm statistics of the aggregation epilogue: a hub row is one partial row of its own
         float4 sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -589,11 +592,11 @@ extern "C" int egnn_spmm_csr_f32(int64_t n_rows, int64_t n_src, int64_t K, const
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (index_bits == 32) {
     SpmmArgs<int32_t> a{n_rows, K, (const int32_t*)rowptr, (const int32_t*)col, val, src_scale, bias, X, ldx, Y, ldy,
-                        reduce == EGNN_MEAN, argmax, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+                        reduce == EGNN_MEAN, argmax, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0};
     return dispatch(a, reduce, plan, st);
   }
   SpmmArgs<int64_t> a{n_rows, K, (const int64_t*)rowptr, (const int64_t*)col, val, src_scale, bias, X, ldx, Y, ldy,
-                      reduce == EGNN_MEAN, argmax, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+                      reduce == EGNN_MEAN, argmax, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0};
   return dispatch(a, reduce, plan, st);
 }
 
@@ -613,11 +616,11 @@ extern "C" int egnn_spmm_csr_seg_f32(int64_t n_rows, int64_t n_src, int64_t K, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (index_bits == 32) {
     SpmmArgs<int32_t> a{n_rows, K, (const int32_t*)rowptr, (const int32_t*)col, val, src_scale, bias, X, ldx, Y, ldy,
-                        reduce == EGNN_MEAN, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+                        reduce == EGNN_MEAN, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0};
     return launch_segments(a, seg, n_seg, comb_rows, comb_ptr, n_comb, partial, st);
   }
   SpmmArgs<int64_t> a{n_rows, K, (const int64_t*)rowptr, (const int64_t*)col, val, src_scale, bias, X, ldx, Y, ldy,
-                      reduce == EGNN_MEAN, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+                      reduce == EGNN_MEAN, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0, 0};
   return launch_segments(a, seg, n_seg, comb_rows, comb_ptr, n_comb, partial, st);
 }
 
@@ -625,25 +628,27 @@ extern "C" int egnn_spmm_csr_seg_f32(int64_t n_rows, int64_t n_src, int64_t K, c
 // partial slots, in slot order) * inv + bias; optionally one statistics partial row per combined row.
 extern "C" int egnn_spmm_combine_f32(int64_t n_rows, int64_t K, const void* rowptr, int index_bits, const float* bias, float* Y,
                                      int64_t ldy, int reduce, const int64_t* comb_rows, const int64_t* comb_ptr, int64_t n_comb,
-                                     const float* partial, float* stat_part, int64_t stat_base, const float* stat_shift, void* stream) {
+                                     const float* partial, const float* addend, int64_t ld_addend, float* stat_part, int64_t stat_base,
+                                     const float* stat_shift, void* stream) {
   EGNN_CHECK_ARG(n_rows >= 0 && K >= 0 && ldy >= K && n_comb >= 0 && stat_base >= 0);
   EGNN_CHECK_ARG(index_bits == 32 || index_bits == 64);
   EGNN_CHECK_ARG(reduce == EGNN_SUM || reduce == EGNN_MEAN);
   if (n_comb == 0 || K == 0) return EGNN_OK;
   EGNN_CHECK_ARG(rowptr && Y && comb_rows && comb_ptr && partial && n_comb <= 0x7fffffffLL);
   if (K % 4 != 0 || ldy % 4 != 0 || !egnn_aligned16(Y) || !egnn_aligned16(partial) || (bias && !egnn_aligned16(bias)) ||
-      (stat_part && !egnn_aligned16(stat_part)) || (stat_shift && !egnn_aligned16(stat_shift)))
+      (stat_part && !egnn_aligned16(stat_part)) || (stat_shift && !egnn_aligned16(stat_shift)) ||
+      (addend && (!egnn_aligned16(addend) || ld_addend % 4 != 0 || ld_addend < K)))
     return EGNN_EALIGN;
   const int64_t kv = K / 4;
   const int kvp_log = ilog2_ceil(kv < 256 ? kv : 256);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (index_bits == 32) {
     SpmmArgs<int32_t> a{n_rows, K, (const int32_t*)rowptr, nullptr, nullptr, nullptr, bias, nullptr, 0, Y, ldy, reduce == EGNN_MEAN, nullptr,
-                        nullptr, 0, nullptr, const_cast<float*>(partial), stat_part, stat_shift, stat_base, 0, 0, 0};
+                        nullptr, 0, nullptr, const_cast<float*>(partial), addend, ld_addend, stat_part, stat_shift, stat_base, 0, 0, 0};
     hipLaunchKernelGGL((spmm_combine_kernel<int32_t>), dim3((unsigned)n_comb), dim3(256), 0, st, a, comb_rows, comb_ptr, kvp_log);
   } else {
     SpmmArgs<int64_t> a{n_rows, K, (const int64_t*)rowptr, nullptr, nullptr, nullptr, bias, nullptr, 0, Y, ldy, reduce == EGNN_MEAN, nullptr,
-                        nullptr, 0, nullptr, const_cast<float*>(partial), stat_part, stat_shift, stat_base, 0, 0, 0};
+                        nullptr, 0, nullptr, const_cast<float*>(partial), addend, ld_addend, stat_part, stat_shift, stat_base, 0, 0, 0};
     hipLaunchKernelGGL((spmm_combine_kernel<int64_t>), dim3((unsigned)n_comb), dim3(256), 0, st, a, comb_rows, comb_ptr, kvp_log);
   }
   return egnn_launch_status();

@@ -50,6 +50,8 @@ struct BlkArgs {
   const int32_t* hseg;     // [n_hseg][4]: (first entry, end entry, partial slot, 0) of the hub-row segments
   int64_t n_hseg;
   float* P;                // [slots][K] partial sums of the hub segments
+  const float* addend;     // nullable [n_rows][ld_add]: added to every stored row (accumulating aggregation)
+  int64_t ld_add;
   float* stat_part;        // [n_blk * waves per workgroup][2][K]
   const float* stat_shift; // [K] nullable
   int NS, map_mode;
@@ -268,7 +270,8 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_blk_kernel(const BlkArgs a) {
       }
       if (colok) {
         const float inv = a.mean ? 1.f / (float)(cnt_[j] > 0 ? cnt_[j] : 1) : 1.f;
-        const float4 y = make_float4(acc[j][0] * inv + bias.x, acc[j][1] * inv + bias.y, acc[j][2] * inv + bias.z, acc[j][3] * inv + bias.w);
+        float4 y = make_float4(acc[j][0] * inv + bias.x, acc[j][1] * inv + bias.y, acc[j][2] * inv + bias.z, acc[j][3] * inv + bias.w);
+        if (a.addend) { const float4 ad = *reinterpret_cast<const float4*>(a.addend + (int64_t)row * a.ld_add + col0); y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w; }
         store_row4(a.Y + (int64_t)row * a.ldy + col0, y, a.flags);
         if constexpr (STATS) tally(y);
       }
@@ -287,7 +290,8 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_blk_kernel(const BlkArgs a) {
         if (colok) {
           if (a.bias) bias = *reinterpret_cast<const float4*>(a.bias + col0);
           const float inv = a.mean ? 1.f / (float)(cnt > 0 ? cnt : 1) : 1.f;
-          const float4 y = make_float4(acc[0] * inv + bias.x, acc[1] * inv + bias.y, acc[2] * inv + bias.z, acc[3] * inv + bias.w);
+          float4 y = make_float4(acc[0] * inv + bias.x, acc[1] * inv + bias.y, acc[2] * inv + bias.z, acc[3] * inv + bias.w);
+          if (a.addend) { const float4 ad = *reinterpret_cast<const float4*>(a.addend + (int64_t)row * a.ld_add + col0); y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w; }
           store_row4(a.Y + (int64_t)row * a.ldy + col0, y, a.flags);
           if constexpr (STATS) tally(y);
         }
@@ -306,7 +310,8 @@ __global__ __launch_bounds__(WAVES * 64) void spmm_blk_kernel(const BlkArgs a) {
       if (colok) {
         if (a.bias) bias = *reinterpret_cast<const float4*>(a.bias + col0);   // L1-resident; not held across the gathers
         const float inv = a.mean ? 1.f / (float)(cnt > 0 ? cnt : 1) : 1.f;
-        const float4 y = make_float4(acc[0] * inv + bias.x, acc[1] * inv + bias.y, acc[2] * inv + bias.z, acc[3] * inv + bias.w);
+        float4 y = make_float4(acc[0] * inv + bias.x, acc[1] * inv + bias.y, acc[2] * inv + bias.z, acc[3] * inv + bias.w);
+        if (a.addend) { const float4 ad = *reinterpret_cast<const float4*>(a.addend + (int64_t)row * a.ld_add + col0); y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w; }
         store_row4(a.Y + (int64_t)row * a.ldy + col0, y, a.flags);
         if constexpr (STATS) tally(y);
       }
@@ -469,14 +474,15 @@ extern "C" int egnn_spmm_csr_blk_f32(int64_t n_rows, int64_t n_src, int64_t K, c
                                      const float* val, const float* src_scale, const float* bias, const float* X, int64_t ldx,
                                      float* Y, int64_t ldy, int reduce, int seg_max, int rows_per_blk, const int32_t* blk_ptr,
                                      int64_t n_blk, const int32_t* win, const int32_t* hub_seg, int64_t n_hub_seg, float* partial,
-                                     float* stat_part, const float* stat_shift, int flags, void* stream) {
+                                     const float* addend, int64_t ld_addend, float* stat_part, const float* stat_shift, int flags,
+                                     void* stream) {
   EGNN_CHECK_ARG(n_rows >= 0 && n_src >= 0 && K >= 0 && ldx >= K && ldy >= K);
   EGNN_CHECK_ARG(reduce == EGNN_SUM || reduce == EGNN_MEAN);
   EGNN_CHECK_ARG(rows_per_blk > 0 && rows_per_blk % 32 == 0 && seg_max > 0 && n_hub_seg >= 0);
   if (n_rows == 0 || K == 0) return EGNN_OK;
   EGNN_CHECK_ARG(rowptr && col && X && Y && (n_hub_seg == 0 || (hub_seg && partial)));
   if (K % 4 != 0 || ldx % 4 != 0 || ldy % 4 != 0 || !egnn_aligned16(X) || !egnn_aligned16(Y) || (bias && !egnn_aligned16(bias)) ||
-      (partial && !egnn_aligned16(partial)))
+      (partial && !egnn_aligned16(partial)) || (addend && (!egnn_aligned16(addend) || ld_addend % 4 != 0 || ld_addend < K)))
     return EGNN_EALIGN;
   const uint64_t xb = (uint64_t)n_src * (uint64_t)ldx * 4ull;
   if (xb > 0x7FFFFFFFull) return EGNN_EALIGN;  // 32-bit descriptor offsets: the host uses the 64-bit kernels of spmm.hip
@@ -485,7 +491,7 @@ extern "C" int egnn_spmm_csr_blk_f32(int64_t n_rows, int64_t n_src, int64_t K, c
   const bool lds = win != nullptr;
   EGNN_CHECK_ARG(!lds || (n_src == n_rows && rows_per_blk <= 512 && rows_per_blk % 128 == 0));
   BlkArgs a{n_rows, K, rowptr, col, val, src_scale, bias, X, ldx, Y, ldy, reduce == EGNN_MEAN, seg_max, rows_per_blk, blk_ptr, n_blk,
-            win, hub_seg, n_hub_seg, partial, stat_part, stat_shift, 0, 0, (uint32_t)xb, flags};
+            win, hub_seg, n_hub_seg, partial, addend, ld_addend, stat_part, stat_shift, 0, 0, (uint32_t)xb, flags};
   a.NS = (int)((K + 31) / 32);
   a.map_mode = (a.NS <= 8 && 8 % a.NS == 0) ? 1 : (a.NS % 8 == 0 ? 2 : 0);
   const int nsub = lds ? 128 : 32;

@@ -41,42 +41,102 @@ def node_range(n: int, world: int, rank: int):
     return lo, min(lo + per, n), per
 
 
-class ShardPlan:
-    """Local view of a global CSR for one rank: remapped columns + halo send / receive lists."""
+_OVERLAP = os.environ.get("EGNN_DIST_OVERLAP", "1") != "0"
 
-    def __init__(self, rowptr: Tensor, col: Tensor, value: Tensor | None, n: int, world: int, rank: int):
-        rowptr, col = rowptr.cpu(), col.cpu()
+
+def _agg(adj, x, addend=None):
+    """Local sum-aggregation of a shard piece (the single-GPU kernels; tests swap in the oracle through ``ops.spmm``)."""
+    return ops.spmm(adj, x, "sum", addend=addend)
+
+
+class ShardPlan:
+    """Local view of one rank's rows of a global CSR: remapped columns + halo send / receive lists.
+
+    Extended column ids: [0, n_local) = the rank's own nodes, n_local + j = halo node ``halo_ids[j]`` (ascending global id, so
+    grouped by owner).  ``send_idx``: local row ids the peers need, grouped by peer (each group ascending);
+    ``send_counts[p]`` / ``recv_counts[p]``: rows sent to / received from peer p in one halo exchange."""
+
+    def __init__(self, n, world, rank, rowptr_local, col_global, value_local, send_idx, send_counts):
         self.n, self.world, self.rank = n, world, rank
         lo, hi, per = node_range(n, world, rank)
         self.lo, self.hi, self.per, self.n_local = lo, hi, per, hi - lo
-        e0, e1 = int(rowptr[lo]), int(rowptr[hi])
-        c = col[e0:e1]
+        c = col_global
         remote = (c < lo) | (c >= hi)
         self.halo_ids = torch.unique(c[remote])                       # ascending => grouped by owner
         owner = torch.div(self.halo_ids, per, rounding_mode="floor")
         self.recv_counts = torch.bincount(owner, minlength=world).tolist()
-        col_ext = torch.where(remote, self.n_local + torch.searchsorted(self.halo_ids, c), c - lo)
-        self.rowptr_local = (rowptr[lo:hi + 1] - e0).contiguous()
-        self.col_ext = col_ext.contiguous()
-        self.value_local = None if value is None else value.cpu()[e0:e1].contiguous()
-        send, counts = [], []
-        for p in range(world):
-            if p == rank:
-                counts.append(0)
-                continue
-            plo, phi, _ = node_range(n, world, p)
-            cp = col[int(rowptr[plo]):int(rowptr[phi])]
-            need = torch.unique(cp[(cp >= lo) & (cp < hi)]) - lo      # my rows that p's rows reference
-            send.append(need)
-            counts.append(need.numel())
-        self.send_idx = torch.cat(send) if send else torch.zeros(0, dtype=torch.int64)
-        self.send_counts = counts
+        self.col_ext = torch.where(remote, self.n_local + torch.searchsorted(self.halo_ids, c), c - lo).contiguous()
+        self.remote_mask = remote
+        self.rowptr_local = rowptr_local.contiguous()
+        self.value_local = None if value_local is None else value_local.contiguous()
+        self.send_idx, self.send_counts = send_idx, list(send_counts)
         self.n_halo = self.halo_ids.numel()
 
+    # ---- construction ---------------------------------------------------------------------------
+    @classmethod
+    def from_global(cls, rowptr: Tensor, col: Tensor, value: Tensor | None, n: int, world: int, rank: int) -> "ShardPlan":
+        """From the GLOBAL CSR, without communication (single-process tools and tests): what a peer needs from this rank
+        is read off the peer's rows directly."""
+        lo, hi, per = node_range(n, world, rank)
+        e0, e1 = int(rowptr[lo]), int(rowptr[hi])
+        row_owner = torch.div(torch.repeat_interleave(torch.arange(n, device=col.device), rowptr[1:] - rowptr[:-1]), per,
+                              rounding_mode="floor")
+        mine = (col >= lo) & (col < hi) & (row_owner != rank)
+        keys = torch.unique(row_owner[mine] * n + col[mine])          # (peer, my node) pairs, sorted by peer then node
+        send_idx = keys % n - lo
+        send_counts = torch.bincount(torch.div(keys, n, rounding_mode="floor"), minlength=world).tolist()
+        return cls(n, world, rank, rowptr[lo:hi + 1] - e0, col[e0:e1], None if value is None else value[e0:e1], send_idx, send_counts)
+
+    @classmethod
+    def from_local(cls, rowptr_local: Tensor, col_global: Tensor, value_local: Tensor | None, n: int, world: int, rank: int,
+                   group=None) -> "ShardPlan":
+        """COLLECTIVE: every rank passes only ITS rows (rowptr starting at 0, global column ids).  The halo lists are agreed
+        on by exchanging index lists (one all_to_all of counts, one of ids): no rank ever holds the global structure --
+        what the MAG-scale graph needs."""
+        lo, hi, per = node_range(n, world, rank)
+        plan = cls(n, world, rank, rowptr_local, col_global, value_local, torch.zeros(0, dtype=torch.int64, device=col_global.device),
+                   [0] * world)
+        if world > 1:
+            dev = col_global.device
+            need_counts = torch.tensor(plan.recv_counts, dtype=torch.int64, device=dev)      # rows I need from each peer
+            give_counts = torch.empty(world, dtype=torch.int64, device=dev)
+            dist.all_to_all_single(give_counts, need_counts, group=group)
+            send_counts = give_counts.tolist()
+            wanted = torch.empty(int(sum(send_counts)), dtype=torch.int64, device=dev)
+            dist.all_to_all_single(wanted, plan.halo_ids.contiguous(), send_counts, plan.recv_counts, group=group)
+            plan.send_idx, plan.send_counts = wanted - lo, send_counts
+        return plan
+
+    # ---- the pieces the aggregation uses -----------------------------------------------------------
     def local_adj(self, device) -> SparseTensor:
+        """All entries over the extended columns [own | halo] (one aggregation after the exchange)."""
         return SparseTensor(rowptr=self.rowptr_local.to(device), col=self.col_ext.to(device),
                             value=None if self.value_local is None else self.value_local.to(device),
                             sparse_sizes=(self.n_local, self.n_local + self.n_halo))
+
+    def split_adj(self, device, value: Tensor | None = None):
+        """(entries with an own column, entries with a halo column): the second one can only run after the exchange, the
+        first one overlaps it.  ``value``: per-entry values to use instead of ``value_local``."""
+        val = self.value_local if value is None else value
+        rows = torch.repeat_interleave(torch.arange(self.n_local, device=self.col_ext.device),
+                                       self.rowptr_local[1:] - self.rowptr_local[:-1])
+        out = []
+        for mask, ncol, off in ((~self.remote_mask, self.n_local, 0), (self.remote_mask, self.n_halo, self.n_local)):
+            r, c = rows[mask], self.col_ext[mask] - off
+            rp = torch.zeros(self.n_local + 1, dtype=torch.int64, device=r.device)
+            torch.cumsum(torch.bincount(r, minlength=self.n_local), 0, out=rp[1:])
+            out.append(SparseTensor(rowptr=rp.to(device), col=c.contiguous().to(device),
+                                    value=None if val is None else val[mask].contiguous().to(device), sparse_sizes=(self.n_local, ncol)))
+        return out
+
+    def scatter_adj(self, device) -> SparseTensor:
+        """[n_local, n_send] 0/1 matrix: row send_idx[j] holds entry j.  Aggregating the rows received by the REVERSE
+        exchange with it adds every peer's contribution into the owner's rows in a fixed order (columns ascending = peer
+        order) -- one kernel, no atomics, instead of one indexed add per peer."""
+        order = torch.argsort(self.send_idx, stable=True)
+        rp = torch.zeros(self.n_local + 1, dtype=torch.int64, device=self.send_idx.device)
+        torch.cumsum(torch.bincount(self.send_idx, minlength=self.n_local), 0, out=rp[1:])
+        return SparseTensor(rowptr=rp.to(device), col=order.to(device), sparse_sizes=(self.n_local, self.send_idx.numel()))
 
 
 class _HaloExchange(torch.autograd.Function):
@@ -100,43 +160,121 @@ class _HaloExchange(torch.autograd.Function):
         sadj = ctx.sadj
         plan, group = sadj.plan, sadj.group
         K = g_ext.shape[1]
-        g_local = g_ext[:plan.n_local].clone()
         g_halo = g_ext[plan.n_local:].contiguous()
         back = torch.empty(plan.send_idx.numel(), K, dtype=g_ext.dtype, device=g_ext.device)
         dist.all_to_all_single(back, g_halo, plan.send_counts, plan.recv_counts, group=group)
-        off = 0
-        for p, cnt in enumerate(plan.send_counts):  # ids are unique within one peer's list: fixed-order, no atomics
-            if cnt:
-                idx = sadj.send_idx_dev[off:off + cnt]
-                g_local[idx] += back[off:off + cnt]
-                off += cnt
+        g_local = g_ext[:plan.n_local].contiguous()
+        if back.shape[0]:
+            g_local = _agg(sadj.scatter, back, addend=g_local)        # fixed-order accumulation into the owners' rows
         return g_local, None
 
 
-class ShardedAdj:
-    """What the convs receive as ``adj_t`` on a sharded run: the rank's rows of A (and of A^ = gcn_norm(A))."""
+class _OverlapAggregate(torch.autograd.Function):
+    """y = A_own x_own + A_halo x_halo with the halo exchange IN FLIGHT under the first product (and, in the backward, the
+    reverse exchange under A_own^T g): the entries of a shard are split by column ownership, so the overlap does not
+    depend on the graph having interior rows (on a graph without locality there are none)."""
 
-    def __init__(self, adj_global: SparseTensor, world: int, rank: int, device, group=None, gcn_values: Tensor | None = None,
-                 gcn_struct: SparseTensor | None = None):
-        rowptr, col, _ = adj_global.csr()
-        n = adj_global.sparse_size(0)
-        self.group, self.device = group, device
-        self.plan = ShardPlan(rowptr, col, None, n, world, rank)
-        self.send_idx_dev = self.plan.send_idx.to(device)
-        self.raw = self.plan.local_adj(device)
+    @staticmethod
+    def forward(ctx, x_local, sadj, a_own, a_halo, static_halo):
+        plan, group = sadj.plan, sadj.group
+        K = x_local.shape[1]
+        work = None
+        if static_halo is not None:
+            x_halo = static_halo
+        else:
+            send_buf = x_local.index_select(0, sadj.send_idx_dev).contiguous()
+            x_halo = torch.empty(plan.n_halo, K, dtype=x_local.dtype, device=x_local.device)
+            work = dist.all_to_all_single(x_halo, send_buf, plan.recv_counts, plan.send_counts, group=group, async_op=True)
+        y = _agg(a_own, x_local)                                    # runs while the halo rows travel
+        if work is not None:
+            work.wait()
+        if plan.n_halo:
+            y = _agg(a_halo, x_halo, addend=y)
+        ctx.sadj, ctx.pieces = sadj, (a_own, a_halo)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        sadj = ctx.sadj
+        a_own, a_halo = ctx.pieces
+        plan, group = sadj.plan, sadj.group
+        g_y = g_y.contiguous()
+        K = g_y.shape[1]
+        work = None
+        back = torch.empty(plan.send_idx.numel(), K, dtype=g_y.dtype, device=g_y.device)
+        g_halo = _agg(a_halo.t(), g_y) if plan.n_halo else torch.zeros(0, K, dtype=g_y.dtype, device=g_y.device)
+        work = dist.all_to_all_single(back, g_halo, plan.send_counts, plan.recv_counts, group=group, async_op=True)
+        g_x = _agg(a_own.t(), g_y)                                  # runs while the halo gradients travel back
+        work.wait()
+        if back.shape[0]:
+            g_x = _agg(sadj.scatter, back, addend=g_x)
+        return g_x, None, None, None, None
+
+
+class ShardedAdj:
+    """What the convs receive as ``adj_t`` on a sharded run: the rank's rows of A (and of A^ = gcn_norm(A)).
+
+    Built from the rank's OWN rows only (``rowptr_local`` starting at 0, global column ids); the halo lists come from
+    ``ShardPlan.from_local`` (a collective) and, for A^, the degrees of the halo nodes from one exchange of a vector."""
+
+    def __init__(self, rowptr_local: Tensor, col_global: Tensor, n: int, world: int, rank: int, device, group=None,
+                 with_gcn: bool = True, _plan: ShardPlan | None = None):
+        self.group, self.device = group, torch.device(device)
+        collective = world > 1 and dist.is_available() and dist.is_initialized()
+        make = (lambda rp, c, v: ShardPlan.from_local(rp, c, v, n, world, rank, group)) if collective or world == 1 else None
+        if _plan is not None:
+            self.plan = _plan
+        elif make is not None:
+            self.plan = make(rowptr_local.to(self.device), col_global.to(self.device), None)
+        else:
+            raise RuntimeError("ShardedAdj with world > 1 needs an initialised process group (or a plan built by ShardPlan.from_global)")
+        self._finish()
         self._gcn = None
-        if gcn_struct is not None:  # normalised adjacency (structure differs: self loops inserted)
-            rp, c, v = gcn_struct.csr()
+        if with_gcn:
             self._gcn = ShardedAdj.__new__(ShardedAdj)
-            self._gcn.group, self._gcn.device = group, device
-            self._gcn.plan = ShardPlan(rp, c, v, n, world, rank)
-            self._gcn.send_idx_dev = self._gcn.plan.send_idx.to(device)
-            self._gcn.raw = self._gcn.plan.local_adj(device)
+            self._gcn.group, self._gcn.device = group, self.device
+            self._gcn.plan = self._gcn_plan(rowptr_local.to(self.device), col_global.to(self.device), n, world, rank, group, make)
+            self._gcn._finish()
             self._gcn._gcn = None
+
+    def _finish(self):
+        dev = self.device
+        self.send_idx_dev = self.plan.send_idx.to(dev)
+        self.raw = self.plan.local_adj(dev)
+        self.scatter = self.plan.scatter_adj(dev)
+        self._pieces = {}
+        self._static = None
+
+    @staticmethod
+    def _gcn_plan(rowptr_local, col_global, n, world, rank, group, make):
+        """Rows of A^ = D^-1/2 (A + I) D^-1/2 for this shard (PyG gcn_norm, SparseTensor branch: existing diagonal removed, one
+        loop per node, deg = row sums of ones).  Self loops are own columns, so the halo set is that of A; the only remote
+        quantity is deg^-1/2 of the halo nodes: one exchange of a [n_local] vector."""
+        lo, hi, _ = node_range(n, world, rank)
+        n_local = hi - lo
+        dev = col_global.device
+        rows = torch.repeat_interleave(torch.arange(n_local, device=dev), rowptr_local[1:] - rowptr_local[:-1])
+        keep = col_global != rows + lo
+        loops = torch.arange(n_local, device=dev)
+        r2, c2 = torch.cat([rows[keep], loops]), torch.cat([col_global[keep], loops + lo])
+        order = torch.argsort(r2 * n + c2, stable=True)
+        r2, c2 = r2[order], c2[order]
+        rp = torch.zeros(n_local + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(torch.bincount(r2, minlength=n_local), 0, out=rp[1:])
+        plan = make(rp, c2, None)
+        dinv = (rp[1:] - rp[:-1]).to(torch.float32).pow(-0.5)
+        dinv.masked_fill_(dinv == float("inf"), 0.0)
+        dinv_ext = torch.empty(n_local + plan.n_halo, dtype=torch.float32, device=dev)
+        dinv_ext[:n_local] = dinv
+        if plan.world > 1 and dist.is_initialized():
+            dist.all_to_all_single(dinv_ext[n_local:], dinv.index_select(0, plan.send_idx).contiguous(), plan.recv_counts, plan.send_counts,
+                                   group=group)
+        plan.value_local = ((1.0 * dinv[r2]) * dinv_ext[plan.col_ext]).contiguous()      # (1 * dinv[row]) * dinv[col], as PyG forms it
+        return plan
 
     def gcn_normalized(self) -> "ShardedAdj":
         if self._gcn is None:
-            raise RuntimeError("ShardedAdj was built without the normalised adjacency (pass gcn_struct=)")
+            raise RuntimeError("ShardedAdj was built without the normalised adjacency (with_gcn=False)")
         return self._gcn
 
     def register_static(self, x_local: Tensor) -> None:
@@ -144,16 +282,40 @@ class ShardedAdj:
         from the peers ONCE and kept next to the local rows, as a partitioned graph store keeps the features of a
         partition's halo nodes.  Every later aggregation of exactly this tensor skips the exchange (2 of the 8 per
         epoch, 22 % of the halo volume of the GCN run).  Collective: all ranks must register."""
-        self._static = (x_local, _HaloExchange.apply(x_local.detach(), self), x_local._version)
+        x_ext = _HaloExchange.apply(x_local.detach(), self)
+        self._static = (x_local, x_ext, x_local._version)
         if self._gcn is not None:
             self._gcn.register_static(x_local)
 
+    def _split(self, mean: bool, valueless: bool):
+        """(own-column piece, halo-column piece) of the aggregation matrix actually applied: A^ values, or 1 / rowcount per
+        entry for ``mean`` (sum of the two pieces = the mean over all of the row's entries), or no values (sum)."""
+        key = (mean, valueless)
+        if key not in self._pieces:
+            val = None if valueless else self.plan.value_local
+            if mean:
+                cnt = (self.plan.rowptr_local[1:] - self.plan.rowptr_local[:-1]).clamp(min=1).to(torch.float32)
+                inv = torch.repeat_interleave(1.0 / cnt, self.plan.rowptr_local[1:] - self.plan.rowptr_local[:-1])
+                val = inv if val is None else val * inv
+                own, halo = self.plan.split_adj(self.device, value=val)
+            elif val is None:
+                saved, self.plan.value_local = self.plan.value_local, None
+                own, halo = self.plan.split_adj(self.device)
+                self.plan.value_local = saved
+            else:
+                own, halo = self.plan.split_adj(self.device)
+            self._pieces[key] = (own, halo)
+        return self._pieces[key]
+
     def aggregate(self, x_local: Tensor, reduce: str, valueless: bool = False) -> Tensor:
-        st = getattr(self, "_static", None)
-        if st is not None and st[0] is x_local and not x_local.requires_grad and x_local._version == st[2]:   # version AT registration
-            x_ext = st[1]
-        else:
-            x_ext = _HaloExchange.apply(x_local, self)
+        if reduce not in ("sum", "add", "mean"):
+            raise NotImplementedError(f"sharded aggregation supports sum / mean, not '{reduce}'")
+        st = self._static
+        static = st is not None and st[0] is x_local and not x_local.requires_grad and x_local._version == st[2]   # version AT registration
+        if _OVERLAP:
+            own, halo = self._split(reduce == "mean", valueless)
+            return _OverlapAggregate.apply(x_local, self, own, halo, st[1][self.plan.n_local:] if static else None)
+        x_ext = st[1] if static else _HaloExchange.apply(x_local, self)
         adj = self.raw.set_value(None) if valueless and self.raw.has_value() else self.raw
         return ops.spmm(adj, x_ext, reduce)
 
@@ -310,15 +472,15 @@ class ShardedProblem:
     """Everything one rank holds: its rows of x / y / teacher artefacts, local train / eval index sets."""
 
     def __init__(self, data, world: int, rank: int, device, group=None, need_gcn: bool = True):
-        from .sparse import gcn_norm
         n = data.num_nodes
         self.world, self.rank, self.group, self.device = world, rank, group, device
         lo, hi, _ = node_range(n, world, rank)
         self.lo, self.hi, self.n = lo, hi, n
-        gcn_struct = None
-        if need_gcn:
-            gcn_struct = gcn_norm(data.adj_t.to(device)) if torch.device(device).type == "cuda" else data.gcn_struct
-        self.adj = ShardedAdj(data.adj_t, world, rank, device, group, gcn_struct=gcn_struct)
+        # this rank's rows only (a data loader would read just these; the synthetic generator makes the whole graph on the
+        # host of every rank, deterministically, and the slice is taken here)
+        rowptr, col, _ = data.adj_t.csr()
+        e0, e1 = int(rowptr[lo]), int(rowptr[hi])
+        self.adj = ShardedAdj((rowptr[lo:hi + 1] - e0), col[e0:e1], n, world, rank, device, group, with_gcn=need_gcn)
         self.x = data.x[lo:hi].to(device)
         self.adj.register_static(self.x)          # input features never change: halo copy fetched once
         self.y = data.y[lo:hi].to(device)
@@ -477,6 +639,23 @@ def sharded_evaluate(model, prob: ShardedProblem):
 # ------------------------------------------------------------------------------------------------
 # bench entry (called by bench.py when WORLD_SIZE > 1)
 # ------------------------------------------------------------------------------------------------
+def mag_problem(scale: float, seed: int):
+    """BASELINE.json configs[4] shape: the ogbn-mag graph made homogeneous (N = 1 939 743, 42.2 M directed entries after the
+    reverse edges, x [N,128], 349 classes; /root/reference/mag_pyg/gnn.py:322-346), a GraphSage(mean) student distilled
+    from (synthetic) R-GCN teacher logits -- the operator of mag_pyg/gnn.py:151,162 on node-range shards."""
+    from . import data as D
+    d = D.mag_like(scale, seed=seed)
+    g = torch.Generator().manual_seed(seed + 5)
+    n = d.num_nodes
+    d.y = torch.randint(0, d.num_classes, (n, 1), generator=g)
+    perm = torch.randperm(n, generator=g)
+    n_tr, n_va = int(0.325 * n), int(0.033 * n)        # 629 571 / 64 879 / 41 939 labelled papers of 1.94 M nodes
+    d.split_idx = {"train": perm[:n_tr].clone(), "valid": perm[n_tr:n_tr + n_va].clone(), "test": perm[n_tr + n_va:n_tr + 2 * n_va].clone()}
+    d.teacher_logits = torch.randn(n, d.num_classes, generator=g) * 3.0
+    d.teacher_out_feat = None
+    return d
+
+
 def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", emit=print):
     from . import data as D
     from . import models as PM
@@ -494,9 +673,12 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
         dist.barrier()
         if on_gpu:
             torch.cuda.synchronize()
-    data = D.arxiv_like(args.scale, seed=args.seed)        # same seeded graph on every rank (host-side, one-off)
-    if not on_gpu:  # CPU (gloo) runs get the normalised structure from the caller-provided hook
-        data.gcn_struct = args.cpu_gcn_struct(data)
+    workload = getattr(args, "workload", "arxiv")
+    if workload == "mag":    # config 5: SAGE-mean student + logit KD on the MAG-shaped graph
+        data = mag_problem(args.scale, args.seed)
+        args.gnn, args.training = "sage", "kd"
+    else:
+        data = D.arxiv_like(args.scale, seed=args.seed)        # same seeded graph on every rank (host-side, one-off)
     prob = ShardedProblem(data, world, rank, device, None, need_gcn=(args.gnn == "gcn"))
     Net = PM.GCN if args.gnn == "gcn" else PM.SAGE
     model = Net(data.num_features, model_cfg["hidden"], data.num_classes, model_cfg["layers"], model_cfg["dropout"]).to(device)
@@ -507,7 +689,6 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
         sp = swap_batchnorm(PM.make_projection(model_cfg["hidden"], hp["proj_dim"]).to(device))
         tp = swap_batchnorm(PM.make_projection(data.teacher_out_feat.shape[1], hp["proj_dim"]).to(device))
         groups += [{"params": sp.parameters(), "lr": model_cfg["lr"]}, {"params": tp.parameters(), "lr": model_cfg["lr"]}]
-    import os
     opt = torch.optim.Adam(groups, fused=(on_gpu and os.environ.get("EGNN_ADAM", "fused") == "fused"))
     torch.manual_seed(args.seed + 1000 + rank)               # dropout masks differ per shard
 
@@ -524,29 +705,57 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
     import gc
     gc.collect()
     gc.freeze()
+    # rank 0 brackets its local aggregation launches (HIP events on the launch stream) for the roofline object
+    probe_records = []
+    orig_raw = ops.spmm_raw
+    if on_gpu and rank == 0:
+        def probed(adj, x, *a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_raw(adj, x, *a, **kw)
+            e1.record()
+            probe_records.append((x.shape[1], adj.sparse_sizes(), adj.nnz(), adj.spmm_algorithmic_bytes(x.shape[1]), e0, e1))
+            return out
+        ops.spmm_raw = probed
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses, accs = epoch()
     sync()
+    ops.spmm_raw = orig_raw
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     halo = torch.tensor([float(prob.adj.plan.n_halo)], device=device)
     dist.all_reduce(halo)
     if rank == 0:
         el = float(elapsed)
+        roofline = None
+        if probe_records:   # the widest aggregation of the step, per launch on rank 0's shard (algorithmic bytes of the shard's pieces)
+            kmax = max(r[0] for r in probe_records)
+            sel = [r for r in probe_records if r[0] == kmax]
+            secs = sum(a.elapsed_time(b) for *_, a, b in sel) * 1e-3
+            nbytes = sum(r[3] for r in sel)
+            gbs = nbytes / secs / 1e9
+            roofline = dict(bound="hbm", kernel=f"rank 0's local aggregation launches (egnn_spmm_csr_blk_f32 on the shard's own-column and "
+                                                f"halo-column pieces), K={kmax}", achieved=round(gbs, 1), peak=8000.0, unit="GB/s",
+                            frac=round(gbs / 8000.0, 4), launches_timed=len(sel), algorithmic_bytes_timed=int(nbytes), traffic=None)
+        if workload == "mag":
+            metric = "training epochs/sec, ogbn-mag-shaped graph, GraphSage(mean) student + logit KD, node-range shards"
+            wl = (f"ogbn-mag-shaped synthetic homogeneous graph (N={data.num_nodes}, nnz={data.adj_t.nnz()}), {model_cfg['layers']}-layer "
+                  f"SAGE-{model_cfg['hidden']} (mean) student + logit KD from synthetic teacher logits, full-graph train step + eval per epoch")
+        else:
+            metric = "training epochs/sec, ogbn-arxiv 3-layer GCN student + G-CRD, 1/2/4/8 MI355X"
+            wl = (f"ogbn-arxiv-shaped synthetic graph (N={data.num_nodes}, nnz_sym={data.adj_t.nnz()}), 3-layer {args.gnn.upper()}-256 student + "
+                  f"{args.training} loss (max_samples={hp['max_samples']}, proj_dim={hp['proj_dim']}), full-graph train step + eval per epoch")
         out = dict(
-            metric="training epochs/sec, ogbn-arxiv 3-layer GCN student + G-CRD, 1/2/4/8 MI355X",
-            value=round(args.steps / el, 3), unit="epochs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+            metric=metric, value=round(args.steps / el, 3), unit="epochs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
             ms_per_step=round(1e3 * el / args.steps, 3), higher_is_better=True, scaling="strong", vs_baseline=None,
             dtype="f32", data="synthetic",
-            config=dict(workload=f"ogbn-arxiv-shaped synthetic graph (N={data.num_nodes}, nnz_sym={data.adj_t.nnz()}), "
-                                 f"3-layer {args.gnn.upper()}-256 student + {args.training} loss, full-graph train step + eval "
-                                 f"per epoch", gnn=args.gnn, training=args.training, hidden=model_cfg["hidden"],
-                        layers=model_cfg["layers"], max_samples=hp["max_samples"], proj_dim=hp["proj_dim"],
-                        partitioning=f"node-range shards x{world}, halo all_to_all + SyncBN all-reduce + flat grad all-reduce over RCCL",
+            config=dict(workload=wl,
+                        partitioning=f"node-range shards x{world}: halo all_to_all {'overlapped with the own-column aggregation' if _OVERLAP else '(blocking)'}"
+                                     f" + SyncBN all-reduce + flat grad all-reduce over RCCL",
                         mean_halo_rows_per_rank=int(float(halo) / world)),
-            roofline=None, cpu_baseline=None,
+            roofline=roofline, cpu_baseline=None,
             last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs])
     dist.barrier()
     dist.destroy_process_group()

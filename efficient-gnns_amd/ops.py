@@ -45,13 +45,15 @@ class HipStatsUnavailable(RuntimeError):
 
 
 def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = None, use_plan: bool = True,
-             bias: Tensor | None = None, out: Tensor | None = None, stat_shift: Tensor | None = None, want_stats: bool = False):
+             bias: Tensor | None = None, out: Tensor | None = None, stat_shift: Tensor | None = None, want_stats: bool = False,
+             addend: Tensor | None = None):
     """Y = REDUCE(adj, X) on the GPU.  Returns (Y, argmax | None), or (Y, None, (mean, biased var)) with ``want_stats``.
 
     Schedules: 'blocks' (default; egnn_spmm_csr_blk_f32: one launch over hub segments + row blocks, int32 indices, then the
     fixed-order combine of the hub rows), 'segments' (round-1 egnn_spmm_csr_seg_f32), 'classes' (egnn_spmm_csr_f32: also the
     path of ``max`` and of shapes the float4 kernels do not take).
     ``out``: optional [n_rows, K] destination with unit column stride (e.g. a column block of a wider matrix).
+    ``addend``: optional [n_rows, K] matrix added to the result in the kernel's store (Y = A X + addend; sum / mean).
     ``want_stats`` (sum / mean on the block schedule only): per-column mean and biased variance of Y over all rows, formed in
     the aggregation's epilogue (BatchNorm statistics, gnn.py:47-48); ``stat_shift`` [K]: shift of the shifted sums."""
     _lib.require_gpu(x, adj._col)
@@ -68,10 +70,16 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
     else:
         y = torch.empty(n_rows, K, dtype=torch.float32, device=x.device)
     arg = torch.empty(n_rows, K, dtype=torch.int64, device=x.device) if red == 2 else None
+    if addend is not None:
+        if red == 2 or tuple(addend.shape) != (n_rows, K) or addend.dtype != torch.float32:
+            raise ValueError("spmm_raw: `addend` is a float32 [n_rows, K] matrix (sum / mean only)")
+        addend = _rowmajor(addend)
     if adj.nnz() == 0:   # no stored entry at all: every row is empty (sum / mean / max = 0, argmax = -1), plus the bias
         y.zero_()
         if bias is not None:
             y.add_(bias)
+        if addend is not None:
+            y.add_(addend)
         if arg is not None:
             arg.fill_(-1)
         if want_stats:
@@ -81,9 +89,11 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
     lib = _lib.load()
     float4_ok = (use_plan and red != 2 and K % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
                  and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0 and (bias is None or bias.data_ptr() % 16 == 0))
+    add_fused = addend is not None and addend.stride(0) % 4 == 0 and addend.data_ptr() % 16 == 0
     # the block schedule wins from two 128-byte column slices up (K = 256: 343 vs 385 us, K = 128: 167 vs 186 us on the
     # arxiv-shaped graph); below that (the 40-class output layer) the 16-lane form of the segment kernel is faster (92 vs 113 us)
-    if float4_ok and _SPMM_SCHEDULE == "blocks" and bits == 32 and K >= 64 and n_src * x.stride(0) * 4 < 2 ** 31 and n_rows > 0:
+    if (float4_ok and _SPMM_SCHEDULE == "blocks" and bits == 32 and K >= 64 and n_src * x.stride(0) * 4 < 2 ** 31 and n_rows > 0
+            and (addend is None or add_fused)):
         from .sparse import BLK_ROWS, SEG_MAX
         hseg, crow, cptr, slots = adj._blk_plan()
         partial = adj._scratch("partial", (max(slots, 1), K))
@@ -101,11 +111,13 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
         rc = lib.egnn_spmm_csr_blk_f32(n_rows, n_src, K, _lib.ptr(rowptr), _lib.ptr(col), _lib.ptr(adj._value), _lib.ptr(src_scale),
                                        _lib.ptr(bias), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), red, SEG_MAX, rows_blk, None, 0,
                                        _lib.ptr(loc[1]) if use_lds else None, _lib.ptr(hseg), hseg.shape[0], _lib.ptr(partial),
+                                       _lib.ptr(addend), 0 if addend is None else addend.stride(0),
                                        _lib.ptr(stat_part), _lib.ptr(stat_shift) if want_stats else None, flags, _lib.stream())
         if rc == 0:
             if n_hub > 0:   # the hub rows: fixed-order sum of their partial slots (+ mean / bias, + their statistics rows)
                 _lib.check(lib.egnn_spmm_combine_f32(n_rows, K, _lib.ptr(rowptr), bits, _lib.ptr(bias), _lib.ptr(y), y.stride(0), red,
-                                                     _lib.ptr(crow), _lib.ptr(cptr), n_hub, _lib.ptr(partial), _lib.ptr(stat_part), n_stat,
+                                                     _lib.ptr(crow), _lib.ptr(cptr), n_hub, _lib.ptr(partial), _lib.ptr(addend),
+                                                     0 if addend is None else addend.stride(0), _lib.ptr(stat_part), n_stat,
                                                      _lib.ptr(stat_shift) if want_stats else None, _lib.stream()), "egnn_spmm_combine_f32")
             if not want_stats:
                 return y, None
@@ -129,6 +141,8 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
                                        _lib.ptr(bias), _lib.ptr(x), x.stride(0), _lib.ptr(y), y.stride(0), red, _lib.ptr(seg),
                                        seg.shape[0], _lib.ptr(crow), _lib.ptr(cptr), crow.numel(), _lib.ptr(partial), slots, _lib.stream())
         if rc == 0:
+            if addend is not None:
+                y.add_(addend)
             return y, None
         if rc != -4:   # EGNN_EALIGN: shape outside the segment kernel's float4 forms -> classic schedule below
             _lib.check(rc, "egnn_spmm_csr_seg_f32")
@@ -163,6 +177,8 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
     else:
         rc = launch(short, mid, long_, _lib.stream())
     _lib.check(rc, "egnn_spmm_csr_f32")
+    if addend is not None:
+        y.add_(addend)
     return y, arg
 
 
@@ -216,7 +232,7 @@ def colsum(g: Tensor) -> Tensor:
 
 
 def spmm(adj, x: Tensor, reduce: str = "sum", bias: Tensor | None = None, bn_stats_shift: Tensor | None = None,
-         want_bn_stats: bool = False) -> Tensor:
+         want_bn_stats: bool = False, addend: Tensor | None = None) -> Tensor:
     """adj @ x with the given reduction; ``bias`` ([K]) is added in the kernel's store (sum / mean only).
 
     ``want_bn_stats``: the caller will BatchNorm the result next (gnn.py:47-48): the column mean / biased variance are
@@ -225,6 +241,10 @@ def spmm(adj, x: Tensor, reduce: str = "sum", bias: Tensor | None = None, bn_sta
     epilogue nothing is attached and ``bn_act`` runs its own statistics pass."""
     if reduce not in _REDUCE:
         raise ValueError(f"unknown reduce '{reduce}'")
+    if addend is not None:   # accumulating form (adj @ x + addend), used without autograd by the sharded run's own Functions
+        if torch.is_grad_enabled() and (x.requires_grad or addend.requires_grad):
+            raise NotImplementedError("spmm(addend=...) is a forward-only form")
+        return spmm_raw(adj, x, reduce, bias=bias, addend=addend)[0]
     if bias is not None and (reduce == "max" or (x.shape[1] % 4 == 0 and bias.data_ptr() % 16 != 0)):
         return _SpMM.apply(x, adj, reduce, None)[0] + bias
     y, mean, var = _SpMM.apply(x, adj, reduce, bias, bn_stats_shift, bool(want_bn_stats) and reduce != "max")

@@ -109,6 +109,8 @@ int egnn_spmm_csr_seg_f32(int64_t n_rows, int64_t n_src, int64_t K,
  *              source inside row r's own block.  When given (square adjacency, X rows in node order, rows_per_blk a multiple
  *              of 128, <= 512) the block's X rows are streamed into LDS (LDS-DMA) while the out-of-block entries are
  *              gathered, and the in-block entries read LDS instead of L2 (graphs in a locality order).
+ *   addend     nullable [n_rows, ld_addend] fp32: added to every row this call stores (Y = A X + addend): the sharded run
+ *              aggregates its local and its halo columns in two calls, the second one accumulating onto the first
  *   stat_part  nullable [egnn_spmm_blk_stat_rows(n_rows, rows_per_blk, win != NULL), 2, K] fp32: per WAVE of every row block
  *              sum_r (y_r - shift) and sum_r (y_r - shift)^2 over the rows that wave stored -- BatchNorm statistics in the
  *              aggregation epilogue (gnn.py:47-48), finished by egnn_bn_stats_merge_f32 (n_blk = that row count);
@@ -120,6 +122,7 @@ int egnn_spmm_csr_blk_f32(int64_t n_rows, int64_t n_src, int64_t K,
                           const float* X, int64_t ldx, float* Y, int64_t ldy, int reduce,
                           int seg_max, int rows_per_blk, const int32_t* blk_ptr, int64_t n_blk, const int32_t* win,
                           const int32_t* hub_seg, int64_t n_hub_seg, float* partial,
+                          const float* addend, int64_t ld_addend,
                           float* stat_part, const float* stat_shift, int flags, void* stream);
 int64_t egnn_spmm_blk_stat_rows(int64_t n_rows, int rows_per_blk, int lds);
 int egnn_spmm_blk_window_i32(const int32_t* rowptr, const int32_t* col, int64_t n_rows, int rows_per_blk,
@@ -133,12 +136,14 @@ int egnn_bn_stats_merge_f32(const float* stat_part, int64_t n_blk, int64_t C, co
                             float* mean, float* var, float* ws, size_t ws_floats, void* stream);
 
 /* The combine step on its own -- the hub rows of egnn_spmm_csr_blk_f32: Y[r] = (sum of partial slots comb_ptr[i] .. comb_ptr[i+1]-1
- * of row r = comb_rows[i], added in slot order) * (1 / rowcount for EGNN_MEAN) + bias.  K % 4 == 0, 16-byte aligned rows.
+ * of row r = comb_rows[i], added in slot order) * (1 / rowcount for EGNN_MEAN) + bias (+ addend[r], nullable).  K % 4 == 0,
+ * 16-byte aligned rows.
  * stat_part != NULL: row (stat_base + i) of the [*, 2, K] statistics partials receives (y - shift) and (y - shift)^2 of
  * combined row i (one partial row per hub row, folded by egnn_bn_stats_merge_f32 together with the block kernel's). */
 int egnn_spmm_combine_f32(int64_t n_rows, int64_t K, const void* rowptr, int index_bits, const float* bias, float* Y, int64_t ldy,
                           int reduce, const int64_t* comb_rows, const int64_t* comb_ptr, int64_t n_comb, const float* partial,
-                          float* stat_part, int64_t stat_base, const float* stat_shift, void* stream);
+                          const float* addend, int64_t ld_addend, float* stat_part, int64_t stat_base, const float* stat_shift,
+                          void* stream);
 
 /* Backward of EGNN_MAX: dX[col[argmax[i,k]], k] += val * dY[i,k].  dX must be zero-filled by the
  * caller.  Uses float atomics (the only entry point that does); max-aggregation is never exercised

@@ -29,7 +29,8 @@ def _patch_ops_with_oracle():
         rowptr, col, val = adj.csr()
         return OS.SparseTensor(rowptr=rowptr, col=col, value=val, sparse_sizes=adj.sparse_sizes())
 
-    ops.spmm = lambda adj, x, reduce="sum", bias=None, **_: OS.matmul(to_oracle(adj), x, reduce) + (0 if bias is None else bias)
+    ops.spmm = lambda adj, x, reduce="sum", bias=None, addend=None, **_: (OS.matmul(to_oracle(adj), x, reduce) + (0 if bias is None else bias)
+                                                                            + (0 if addend is None else addend))
     ops.take_rows = lambda x, idx: x[idx]
     ops.matmul = lambda x, w, bias=None: x @ w if bias is None else x @ w + bias
     ops.linear = lambda x, w, b=None: F.linear(x, w, b)
@@ -162,7 +163,7 @@ def test_shard_plan_integer_logic():
     d = _make_data(seed=7)
     rowptr, col, _ = d.adj_t.csr()
     n, world = d.num_nodes, 3
-    plans = [DD.ShardPlan(rowptr, col, None, n, world, r) for r in range(world)]
+    plans = [DD.ShardPlan.from_global(rowptr, col, None, n, world, r) for r in range(world)]
     dense = torch.zeros(n, n)
     dense[d.adj_t.storage.row(), col] = 1
     for r, p in enumerate(plans):
@@ -183,42 +184,88 @@ def test_shard_plan_integer_logic():
             assert torch.equal(pq.send_idx[so:so + pq.send_counts[r]] + pq.lo, ids)
 
 
-def _bench_worker(rank, world, port, path):
+def _bench_worker(rank, world, port, path, workload="arxiv", overlap="1"):
     import types
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), EGNN_DIST_OVERLAP=overlap)
     _patch_ops_with_oracle()
-    import efficient_gnns_amd as E
     import efficient_gnns_amd.dist as DD
-    import oracle.sparse as OS
-
-    def cpu_gcn(data):
-        rowptr, col, _ = data.adj_t.csr()
-        g = OS.gcn_norm_sparse(OS.SparseTensor(rowptr=rowptr, col=col, sparse_sizes=data.adj_t.sparse_sizes()))
-        return E.SparseTensor(rowptr=g.csr()[0], col=g.csr()[1], value=g.csr()[2], sparse_sizes=g.sparse_sizes())
-    args = types.SimpleNamespace(seed=0, scale=0.004, gnn="gcn", training="nce", warmup=1, steps=2, cpu_gcn_struct=cpu_gcn)
+    args = types.SimpleNamespace(seed=0, scale=0.004 if workload == "arxiv" else 0.0006, gnn="gcn", training="nce", warmup=1, steps=2,
+                                 workload=workload)
     hp = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=128, proj_dim=16, kernel="rbf")
-    cfg = dict(hidden=32, layers=3, dropout=0.5, lr=0.01)
+    cfg = dict(hidden=32, layers=3 if workload == "arxiv" else 2, dropout=0.5, lr=0.01)
     lines = []
     DD.bench_main(args, hp, cfg, rank, world, "cpu", backend="gloo", emit=lines.append)
     if rank == 0:
         open(path, "w").write(lines[0])
 
 
-def test_bench_entry_point_runs_sharded_and_prints_contract_json(tmp_path):
+@pytest.mark.parametrize("workload,world,overlap", [("arxiv", 2, "1"), ("arxiv", 2, "0"), ("mag", 2, "1"), ("mag", 4, "1")])
+def test_bench_entry_point_runs_sharded_and_prints_contract_json(tmp_path, workload, world, overlap):
+    """bench.py's multi-rank entry (dist.bench_main) over gloo: the headline workload with and without the halo / compute
+    overlap, and BASELINE.json configs[4] (MAG-shaped graph, SAGE-mean + logit KD) on 2 and 4 node-range shards."""
     import json
-    world = 2
     ctx = mp.get_context("spawn")
     path = str(tmp_path / "bench.json")
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, path)) for r in range(world)]
+    port = 31500 + (os.getpid() + hash((workload, world, overlap))) % 2000
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, path, workload, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(300)
+        p.join(600)
         assert p.exitcode == 0
     out = json.loads(open(path).read())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config"):
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in out
-    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and "workload" in out["config"]
+    assert out["n_gpus"] == world and out["scaling"] == "strong" and out["value"] > 0 and "workload" in out["config"]
+    assert ("mag" in out["config"]["workload"]) == (workload == "mag")
     assert all(np.isfinite(out["last_losses"]))
+
+
+def _plan_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import efficient_gnns_amd.dist as DD
+        d = _make_data(seed=7)
+        rowptr, col, _ = d.adj_t.csr()
+        n = d.num_nodes
+        lo, hi, _ = DD.node_range(n, world, rank)
+        e0, e1 = int(rowptr[lo]), int(rowptr[hi])
+        loc = DD.ShardPlan.from_local(rowptr[lo:hi + 1] - e0, col[e0:e1], None, n, world, rank)     # own rows only + index-list exchange
+        glo = DD.ShardPlan.from_global(rowptr, col, None, n, world, rank)                           # read off the global structure
+        same = (torch.equal(loc.send_idx, glo.send_idx) and loc.send_counts == glo.send_counts and loc.recv_counts == glo.recv_counts
+                and torch.equal(loc.halo_ids, glo.halo_ids) and torch.equal(loc.col_ext, glo.col_ext))
+        # local GCN normalisation of the shard == the rows of the globally normalised matrix (values bit-for-bit: same formula)
+        sadj = DD.ShardedAdj(rowptr[lo:hi + 1] - e0, col[e0:e1], n, world, rank, "cpu", None, with_gcn=True)
+        g = d.gcn_struct
+        grp, gcol, gval = g.csr()
+        g0, g1 = int(grp[lo]), int(grp[hi])
+        pl = sadj.gcn_normalized().plan
+        ext_to_global = torch.cat([torch.arange(lo, hi), pl.halo_ids])
+        same_gcn = (torch.equal(pl.rowptr_local, grp[lo:hi + 1] - g0) and torch.equal(ext_to_global[pl.col_ext], gcol[g0:g1])
+                    and torch.allclose(pl.value_local, gval[g0:g1], rtol=1e-6, atol=0))
+        # the scatter matrix adds every received row into its owner row exactly once
+        sc = sadj.scatter
+        ok_scatter = sc.nnz() == loc.send_idx.numel() and torch.equal(torch.sort(sc.csr()[1]).values, torch.arange(sc.nnz()))
+        got = [None] * world
+        dist.all_gather_object(got, (same, same_gcn, ok_scatter))
+        if rank == 0:
+            q.put(got)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_collective_plan_from_local_rows_equals_the_global_plan(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 33500 + (os.getpid() + world) % 2000
+    procs = [ctx.Process(target=_plan_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(all(t) for t in got), got

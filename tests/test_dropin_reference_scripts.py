@@ -153,7 +153,8 @@ def _host_layer_worker(q, gnn, mode):
         g = OS.gcn_norm_sparse(to_oracle(adj))
         return E.SparseTensor(rowptr=g.csr()[0], col=g.csr()[1], value=g.csr()[2], sparse_sizes=g.sparse_sizes())
     PN.gcn_norm = gcn_norm
-    ops.spmm = lambda adj, x, reduce="sum", bias=None, **_: OS.matmul(to_oracle(adj), x, reduce) + (0 if bias is None else bias)
+    ops.spmm = lambda adj, x, reduce="sum", bias=None, addend=None, **_: (OS.matmul(to_oracle(adj), x, reduce) + (0 if bias is None else bias)
+                                                                            + (0 if addend is None else addend))
     ops.matmul = lambda x, w, bias=None: x @ w if bias is None else x @ w + bias
     ops.linear = lambda x, w, b=None: F.linear(x, w, b)
     ops.take_rows = lambda x, idx: x[idx]

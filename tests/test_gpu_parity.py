@@ -205,6 +205,9 @@ def test_spmm_schedules_agree_with_oracle(schedule, K, monkeypatch):
     y1, _ = ops.spmm_raw(p, x.to(DEV), "sum")
     y2, _ = ops.spmm_raw(p, x.to(DEV), "sum")
     assert torch.equal(y1, y2), "fixed summation order => run-to-run bit-stable"
+    add = torch.randn(n, K, generator=g)
+    ya, _ = ops.spmm_raw(p, x.to(DEV), "mean", bias=bias.to(DEV), addend=add.to(DEV))     # Y = A X + bias + addend (hub rows included)
+    close(ya, o.matmul(x, "mean") + bias + add, msg=f"{schedule} addend")
 
 
 @pytest.mark.parametrize("K,reduce", [(256, "sum"), (64, "mean"), (128, "sum")])
@@ -1386,3 +1389,20 @@ def test_arxiv_gat_teacher_vs_oracle_and_artifact_files(use_attn_dst, sym, tmp_p
     D.save_teacher_artifacts(str(tmp_path), "gat-3L250x3h", 0, fp, pp)
     f2, l2 = D.load_teacher_artifacts(str(tmp_path), "gat-3L250x3h", 0, num_nodes=n, device=DEV)
     assert torch.equal(f2, fp) and torch.equal(l2, pp)
+
+
+@pytest.mark.gpu
+def test_bench_mag_workload_runs_on_one_rank_over_rccl():
+    """BASELINE.json configs[4] through bench.py on ONE rank over the real RCCL backend (the sharded code path with an empty
+    halo): MAG-shaped graph at 1 % size, SAGE-mean + logit KD; the JSON line carries the roofline of rank 0's aggregation."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "mag", "--scale", "0.01", "--steps", "2", "--warmup", "1",
+                          "--gpus", "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert "mag" in line["config"]["workload"] and line["n_gpus"] == 1 and line["value"] > 0
+    assert line["roofline"] and line["roofline"]["achieved"] > 0 and all(np.isfinite(line["last_losses"]))

@@ -233,12 +233,12 @@ int main(int argc, char** argv) {
         return egnn_spmm_csr_seg_f32(n, n, K, d_rp, d_col, 32, d_val, nullptr, nullptr, d_x, K, d_y, K, EGNN_SUM, d_seg_all,
                                      (int64_t)sp.seg_all.size() / 3, d_crow, d_cptr, (int64_t)sp.crow.size(), d_partial, sp.slots, st);
       int rc = egnn_spmm_csr_blk_f32(n, n, K, d_rp, d_col, d_val, nullptr, nullptr, d_x, K, d_y, K, EGNN_SUM, seg_max, v.R, d_blk, n_blk,
-                                     v.lds ? d_win : nullptr, d_hseg, n_hseg, d_partial, v.stats ? d_stat : nullptr,
+                                     v.lds ? d_win : nullptr, d_hseg, n_hseg, d_partial, nullptr, 0, v.stats ? d_stat : nullptr,
                                      v.stats ? d_shift : nullptr, v.flags, st);
       if (rc) return rc;
       const int64_t n_stat = v.stats ? egnn_spmm_blk_stat_rows(n, v.R, v.lds) : 0;
       if (!sp.crow.empty())   // the hub rows: fixed-order sum of the partial slots the block kernel's launch filled
-        rc = egnn_spmm_combine_f32(n, K, d_rp, 32, nullptr, d_y, K, EGNN_SUM, d_crow, d_cptr, (int64_t)sp.crow.size(), d_partial,
+        rc = egnn_spmm_combine_f32(n, K, d_rp, 32, nullptr, d_y, K, EGNN_SUM, d_crow, d_cptr, (int64_t)sp.crow.size(), d_partial, nullptr, 0,
                                    v.stats ? d_stat : nullptr, n_stat, v.stats ? d_shift : nullptr, st);
       if (rc) return rc;
       if (v.stats)
