@@ -1,6 +1,8 @@
 // Dense fp32 GEMM entry point (K4): C = alpha * op(A) op(B) (+ bias), on the f32-input MFMA.
 // Replaces cuBLAS SGEMM under `x @ W` (GCNConv), nn.Linear (SAGEConv, projection heads) and their
 // backward GEMMs (/root/reference/arxiv_pyg/gnn.py:47,79,296-306,192).
+#include <cstdlib>
+
 #include "gemm_core.h"
 
 using namespace egnn_gemm;
@@ -39,6 +41,7 @@ struct GemmArgs {
   int64_t k_per_split;     // multiple of BK
   float* ws;               // [split_k, M, N] when split_k > 1
   const int64_t* rows;     // GATHER 1: storage rows of A ([M,K]) ; GATHER 2: storage rows of B ([K,N]); else unused
+  int wide_store;          // output rows 16-byte aligned: epilogue through LDS with 16-byte stores
 };
 
 // epilogue of one output tile (or of one split-K partial)
@@ -65,6 +68,54 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TM_][TN_], const 
   }
 }
 
+// The same epilogue through LDS: a wave's accumulators (a column per lane, 4-byte stores of 128 bytes per row) are turned
+// into rows in the operand buffers, which are free once the main loop has finished, and leave as 16-byte stores -- 256 B
+// contiguous per 16 lanes, 16 store instructions per wave instead of 64.  (The narrow stores were ~14 % of a K = 256 GEMM:
+// profiles/r01_gemm_mainloop_ablation.txt, "no epilogue".)  Needs 16-byte aligned output rows; else store_tile.
+template <int BM, int BN, int TM_, int TN_>
+__device__ __forceinline__ void store_tile_wide(const f32x16 (&acc)[TM_][TN_], const GemmArgs& g, int64_t m0, int64_t n0, int split,
+                                                int lane, int wm, int wn, float* smem) {
+  constexpr int WM = BM / 2, WN = BN / 2, LD = WN + 4, F4 = WN / 4, RPI = 64 / F4;   // float4 per row, rows per store instruction
+  static_assert(4 * 32 * LD <= TileShape<BM, BN>::SMEM_FLOATS, "epilogue staging must fit the operand buffers");
+  const bool partial = g.split_k > 1;
+  const float alpha = partial ? 1.f : g.alpha * (g.alpha_dev ? g.alpha_dev[0] : 1.f);
+  float* out = partial ? g.ws + (int64_t)split * g.M * g.N : g.C;
+  const int64_t ldo = partial ? g.N : g.ldc;
+  float* sm = smem + (wm * 2 + wn) * (32 * LD);
+  const bool cols_full = n0 + BN <= g.N;
+  __syncthreads();   // every wave is done with the operand tiles
+#pragma unroll
+  for (int tm = 0; tm < TM_; ++tm) {
+#pragma unroll
+    for (int tn = 0; tn < TN_; ++tn) {
+      const int64_t c = n0 + wn * WN + tn * 32 + (lane & 31);
+      const float bv = (!partial && g.bias && c < g.N) ? g.bias[c] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sm[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LD + tn * 32 + (lane & 31)] = alpha * acc[tm][tn][r] + bv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the wave's LDS stores are ordered before its loads (other lanes' data)
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 / RPI; ++it) {
+      const int rin = it * RPI + lane / F4, c4 = (lane % F4) * 4;
+      const int64_t row = m0 + wm * WM + tm * 32 + rin;
+      const int64_t col = n0 + wn * WN + c4;
+      const float4 v = *reinterpret_cast<const float4*>(sm + rin * LD + c4);
+      float* o = out + row * ldo + col;
+      if (cols_full) {               // block-uniform: the whole tile's columns are in range -> one 16-byte store per lane
+        if (row < g.M) *reinterpret_cast<float4*>(o) = v;
+      } else if (row < g.M) {
+        if (col < g.N) o[0] = v.x;
+        if (col + 1 < g.N) o[1] = v.y;
+        if (col + 2 < g.N) o[2] = v.z;
+        if (col + 3 < g.N) o[3] = v.w;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // ... and the loads before the next half's stores
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   using TS = TileShape<BM, BN>;
@@ -83,7 +134,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   mainloop<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kend, id, id,
                                                                         smem, g.rows, g.rows);
   const int wave = egnn_wave_id();
-  store_tile<BM, BN>(acc, g, m0, n0, split, egnn_lane(), wave >> 1, wave & 1);
+  if (g.wide_store) store_tile_wide<BM, BN>(acc, g, m0, n0, split, egnn_lane(), wave >> 1, wave & 1, smem);
+  else store_tile<BM, BN>(acc, g, m0, n0, split, egnn_lane(), wave >> 1, wave & 1);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
@@ -141,8 +193,10 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   if (split_k > 1) {
     if (!ws || ws_bytes < (size_t)split_k * M * N * sizeof(float)) return EGNN_EWORKSPACE;
   }
+  const bool wide = split_k > 1 ? (N % 4 == 0 && egnn_aligned16(ws)) : (ldc % 4 == 0 && egnn_aligned16(C));
+  static const bool narrow_forced = getenv("EGNN_GEMM_NARROW_STORE") != nullptr;   // A/B switch for the epilogue form
   GemmArgs g{M, N, K, A, lda, B, ldb, bias, C, ldc, alpha, nullptr, split_k,
-             ((ksteps + split_k - 1) / split_k) * BK, ws, a_rows ? a_rows : b_rows};
+             ((ksteps + split_k - 1) / split_k) * BK, ws, a_rows ? a_rows : b_rows, (wide && !narrow_forced) ? 1 : 0};
   hipStream_t st = (hipStream_t)stream;
   const bool vec4 = (lda % 4 == 0) && (ldb % 4 == 0) && egnn_aligned16(A) && egnn_aligned16(B);
   const int amaj = trans_a ? MNMAJOR : KMAJOR;   // A stored [K,M] when transposed

@@ -330,6 +330,21 @@ class SparseTensor:
         self._struct["locality"] = (rows_per_blk, win)
         return self
 
+    def permute(self, perm: Tensor) -> "SparseTensor":
+        """Symmetric relabelling of a square adjacency: new node i is old node ``perm[i]`` (rows AND columns), entries re-sorted
+        by (row, col).  Values travel with their entries.  The result describes the same graph: aggregating features permuted
+        the same way (``x[perm]``) gives the permuted result, bit-for-bit up to the summation order inside a row."""
+        n = self._sizes[0]
+        if self._sizes[1] != n or perm.numel() != n:
+            raise ValueError("permute: square adjacency and a permutation of its nodes")
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(n, dtype=perm.dtype, device=perm.device)
+        row, col = inv[self._row()], inv[self._col]
+        order = torch.argsort(row * n + col, stable=True)
+        out = SparseTensor(row=row[order], col=col[order], value=None if self._value is None else self._value[order],
+                           sparse_sizes=(n, n), is_sorted=True)
+        return out
+
     def _scratch(self, key, shape, dtype=torch.float32) -> Tensor:
         """Per-structure scratch buffers of the aggregation (hub partial slots, statistics partials): allocated once per
         (purpose, shape, stream) instead of on every call; calls on one stream are ordered, so reuse is safe."""
@@ -414,3 +429,46 @@ def gcn_norm(adj_t: SparseTensor) -> SparseTensor:
     out = SparseTensor(rowptr=rowptr_out, col=col_out, value=val, sparse_sizes=(n, n))
     out._cols_sorted = True
     return out
+
+
+def community_order(adj_t: SparseTensor, iters: int = 20, max_community: int = 4096, hub_degree: int = 64, seed: int = 0) -> Tensor:
+    """Locality-aware node order for the aggregation (``perm``: new node i is old node perm[i]): size-capped label propagation
+    -- every node repeatedly adopts the most frequent label among its non-hub neighbours (ties: the smallest label; half of
+    the nodes per sweep, chosen by a hash, so that the sweeps do not oscillate; a label that already has ``max_community``
+    members accepts no newcomers, and neighbours with more than ``hub_degree`` entries do not vote: without these two rules
+    the hubs of a power-law graph spread one label over 80 % of the nodes) -- then nodes are sorted by (label, old id).
+    Graphs with community structure (citation graphs: papers cite inside their sub-field) end up with most of a row's
+    sources a few thousand rows away, which is what the per-XCD L2 (32 768 lines of one column slice) can hold: on the
+    synthetic community graph with shuffled ids it recovers 90 % of the locality of the true community order
+    (57 % vs 62 % of the entries within +-2048 rows; 2 % before).  A graph without such structure (the Chung-Lu headline
+    workload) gains nothing (profiles/r01_l2_lru_model.txt).  Integer work on whatever device the structure lives on
+    (sorts / segment maxima; once per graph)."""
+    n = adj_t.sparse_size(0)
+    rowptr, col, _ = adj_t.csr()
+    dev = col.device
+    row = adj_t._row()
+    labels = torch.arange(n, dtype=torch.int64, device=dev)
+    if col.numel() == 0:
+        return labels
+    cnt_all = rowptr[1:] - rowptr[:-1]
+    bound = int(cnt_all.max()) + 1
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    phase = torch.randint(0, 2, (n,), generator=g).to(dev)
+    vote = cnt_all[col] <= hub_degree
+    r2, c2 = row[vote], col[vote]
+    for it in range(iters):
+        sizes = torch.bincount(labels, minlength=n)
+        lab_nb = labels[c2]
+        ok = (sizes[lab_nb] < max_community) | (lab_nb == labels[r2])
+        uniq, cnt = torch.unique((r2 * n + lab_nb)[ok], return_counts=True)          # sorted by (node, label)
+        node, lab = torch.div(uniq, n, rounding_mode="floor"), uniq % n
+        # per node: the label with the largest count, smallest label on ties = first entry after sorting by (node, -count, label)
+        order = torch.argsort((node * bound + (bound - 1 - cnt)) * n + lab)
+        node_s, lab_s = node[order], lab[order]
+        first = torch.ones_like(node_s, dtype=torch.bool)
+        first[1:] = node_s[1:] != node_s[:-1]
+        best = labels.clone()
+        best[node_s[first]] = lab_s[first]
+        move = (phase == (it & 1)) & (best != labels)
+        labels = torch.where(move, best, labels)
+    return torch.argsort(labels * n + torch.arange(n, device=dev), stable=True)

@@ -19,13 +19,42 @@ def to_sparse_tensor(edge_index: torch.Tensor, num_nodes: int) -> SparseTensor:
     return SparseTensor(row=dst[perm], col=src[perm], value=None, sparse_sizes=(num_nodes, num_nodes), is_sorted=True)
 
 
+def reorder_nodes(data, perm: torch.Tensor):
+    """Apply a node permutation (new node i = old node perm[i]) to a whole node-classification problem in place: ``adj_t``,
+    the per-node tensors (x, y, teacher artefacts) and the split index sets.  Done once per dataset; every later epoch runs on
+    the reordered problem, predictions map back through ``perm``."""
+    n = perm.numel()
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n, dtype=perm.dtype, device=perm.device)
+    data.adj_t = data.adj_t.permute(perm.to(data.adj_t.device))
+    for name in ("x", "y", "teacher_out_feat", "teacher_logits", "community"):
+        t = getattr(data, name, None)
+        if t is not None:
+            setattr(data, name, t[perm.to(t.device)])
+    if getattr(data, "split_idx", None) is not None:
+        data.split_idx = {k: inv.to(v.device)[v] for k, v in data.split_idx.items()}
+    data.perm = perm
+    return data
+
+
 class ToSparseTensor:
+    """``reorder='community'`` (extension, off by default like PyG's): after building ``adj_t``, relabel the nodes in a
+    locality-aware order (``sparse.community_order``) and permute the per-node tensors of ``data`` with it."""
+
+    def __init__(self, reorder: str | None = None):
+        if reorder not in (None, "community"):
+            raise ValueError(f"unknown reorder '{reorder}'")
+        self.reorder = reorder
+
     def __call__(self, data):
         n = getattr(data, "num_nodes", None)
         if n is None:
             n = data.x.shape[0]
         data.adj_t = to_sparse_tensor(data.edge_index, int(n))
         data.edge_index = None
+        if self.reorder == "community":
+            from .sparse import community_order
+            reorder_nodes(data, community_order(data.adj_t.to_symmetric()))
         return data
 
 

@@ -335,3 +335,34 @@ def test_dropin_launcher_path_order(tmp_path):
         keep = subprocess.run([_sys.executable, launch, "--keep-criterion", str(sdir / "gnn.py")], capture_output=True, text=True, timeout=300)
         assert keep.returncode == 0, keep.stderr[-2000:]
         assert str(sdir / "criterion.py") in keep.stdout
+
+
+def test_community_order_and_permute_host_logic():
+    """sparse.community_order / SparseTensor.permute / transforms.reorder_nodes (integer host logic, any device): a valid
+    permutation, the permuted matrix is the same graph (P A P^T), the problem's tensors and index sets move with it, and on
+    the community graph with shuffled ids the order recovers most of the true communities' locality."""
+    from efficient_gnns_amd.sparse import community_order
+    from efficient_gnns_amd.transforms import reorder_nodes
+    d = D.arxiv_like(scale=0.05, seed=5, with_teacher=True, graph="local")
+    n = d.num_nodes
+    adj0, x0, y0, tr0 = d.adj_t, d.x.clone(), d.y.clone(), d.split_idx["train"].clone()
+    perm = community_order(adj0)
+    assert torch.equal(torch.sort(perm).values, torch.arange(n))
+    dense0 = torch.zeros(n, n)
+    dense0[adj0.storage.row(), adj0.storage.col()] = 1
+
+    def near(adj, w):
+        rowptr, col, _ = adj.csr()
+        row = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+        return float(((row - col).abs() < w).float().mean())
+    before = near(adj0, n // 40)
+    reorder_nodes(d, perm)
+    dense1 = torch.zeros(n, n)
+    dense1[d.adj_t.storage.row(), d.adj_t.storage.col()] = 1
+    assert torch.equal(dense1, dense0[perm][:, perm]), "P A P^T"
+    rowptr, col, _ = d.adj_t.csr()
+    assert all(bool((col[int(rowptr[i]):int(rowptr[i + 1])][1:] > col[int(rowptr[i]):int(rowptr[i + 1])][:-1]).all()) for i in range(0, n, 97))
+    assert torch.equal(d.x, x0[perm]) and torch.equal(d.y, y0[perm])
+    assert torch.equal(perm[d.split_idx["train"]], tr0), "index sets keep pointing at the same nodes"
+    after = near(d.adj_t, n // 40)
+    assert after > 5 * before and after > 0.3, (before, after)

@@ -1406,3 +1406,24 @@ def test_bench_mag_workload_runs_on_one_rank_over_rccl():
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert "mag" in line["config"]["workload"] and line["n_gpus"] == 1 and line["value"] > 0
     assert line["roofline"] and line["roofline"]["achieved"] > 0 and all(np.isfinite(line["last_losses"]))
+
+
+@pytest.mark.gpu
+def test_reordered_graph_aggregates_to_the_permuted_result():
+    """ToSparseTensor(reorder='community') on the device: the reordered problem is the same problem -- aggregating x[perm] over
+    the permuted adjacency equals the permuted aggregation (oracle on the original graph), for GCN values and for SAGE mean."""
+    import types
+    from efficient_gnns_amd.transforms import ToSparseTensor
+    src = D.arxiv_like(scale=0.05, seed=8, with_teacher=False, graph="local")
+    rowptr, col, _ = src.adj_t.csr()
+    n = src.num_nodes
+    rows = torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])
+    data = types.SimpleNamespace(edge_index=torch.stack([col, rows]).to(DEV), x=src.x.to(DEV), y=src.y.to(DEV), num_nodes=n,
+                                 split_idx={k: v.to(DEV) for k, v in src.split_idx.items()})
+    data = ToSparseTensor(reorder="community")(data)
+    perm = data.perm.cpu()
+    o = OS.SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(n, n))          # the graph is symmetric already
+    x = src.x
+    close(data.adj_t.matmul(data.x, "mean"), o.matmul(x, "mean")[perm], rtol=1e-5)
+    close(E.gcn_norm(data.adj_t).matmul(data.x, "sum"), OS.gcn_norm_sparse(o).matmul(x, "sum")[perm], rtol=1e-5)
+    assert torch.equal(data.y.cpu(), src.y[perm])
