@@ -3,7 +3,7 @@
 // backward GEMMs (/root/reference/arxiv_pyg/gnn.py:47,79,296-306,192).
 #include <cstdlib>
 
-#include "gemm_core.h"
+#include "gemm_split.h"
 
 using namespace egnn_gemm;
 
@@ -29,6 +29,8 @@ int skinny_kind(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, bool 
   return 0;
 }
 
+bool gemm_split_pipe() { return egnn_split_pipe(); }
+
 struct GemmArgs {
   int64_t M, N, K;
   const float* A; int64_t lda;
@@ -42,6 +44,8 @@ struct GemmArgs {
   float* ws;               // [split_k, M, N] when split_k > 1
   const int64_t* rows;     // GATHER 1: storage rows of A ([M,K]) ; GATHER 2: storage rows of B ([K,N]); else unused
   int wide_store;          // output rows 16-byte aligned: epilogue through LDS with 16-byte stores
+  int split_pipe;          // 1: products on the bf16 pipe (three-way operand split, gemm_split.h); 0: f32-input MFMA
+  const u32x4* planes;     // pre-split B (gemm_split.h, "planes" form) or null
 };
 
 // epilogue of one output tile (or of one split-K partial)
@@ -76,7 +80,7 @@ template <int BM, int BN, int TM_, int TN_>
 __device__ __forceinline__ void store_tile_wide(const f32x16 (&acc)[TM_][TN_], const GemmArgs& g, int64_t m0, int64_t n0, int split,
                                                 int lane, int wm, int wn, float* smem) {
   constexpr int WM = BM / 2, WN = BN / 2, LD = WN + 4, F4 = WN / 4, RPI = 64 / F4;   // float4 per row, rows per store instruction
-  static_assert(4 * 32 * LD <= TileShape<BM, BN>::SMEM_FLOATS, "epilogue staging must fit the operand buffers");
+  static_assert(4 * 32 * LD <= TileShape<BM, BN>::SMEM_FLOATS, "epilogue staging must fit the operand buffers");   // (the split image is larger)
   const bool partial = g.split_k > 1;
   const float alpha = partial ? 1.f : g.alpha * (g.alpha_dev ? g.alpha_dev[0] : 1.f);
   float* out = partial ? g.ws + (int64_t)split * g.M * g.N : g.C;
@@ -116,10 +120,12 @@ __device__ __forceinline__ void store_tile_wide(const f32x16 (&acc)[TM_][TN_], c
   }
 }
 
-template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER = 0>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
-  using TS = TileShape<BM, BN>;
-  __shared__ __attribute__((aligned(16))) float smem[TS::SMEM_FLOATS];
+// SPLIT: products on the bf16 matrix pipe from a three-way split of the fp32 operands (gemm_split.h); its LDS image
+// (72 KB for 128 x 128) is dynamic shared memory.
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER = 0, bool SPLIT = false>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GemmArgs g) {
+  using TS = typename TileSel<SPLIT, BM, BN>::type;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int64_t tiles_n = (g.N + BN - 1) / BN;
   const int64_t m0 = (blockIdx.x / tiles_n) * BM;
   const int64_t n0 = (blockIdx.x % tiles_n) * BN;
@@ -131,11 +137,78 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   f32x16 acc[TS::TM][TS::TN];
   zero_acc(acc);
   IdentityXf id;
-  mainloop<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kend, id, id,
-                                                                        smem, g.rows, g.rows);
+  if constexpr (SPLIT) {
+    // interior tiles (all but the last row / column of tiles, whole k-steps) run a loop without edge handling
+    if (m0 + BM <= g.M && n0 + BN <= g.N && (kend - kbeg) % BK == 0)
+      mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, true, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kend, id, id,
+                                                                                 smem, g.rows, g.rows);
+    else
+      mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kend, id, id,
+                                                                                  smem, g.rows, g.rows);
+  } else {
+    mainloop<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kend, id, id,
+                                                                          smem, g.rows, g.rows);
+  }
   const int wave = egnn_wave_id();
   if (g.wide_store) store_tile_wide<BM, BN>(acc, g, m0, n0, split, egnn_lane(), wave >> 1, wave & 1, smem);
   else store_tile<BM, BN>(acc, g, m0, n0, split, egnn_lane(), wave >> 1, wave & 1);
+}
+
+// B pre-split into planes (a small, much-reused operand): 128 x 128 block tile, waves 1 x 4, only A staged through LDS
+template <int AMAJ, bool VEC4, bool GA>
+__global__ __launch_bounds__(256, 2) void gemm_pb_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int64_t tiles_n = (g.N + 127) / 128;
+  const int64_t m0 = (blockIdx.x / tiles_n) * 128;
+  const int64_t n0 = (blockIdx.x % tiles_n) * 128;
+  const int split = blockIdx.y;
+  const int64_t kbeg = split * g.k_per_split;
+  int64_t kend = kbeg + g.k_per_split;
+  if (kend > g.K) kend = g.K;
+  const int lane = egnn_lane(), wave = egnn_wave_id();
+  const u32x4* bp = g.planes + ((n0 >> 5) + wave) * planes_nk(g.K) * (3 * 64) + lane;
+  f32x16 acc[4];
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+  IdentityXf id;
+  if (m0 + 128 <= g.M && (kend - kbeg) % BK == 0) mainloop_pb<AMAJ, VEC4, true, GA>(acc, g.A, g.lda, m0, g.M, bp, kbeg, kend, id, smem, g.rows);
+  else mainloop_pb<AMAJ, VEC4, false, GA>(acc, g.A, g.lda, m0, g.M, bp, kbeg, kend, id, smem, g.rows);
+  const bool partial = g.split_k > 1;
+  const float alpha = partial ? 1.f : g.alpha * (g.alpha_dev ? g.alpha_dev[0] : 1.f);
+  float* out = partial ? g.ws + (int64_t)split * g.M * g.N : g.C;
+  const int64_t ldo = partial ? g.N : g.ldc;
+  const int64_t c = n0 + wave * 32 + (lane & 31);
+  if (c < g.N) {
+    const float bv = (!partial && g.bias) ? g.bias[c] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < g.M) out[row * ldo + c] = alpha * acc[tm][r] + bv;
+      }
+  }
+}
+
+template <int AMAJ, bool GA>
+int launch_pb(const GemmArgs& g, bool vec4, hipStream_t st) {
+  const int64_t tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
+  if (tiles > 0x7fffffffLL) return EGNN_EINVAL;
+  const dim3 grid((unsigned)tiles, (unsigned)g.split_k);
+  constexpr size_t shm = 2 * 3 * 128 * S_ROW;
+  if (vec4) hipLaunchKernelGGL((gemm_pb_kernel<AMAJ, true, GA>), grid, dim3(256), shm, st, g);
+  else hipLaunchKernelGGL((gemm_pb_kernel<AMAJ, false, GA>), grid, dim3(256), shm, st, g);
+  return EGNN_OK;
+}
+
+// the planes form pays when B is small next to A (it is cut once, then read by every row tile)
+bool planes_form(int64_t M, int64_t N, int64_t K, bool b_gather) {
+  // measured slower than the two-operand staging on the layer shapes (169343 x 256 x 256: 205 vs 181 us: the fragment
+  // loads cost more L2 -> CU traffic than they save in LDS work), so it is opt-in: EGNN_GEMM_PLANES=1
+  static const bool on = getenv("EGNN_GEMM_PLANES") != nullptr;
+  return on && gemm_split_pipe() && !b_gather && N >= 96 && K >= 16 && M >= 3 * N && planes_bytes(N, K) <= (256u << 20);
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
@@ -149,14 +222,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
   }
 }
 
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER, bool SPLIT>
+int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  using TS = typename TileSel<SPLIT, BM, BN>::type;
+  constexpr size_t shm = (size_t)TS::SMEM_FLOATS * sizeof(float);
+  auto* fn = gemm_kernel<BM, BN, AMAJ, BMAJ, VEC4, GATHER, SPLIT>;
+  if constexpr (shm > 65536) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (attr != hipSuccess) return EGNN_ELAUNCH;
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), shm, st, g);
+  return EGNN_OK;
+}
+
 template <int BM, int BN, int AMAJ, int BMAJ, int GATHER = 0>
 int launch_tile(const GemmArgs& g, bool vec4, hipStream_t st) {
   const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   if (tiles > 0x7fffffffLL) return EGNN_EINVAL;
   dim3 grid((unsigned)tiles, (unsigned)g.split_k);
-  if (vec4) hipLaunchKernelGGL((gemm_kernel<BM, BN, AMAJ, BMAJ, true, GATHER>), grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((gemm_kernel<BM, BN, AMAJ, BMAJ, false, GATHER>), grid, dim3(256), 0, st, g);
-  return EGNN_OK;
+  if constexpr (BM % 128 == 0 && BN % 128 == 0) {
+    if (g.split_pipe) {
+      return vec4 ? launch_one<BM, BN, AMAJ, BMAJ, true, GATHER, true>(g, grid, st)
+                  : launch_one<BM, BN, AMAJ, BMAJ, false, GATHER, true>(g, grid, st);
+    }
+  }
+  return vec4 ? launch_one<BM, BN, AMAJ, BMAJ, true, GATHER, false>(g, grid, st)
+              : launch_one<BM, BN, AMAJ, BMAJ, false, GATHER, false>(g, grid, st);
 }
 
 template <int AMAJ, int BMAJ, int GATHER = 0>
@@ -196,12 +287,25 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   const bool wide = split_k > 1 ? (N % 4 == 0 && egnn_aligned16(ws)) : (ldc % 4 == 0 && egnn_aligned16(C));
   static const bool narrow_forced = getenv("EGNN_GEMM_NARROW_STORE") != nullptr;   // A/B switch for the epilogue form
   GemmArgs g{M, N, K, A, lda, B, ldb, bias, C, ldc, alpha, nullptr, split_k,
-             ((ksteps + split_k - 1) / split_k) * BK, ws, a_rows ? a_rows : b_rows, (wide && !narrow_forced) ? 1 : 0};
+             ((ksteps + split_k - 1) / split_k) * BK, ws, a_rows ? a_rows : b_rows, (wide && !narrow_forced) ? 1 : 0,
+             (gemm_split_pipe() && !(trans_a && !trans_b)) ? 1 : 0,   // dW = X^T dY (both operands row-major in k) stays on the f32 pipe: 267 vs 280 us
+             nullptr};
   hipStream_t st = (hipStream_t)stream;
   const bool vec4 = (lda % 4 == 0) && (ldb % 4 == 0) && egnn_aligned16(A) && egnn_aligned16(B);
   const int amaj = trans_a ? MNMAJOR : KMAJOR;   // A stored [K,M] when transposed
   const int bmaj = trans_b ? KMAJOR : MNMAJOR;   // B stored [N,K] when transposed, else [K,N]
   int rc;
+  const size_t split_ws = split_k > 1 ? (size_t)split_k * M * N * sizeof(float) : 0;
+  if (planes_form(M, N, K, b_rows != nullptr) && ws && ws_bytes >= split_ws + planes_bytes(N, K) + 16) {
+    u32x4* planes = reinterpret_cast<u32x4*>((reinterpret_cast<uintptr_t>(ws) + split_ws + 15) & ~(uintptr_t)15);
+    g.planes = planes;
+    const int64_t units = planes_nb(N) * planes_nk(K) * 64;
+    IdentityXf id;
+    hipLaunchKernelGGL((presplit_kernel<IdentityXf>), dim3((unsigned)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096)), dim3(256), 0, st, B, ldb,
+                       bmaj == KMAJOR ? 1 : 0, N, K, id, planes);
+    if (a_rows) rc = launch_pb<KMAJOR, true>(g, vec4, st);
+    else rc = amaj == KMAJOR ? launch_pb<KMAJOR, false>(g, vec4, st) : launch_pb<MNMAJOR, false>(g, vec4, st);
+  } else
   if (a_rows) {
     rc = bmaj == KMAJOR ? launch_major<KMAJOR, KMAJOR, 1>(g, vec4, st) : launch_major<KMAJOR, MNMAJOR, 1>(g, vec4, st);
   } else if (b_rows) {
@@ -221,6 +325,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
 extern "C" size_t egnn_gemm_ws_floats(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int split_k) {
   size_t need = split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N : 0;
   const int kind = skinny_kind(trans_a, trans_b, M, N, K, false);
+  if (kind == 0 && planes_form(M, N, K, false)) need += planes_bytes(N, K) / sizeof(float) + 8;   // B cut into bf16 planes (gemm_split.h)
   size_t sk = 0;
   if (kind == 3) sk = egnn_skinny_dw_ws_floats(K, M, N);
   else if (kind == 4) sk = egnn_skinny_dw_ws_floats(K, N, M);

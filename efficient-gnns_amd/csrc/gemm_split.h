@@ -1,0 +1,456 @@
+// fp32 GEMM products on the bf16 matrix pipe of gfx950 ("split" pipeline, drop-in for egnn_gemm::Pipeline).
+//
+// The f32-input MFMA runs at 1/16 of the bf16 MFMA rate on CDNA4 (157 vs 2500 TFLOP/s).  Every fp32 operand element
+// x is therefore cut, while its tile is staged into LDS, into three bf16 terms
+//       x = x0 + x1 + x2,   x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)        (round to nearest)
+// The two subtractions are exact in fp32, so |x - (x0 + x1 + x2)| <= 2^-27 |x|: the three terms carry the whole 24-bit
+// significand.  A product a * b is then accumulated as the six partial products a_i * b_j with i + j <= 2 -- each EXACT
+// in the fp32 accumulator (8-bit x 8-bit significands) -- on v_mfma_f32_32x32x16_bf16; the three dropped products are
+// bounded by 2^-26 |a b|, a quarter of the rounding of ONE fp32 multiply-add.  6 MFMAs of 16 k-values at 32 cycles
+// replace 8 MFMAs of 2 k-values at 64 cycles: 2.67 x the matrix rate of the fp32 pipe for the same fp32 answer
+// (tests/test_gpu_parity.py compares both pipelines with a float64 product: the split one is at least as close).
+// Non-finite inputs (inf) turn into NaN (inf - inf in the split) -- the fp32 pipe would give inf or NaN.
+//
+// Tile / LDS: block tile BM x BN (multiples of 128), 4 waves 2 x 2, k-step 16 = one MFMA; an operand tile lives in LDS as
+// three planes [rows][48 B] (8 + 8 bf16 of one row = 32 B, padded to a 3 x 16-byte stride: both the ds_write_b128 of the
+// staging pass and the ds_read_b128 of the fragments are bank-conflict-free), two buffers, one barrier per step.
+// Staging threads own one row x 8 consecutive k (k-major operand: two 16-byte loads; row-major-in-k operand: eight
+// 4-byte loads, lanes along the rows), i.e. exactly the 16-byte fragment of one lane.
+#pragma once
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "gemm_core.h"
+
+namespace egnn_gemm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+static_assert(BK == 16, "the split pipeline consumes one 32x32x16 MFMA per k-step");
+constexpr int S_ROW = 48;   // bytes per LDS row of one plane
+
+__device__ __forceinline__ unsigned pack_bf16(float x, float y) {   // v_cvt_pk_bf16_f32: x -> low half, y -> high half
+  const f32x2v v = {x, y};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+
+// eight consecutive-k values of one row -> their three bf16 planes (16 bytes each)
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& p0, u32x4& p1, u32x4& p2) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float x = v[2 * q], y = v[2 * q + 1];
+    const unsigned a = pack_bf16(x, y);
+    const float rx = x - __uint_as_float(a << 16), ry = y - __uint_as_float(a & 0xffff0000u);
+    const unsigned b = pack_bf16(rx, ry);
+    const float sx = rx - __uint_as_float(b << 16), sy = ry - __uint_as_float(b & 0xffff0000u);
+    p0[q] = a;
+    p1[q] = b;
+    p2[q] = pack_bf16(sx, sy);
+  }
+}
+
+// Stages one operand tile of R rows x 16 k: global (fp32) -> registers -> three bf16 planes in LDS.
+template <int R, int MAJOR, bool VEC4, class XF, bool GATHER = false>
+struct StagerS {
+  static_assert(R % 128 == 0, "split tiles are multiples of 128 rows");
+  static constexpr int NC = R / 128;   // (row, 8-k chunk) items per thread per k-step
+  float v[NC][8];
+
+  template <bool FULL>
+  __device__ __forceinline__ void load_impl(const float* __restrict__ p, int64_t ld, int64_t r0, int64_t rmax, int64_t k0,
+                                            int64_t kmax, const XF& xf, const int64_t* __restrict__ ridx) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      if constexpr (MAJOR == KMAJOR) {
+#if EGNN_ABL & 64
+        const int64_t r = r0 + (t >> 2) + 128 * i;                 // lab: a wave-load covers 16 rows x 128 B (full lines)
+        const int64_t k = ((k0 >> 5) << 5) + (t & 3) * 8;
+#else
+        const int64_t r = r0 + (t >> 1) + 128 * i;
+        const int64_t k = k0 + (t & 1) * 8;
+#endif
+        int64_t rs = r;
+#if EGNN_ABL & 32
+        rs = r0 + ((t >> 1) & 7);                                 // lab: every load hits 8 rows (L1-resident)
+#endif
+        if constexpr (GATHER) rs = (FULL || r < rmax) ? ridx[r] : 0;
+        const float* q = p + rs * ld + k;
+        if constexpr (FULL) {
+          float x[8];
+          if constexpr (VEC4) {
+            const float4 lo = *reinterpret_cast<const float4*>(q), hi = *reinterpret_cast<const float4*>(q + 4);
+            x[0] = lo.x; x[1] = lo.y; x[2] = lo.z; x[3] = lo.w; x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = q[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][j] = xf(x[j], r, k + j);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][j] = (r < rmax && k + j < kmax) ? xf(q[j], r, k + j) : 0.f;
+        }
+      } else {
+        const int64_t r = r0 + (t & 127) + 128 * i;
+        const int64_t k = k0 + (t >> 7) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          int64_t ks = k + j;
+          if constexpr (GATHER) ks = (FULL || k + j < kmax) ? ridx[k + j] : 0;
+          if constexpr (FULL) v[i][j] = xf(p[ks * ld + r], r, k + j);
+          else v[i][j] = (k + j < kmax && r < rmax) ? xf(p[ks * ld + r], r, k + j) : 0.f;
+        }
+      }
+    }
+  }
+
+  template <bool FULLONLY = false>
+  __device__ __forceinline__ void load(const float* __restrict__ p, int64_t ld, int64_t r0, int64_t rmax, int64_t k0,
+                                       int64_t kmax, const XF& xf, const int64_t* __restrict__ ridx = nullptr) {
+    if constexpr (FULLONLY) {
+      load_impl<true>(p, ld, r0, rmax, k0, kmax, xf, ridx);
+    } else {
+      const bool full = (r0 + R <= rmax) && (k0 + BK <= kmax);  // block-uniform
+      if (full) load_impl<true>(p, ld, r0, rmax, k0, kmax, xf, ridx);
+      else load_impl<false>(p, ld, r0, rmax, k0, kmax, xf, ridx);
+    }
+  }
+
+  // LDS image: [3][R][S_ROW bytes]; chunk g of a row sits at byte 16 g
+  __device__ __forceinline__ void store(char* lds) const {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int row = (MAJOR == KMAJOR ? (t >> 1) : (t & 127)) + 128 * i;
+      const int g = MAJOR == KMAJOR ? (t & 1) : (t >> 7);
+      u32x4 p0, p1, p2;
+#if EGNN_ABL & 16
+      p0 = u32x4{__float_as_uint(v[i][0]), __float_as_uint(v[i][1]), __float_as_uint(v[i][2]), __float_as_uint(v[i][3])};
+      p1 = u32x4{__float_as_uint(v[i][4]), __float_as_uint(v[i][5]), __float_as_uint(v[i][6]), __float_as_uint(v[i][7])};
+      p2 = p0;
+#else
+      split8(v[i], p0, p1, p2);
+#endif
+      char* d = lds + row * S_ROW + g * 16;
+#if EGNN_ABL & 8
+      asm volatile("" ::"v"(p0), "v"(p1), "v"(p2), "v"(d));
+#else
+      *reinterpret_cast<u32x4*>(d) = p0;
+      *reinterpret_cast<u32x4*>(d + R * S_ROW) = p1;
+      *reinterpret_cast<u32x4*>(d + 2 * R * S_ROW) = p2;
+#endif
+    }
+  }
+};
+
+template <int BM, int BN>
+struct TileShapeS {
+  static constexpr int WM = BM / 2, WN = BN / 2;
+  static constexpr int TM = WM / 32, TN = WN / 32;
+  static constexpr int A_BUF = 3 * BM * S_ROW, B_BUF = 3 * BN * S_ROW;   // bytes per buffer
+  static constexpr int SMEM_BYTES = 2 * (A_BUF + B_BUF);
+  static constexpr int SMEM_FLOATS = SMEM_BYTES / 4;
+};
+
+#ifndef EGNN_ABL
+#define EGNN_ABL 0   // lab only: bit 0 no B staging, bit 1 no B fragment reads, bit 2 no A staging (results wrong on purpose)
+#endif
+#ifndef EGNN_SPLIT_DEPTH
+#define EGNN_SPLIT_DEPTH 4   // k-steps of operand tiles in flight (register ring)
+#endif
+#ifndef EGNN_SPLIT_COMMIT_AFTER
+#define EGNN_SPLIT_COMMIT_AFTER 1   // group (of TM x TN MFMAs, 6 per step) after which the next tile is cut and written to LDS
+#endif
+
+// The software pipeline of one workgroup.  A k-step on the bf16 pipe is 2.7 x shorter than on the fp32 pipe while a
+// global load takes as long as before, so operand tiles travel through a RING of D register stages: while step kt
+// runs out of LDS buffer kt & 1, stage kt + 1 is cut into planes and written to the other buffer (its loads were issued
+// D steps earlier) and the loads of stage kt + 1 + D are issued into the registers it frees.  Slots are compile-time
+// (the drivers unroll by lcm(D, 2)), so the ring lives in registers and the compiler's vmcnt counts stay exact.
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY, class XFA, class XFB, bool GA = false, bool GB = false,
+          int D = EGNN_SPLIT_DEPTH>
+struct PipelineS {
+  using TS = TileShapeS<BM, BN>;
+  static constexpr int DEPTH = D, UNROLL = (D % 2 == 0) ? D : 2 * D;
+  static constexpr int B_OFF = 2 * TS::A_BUF;
+  StagerS<BM, AMAJ, VEC4, XFA, GA> sa[D];
+  StagerS<BN, BMAJ, VEC4, XFB, GB> sb[D];
+  const float* __restrict__ A;
+  const float* __restrict__ B;
+  int64_t lda, ldb, M, N, kend;
+  XFA xfa;
+  XFB xfb;
+  const int64_t* arows = nullptr;
+  const int64_t* brows = nullptr;
+
+  __device__ __forceinline__ PipelineS(const float* A_, int64_t lda_, int64_t M_, const float* B_, int64_t ldb_, int64_t N_, int64_t kend_,
+                                       const XFA& xa, const XFB& xb)
+      : A(A_), B(B_), lda(lda_), ldb(ldb_), M(M_), N(N_), kend(kend_), xfa(xa), xfb(xb) {}
+
+  template <int SLOT>
+  __device__ __forceinline__ void prefetch(int64_t m0, int64_t n0, int64_t k0) {
+    sa[SLOT].template load<FULLONLY>(A, lda, m0, M, k0, kend, xfa, arows);
+    sb[SLOT].template load<FULLONLY>(B, ldb, n0, N, k0, kend, xfb, brows);
+  }
+  template <int SLOT>
+  __device__ __forceinline__ void commit(float* smem, int buf) const {
+    char* s = reinterpret_cast<char*>(smem);
+#if !(EGNN_ABL & 4)
+    sa[SLOT].store(s + buf * TS::A_BUF);
+#endif
+#if !(EGNN_ABL & 1)
+    sb[SLOT].store(s + B_OFF + buf * TS::B_BUF);
+#endif
+  }
+  // one k-step out of LDS buffer `cur`; with `more`, ring slot SLOT is committed to buffer cur ^ 1 on the way and
+  // refill() (the loads of the stage that takes the slot over) is called right behind it
+  template <int SLOT, int TM_, int TN_, class F>
+  __device__ __forceinline__ void step(f32x16 (&acc)[TM_][TN_], float* smem, int cur, bool more, int lane, int wm, int wn, F&& refill) {
+    static_assert(TM_ == TS::TM && TN_ == TS::TN, "accumulator shape does not match the block tile");
+    const char* s = reinterpret_cast<const char*>(smem);
+    const char* sA = s + cur * TS::A_BUF + (wm * TS::WM + (lane & 31)) * S_ROW + (lane >> 5) * 16;
+    const char* sB = s + B_OFF + cur * TS::B_BUF + (wn * TS::WN + (lane & 31)) * S_ROW + (lane >> 5) * 16;
+    u32x4 a[TS::TM][3], b[TS::TN][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int tm = 0; tm < TS::TM; ++tm) a[tm][p] = *reinterpret_cast<const u32x4*>(sA + p * BM * S_ROW + tm * 32 * S_ROW);
+#pragma unroll
+      for (int tn = 0; tn < TS::TN; ++tn) {
+#if EGNN_ABL & 2
+        b[tn][p] = a[tn][p];
+#else
+        b[tn][p] = *reinterpret_cast<const u32x4*>(sB + p * BN * S_ROW + tn * 32 * S_ROW);
+#endif
+      }
+    }
+    // the six kept partial products, smallest first; consecutive MFMAs go to different accumulators
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+#pragma unroll
+      for (int tm = 0; tm < TS::TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TS::TN; ++tn)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[tm][PA[t]]),
+                                                                __builtin_bit_cast(bf16x8, b[tn][PB[t]]), acc[tm][tn], 0, 0, 0);
+      if (t == EGNN_SPLIT_COMMIT_AFTER && more) {
+        commit<SLOT>(smem, cur ^ 1);
+        refill();
+      }
+    }
+  }
+};
+
+template <int U, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < U) {
+    f(std::integral_constant<int, I>{});
+    static_for<U, I + 1>(f);
+  }
+}
+
+// acc += A[m0:m0+BM, kbeg:kend] * B[kbeg:kend, n0:n0+BN] on the split pipeline (all 256 threads call with equal bounds)
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY = false, bool GA = false, bool GB = false, class XFA, class XFB,
+          int TM_, int TN_>
+__device__ __forceinline__ void mainloop_split(f32x16 (&acc)[TM_][TN_], const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
+                                               const float* __restrict__ B, int64_t ldb, int64_t n0, int64_t N, int64_t kbeg,
+                                               int64_t kend, const XFA& xfa, const XFB& xfb, float* smem,
+                                               const int64_t* arows = nullptr, const int64_t* brows = nullptr) {
+  using P = PipelineS<BM, BN, AMAJ, BMAJ, VEC4, FULLONLY, XFA, XFB, GA, GB>;
+  P pipe(A, lda, M, B, ldb, N, kend, xfa, xfb);
+  pipe.arows = arows;
+  pipe.brows = brows;
+  const int nk = (int)((kend - kbeg + BK - 1) / BK);
+  if (nk <= 0) return;
+  const int lane = egnn_lane();
+  const int wave = egnn_wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  // Stage s covers k = kbeg + 16 s.  Stages past the end are clamped to the last one and never committed: every step then
+  // issues the same loads, which keeps the compiler's vmcnt bookkeeping exact (a conditional refill makes it fall back
+  // to vmcnt(0), i.e. to a ring of depth one); the re-loaded lines hit L1 / L2.
+  auto k_of = [&](int stage) { return kbeg + (int64_t)(stage < nk ? stage : nk - 1) * BK; };
+  static_for<P::DEPTH>([&](auto d) { pipe.template prefetch<d.value>(m0, n0, k_of(d.value)); });
+  pipe.template commit<0>(smem, 0);
+  pipe.template prefetch<0>(m0, n0, k_of(P::DEPTH));
+  __syncthreads();
+  int kt0 = 0;
+  if constexpr (FULLONLY) {
+    // whole groups of UNROLL steps as ONE basic block (commit and refill unconditional; what the last step commits is
+    // never read): with a branch between a load and its use the compiler sinks the load next to the use, which turns
+    // the ring back into a prefetch distance of one step
+    for (; kt0 + P::UNROLL <= nk; kt0 += P::UNROLL) {
+      static_for<P::UNROLL>([&](auto u) {
+        constexpr int slot = (u.value + 1) % P::DEPTH;
+        pipe.template step<slot>(acc, smem, u.value & 1, true, lane, wm, wn,
+                                 [&]() { pipe.template prefetch<slot>(m0, n0, k_of(kt0 + u.value + 1 + P::DEPTH)); });
+        __syncthreads();
+      });
+    }
+  }
+  for (; kt0 < nk; kt0 += P::UNROLL) {
+    static_for<P::UNROLL>([&](auto u) {
+      const int kt = kt0 + u.value;
+      if (kt < nk) {   // block-uniform
+        constexpr int slot = (u.value + 1) % P::DEPTH;
+        pipe.template step<slot>(acc, smem, u.value & 1, kt + 1 < nk, lane, wm, wn,
+                                 [&]() { pipe.template prefetch<slot>(m0, n0, k_of(kt + 1 + P::DEPTH)); });
+        __syncthreads();
+      }
+    });
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// "Planes" form of a SMALL, much-reused B operand (layer weights; the [S,256] embedding matrices of the G-CRD loss):
+// op(B)[K,N] is cut into its three bf16 terms ONCE per call (presplit_kernel) and laid out in MFMA-fragment order,
+//     unit (nb, ks, p) = 1 KB:  lane l (column 32 nb + (l & 31), g = l >> 5) holds k = 16 ks + 8 g + 0..7 of plane p
+//     address = ((nb * nk + ks) * 3 + p) * 1 KB + 16 l
+// so that a wave owning 32 output columns fetches its B fragments of a k-step with three coalesced 1 KB loads straight
+// into registers (L2-resident): no LDS, no split VALU and no barrier traffic for B; only the big A operand is staged and
+// cut in the loop.  Wave arrangement 1 x 4: every wave holds all 128 rows x 32 columns of the block tile.
+// (lab, 4096^3: without the B staging the loop runs 1.25 x faster; tools/lab/gemm_lab + EGNN_ABL)
+__host__ __device__ inline int64_t planes_nk(int64_t K) { return (K + BK - 1) / BK; }
+__host__ __device__ inline int64_t planes_nb(int64_t N) { return ((N + 127) / 128) * 4; }   // 32-column units, whole 128-column tiles
+__host__ __device__ inline size_t planes_bytes(int64_t N, int64_t K) { return (size_t)planes_nb(N) * (size_t)planes_nk(K) * 3 * 1024; }
+
+// B(k, n): b_kmajor = 1 -> stored [N,K] (k contiguous), else [K,N].  One thread per (nb, ks, lane).
+template <class XF>
+__global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__ B, int64_t ldb, int b_kmajor, int64_t N, int64_t K,
+                                                       XF xf, u32x4* __restrict__ out) {
+  const int64_t nk = planes_nk(K);
+  const int64_t total = planes_nb(N) * nk * 64;
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int l = (int)(t & 63);
+    const int64_t unit = t >> 6, ks = unit % nk, nb = unit / nk;
+    const int64_t n = nb * 32 + (l & 31), k0 = ks * BK + (l >> 5) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t k = k0 + j;
+      v[j] = (n < N && k < K) ? xf(b_kmajor ? B[n * ldb + k] : B[k * ldb + n], n, k) : 0.f;
+    }
+    u32x4 p0, p1, p2;
+    split8(v, p0, p1, p2);
+    u32x4* o = out + unit * 3 * 64 + l;
+    o[0] = p0;
+    o[64] = p1;
+    o[128] = p2;
+  }
+}
+
+constexpr int PB_DEPTH = 4;   // ring depth (k-steps) of both the A register stages and the B fragment stages
+
+// acc[tm] (tm = 0..3: rows 32 tm .. 32 tm + 31 of the 128-row block tile, this wave's 32 columns) += A[m0:m0+128, kbeg:kend] *
+// planes.  `bp` points at unit (this wave's nb, k-step 0, plane 0), lane included; kbeg is a multiple of 16.
+template <int AMAJ, bool VEC4, bool FULLONLY, bool GA = false, class XFA>
+__device__ __forceinline__ void mainloop_pb(f32x16 (&acc)[4], const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
+                                            const u32x4* __restrict__ bp, int64_t kbeg, int64_t kend, const XFA& xfa, float* smem,
+                                            const int64_t* arows = nullptr) {
+  constexpr int D = PB_DEPTH;
+  constexpr int A_BUF = 3 * 128 * S_ROW;
+  const int nk = (int)((kend - kbeg + BK - 1) / BK);
+  if (nk <= 0) return;
+  const int lane = egnn_lane();
+  StagerS<128, AMAJ, VEC4, XFA, GA> sa[D];
+  u32x4 bq[D][3];
+  char* s = reinterpret_cast<char*>(smem);
+  const int ks0 = (int)(kbeg / BK);
+  auto stage_of = [&](int st) { return st < nk ? st : nk - 1; };   // clamped: see mainloop_split
+  auto load_a = [&](auto slot, int st) { sa[slot.value].template load<FULLONLY>(A, lda, m0, M, kbeg + (int64_t)stage_of(st) * BK, kend, xfa, arows); };
+  auto load_b = [&](auto slot, int st) {
+    const u32x4* q = bp + (int64_t)(ks0 + stage_of(st)) * (3 * 64);
+    bq[slot.value][0] = q[0];
+    bq[slot.value][1] = q[64];
+    bq[slot.value][2] = q[128];
+  };
+  auto step = [&](auto uc, int cur, bool more, int st_next_a, int st_next_b) {
+    constexpr int u = uc.value;
+    constexpr int sl_a = (u + 1) % D, sl_b = u % D;
+    const char* sA = s + cur * A_BUF + (lane & 31) * S_ROW + (lane >> 5) * 16;
+    u32x4 a[4][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm) a[tm][p] = *reinterpret_cast<const u32x4*>(sA + p * 128 * S_ROW + tm * 32 * S_ROW);
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PBn[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+#pragma unroll
+      for (int tm = 0; tm < 4; ++tm)
+        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[tm][PA[t]]), __builtin_bit_cast(bf16x8, bq[sl_b][PBn[t]]),
+                                                          acc[tm], 0, 0, 0);
+      if (t == EGNN_SPLIT_COMMIT_AFTER && more) {
+        sa[sl_a].store(s + (cur ^ 1) * A_BUF);
+        load_a(std::integral_constant<int, sl_a>{}, st_next_a);
+      }
+    }
+    if (more) load_b(std::integral_constant<int, sl_b>{}, st_next_b);
+  };
+  static_for<D>([&](auto d) {
+    load_a(d, d.value);
+    load_b(d, d.value);
+  });
+  sa[0].store(s);
+  load_a(std::integral_constant<int, 0>{}, D);
+  __syncthreads();
+  int kt0 = 0;
+  if constexpr (FULLONLY) {
+    for (; kt0 + D <= nk; kt0 += D) {   // D is even: LDS buffer = u & 1; one basic block per D steps (see mainloop_split)
+      static_for<D>([&](auto u) {
+        step(u, u.value & 1, true, kt0 + u.value + 1 + D, kt0 + u.value + D);
+        __syncthreads();
+      });
+    }
+  }
+  for (; kt0 < nk; kt0 += D) {
+    static_for<D>([&](auto u) {
+      const int kt = kt0 + u.value;
+      if (kt < nk) {
+        step(u, u.value & 1, kt + 1 < nk, kt + 1 + D, kt + D);
+        __syncthreads();
+      }
+    });
+  }
+}
+
+
+// EGNN_GEMM_PIPE=f32 keeps every product on the f32-input MFMA (the A/B switch of the two pipelines)
+static inline bool egnn_split_pipe() {
+  static const bool on = !(getenv("EGNN_GEMM_PIPE") && getenv("EGNN_GEMM_PIPE")[0] == 'f');
+  return on;
+}
+
+// launch with dynamic LDS (the split image of a 128 x 128 tile is 72 KB: above the 64 KB that need no opt-in)
+template <auto Kernel, class... Args>
+static inline int launch_dyn_lds(dim3 grid, dim3 block, size_t shm, hipStream_t st, Args... args) {
+  if (shm > 65536) {
+    static const hipError_t attr = hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return EGNN_ELAUNCH;
+  }
+  hipLaunchKernelGGL(Kernel, grid, block, shm, st, args...);
+  return EGNN_OK;
+}
+
+template <bool SPLIT, int BM, int BN>
+struct TileSel { using type = TileShape<BM, BN>; };
+template <int BM, int BN>
+struct TileSel<true, BM, BN> { using type = TileShapeS<BM, BN>; };
+
+// compile-time choice of the pipeline: SPLIT = products on the bf16 pipe (this file), else the f32-input MFMA
+template <bool SPLIT, int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY = false, bool GA = false, bool GB = false, class XFA,
+          class XFB, int TM_, int TN_>
+__device__ __forceinline__ void mainloop_sel(f32x16 (&acc)[TM_][TN_], const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
+                                             const float* __restrict__ B, int64_t ldb, int64_t n0, int64_t N, int64_t kbeg,
+                                             int64_t kend, const XFA& xfa, const XFB& xfb, float* smem,
+                                             const int64_t* arows = nullptr, const int64_t* brows = nullptr) {
+  if constexpr (SPLIT) mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, FULLONLY, GA, GB>(acc, A, lda, m0, M, B, ldb, n0, N, kbeg, kend, xfa, xfb, smem, arows, brows);
+  else mainloop<BM, BN, AMAJ, BMAJ, VEC4, FULLONLY, GA, GB>(acc, A, lda, m0, M, B, ldb, n0, N, kbeg, kend, xfa, xfb, smem, arows, brows);
+}
+
+}  // namespace egnn_gemm

@@ -17,7 +17,7 @@
 //                  i.e. two plain GEMMs on E with a row scale on one side (one exp per 4 staged elements of fhat).
 #include <stdlib.h>
 
-#include "gemm_core.h"
+#include "gemm_split.h"
 
 using namespace egnn_gemm;
 
@@ -95,15 +95,16 @@ __device__ __forceinline__ void nce_tile_epilogue(const f32x16 (&acc)[TM_][TN_],
 // element and half the per-lane state of the online-max form (which costs a whole wave per SIMD in registers).
 // ALIGNED: Sr and Sc are multiples of the tile, P of the k-step and the operands are float4-addressable (the sampled
 // G-CRD problem: 16384 x 16384 x 256); no edge handling is compiled into that variant.
-template <bool VEC4, bool FIXED, bool ALIGNED>
+// SPLIT: products on the bf16 matrix pipe from the three-way split of the fp32 operands (gemm_split.h)
+template <bool VEC4, bool FIXED, bool ALIGNED, bool SPLIT = false>
 __global__ __launch_bounds__(256, ALIGNED ? EGNN_NCE_FWD_WAVES : 1) void nce_fwd_kernel(const float* __restrict__ fhat, int64_t ldf,
                                                       const float* __restrict__ that, int64_t ldt, int64_t Sr, int64_t Sc,
                                                       int64_t diag_off, int64_t P, float inv_tau,
                                                       float* __restrict__ Z, float* __restrict__ zdiag,
                                                       float* __restrict__ pm, float* __restrict__ ps, int nsplit,
                                                       int cb_per_split) {
-  using TS = TileShape<FB, FB>;
-  __shared__ __attribute__((aligned(16))) float smem[TS::SMEM_FLOATS];
+  using TS = typename TileSel<SPLIT, FB, FB>::type;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lane = egnn_lane();
   const int wave = egnn_wave_id();
   const int wm = wave >> 1, wn = wave & 1;
@@ -125,7 +126,41 @@ __global__ __launch_bounds__(256, ALIGNED ? EGNN_NCE_FWD_WAVES : 1) void nce_fwd
     }
 
   IdentityXf id;
-  if constexpr (ALIGNED) {
+  if constexpr (ALIGNED && SPLIT) {
+    // the same continuous pipeline on the split ring: stage s <-> (column tile cb0 + s / nk, k-step s % nk); P % 64 == 0
+    using PS = PipelineS<FB, FB, KMAJOR, KMAJOR, true, true, IdentityXf, IdentityXf>;
+    static_assert(PS::UNROLL == PS::DEPTH && PS::DEPTH % 2 == 0, "ring depth must be even here");
+    PS pipe(fhat, ldf, Sr, that, ldt, Sc, P, id, id);
+    const int nk = (int)(P / BK);
+    const int total = (int)(cb1 - cb0) * nk;
+    f32x16 acc[TS::TM][TS::TN];
+    zero_acc(acc);
+    if (total > 0) {
+      auto fetch = [&](auto slot, int st) {
+        if (st >= total) st = total - 1;
+        pipe.template prefetch<slot.value>(i0, (cb0 + st / nk) * FB, (int64_t)(st % nk) * BK);
+      };
+      static_for<PS::DEPTH>([&](auto d) { fetch(d, d.value); });
+      pipe.template commit<0>(smem, 0);
+      fetch(std::integral_constant<int, 0>{}, PS::DEPTH);
+      __syncthreads();
+      int base = 0;
+      for (int64_t cb = cb0; cb < cb1; ++cb) {
+        for (int kt0 = 0; kt0 < nk; kt0 += PS::UNROLL, base += PS::UNROLL) {
+          static_for<PS::UNROLL>([&](auto u) {
+            constexpr int slot = (u.value + 1) % PS::DEPTH;
+            pipe.template step<slot>(acc, smem, u.value & 1, true, lane, wm, wn,
+                                     [&]() { fetch(std::integral_constant<int, slot>{}, base + u.value + 1 + PS::DEPTH); });
+            __syncthreads();
+          });
+        }
+        int64_t sc = Sc, ib = i0;
+        asm volatile("" : "+s"(sc), "+s"(ib));
+        nce_tile_epilogue<TS>(acc, rs, Z, zdiag, ib, cb * FB, sc, diag_off, inv_tau, shift, lane, wm, wn);
+        zero_acc(acc);
+      }
+    }
+  } else if constexpr (ALIGNED) {
     // One continuous software pipeline over (column tile, k-step): the first k-step of the next tile is fetched and
     // committed to LDS during the last step of the current one, so an epilogue is followed by MFMAs at once.
     Pipeline<FB, FB, KMAJOR, KMAJOR, true, true, IdentityXf, IdentityXf> pipe;
@@ -163,7 +198,7 @@ __global__ __launch_bounds__(256, ALIGNED ? EGNN_NCE_FWD_WAVES : 1) void nce_fwd
     const int64_t j0 = cb * FB;
     f32x16 acc[TS::TM][TS::TN];
     zero_acc(acc);
-    mainloop<FB, FB, KMAJOR, KMAJOR, VEC4>(acc, fhat, ldf, i0, Sr, that, ldt, j0, Sc, 0, P, id, id, smem);
+    mainloop_sel<SPLIT, FB, FB, KMAJOR, KMAJOR, VEC4>(acc, fhat, ldf, i0, Sr, that, ldt, j0, Sc, 0, P, id, id, smem);
     // The epilogue addresses are functions of loop-invariant quantities (i0, Sc); left alone, the compiler hoists one
     // 64-bit pointer per accumulator row out of the column-block loop (~150 registers, one wave per SIMD).  Laundering
     // the two scalars through an empty asm makes it recompute them per tile instead (a few dozen scalar ops).
@@ -312,16 +347,16 @@ __device__ __forceinline__ float nce_bwd_finish(float v, int64_t row, int64_t c,
   return scale * v;
 }
 
-template <int BM, int AMAJ, bool VEC4, bool EXPZ, bool BW = true>
-__global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ Z, int64_t ldz, int64_t M, int64_t Kd,
+template <int BM, int AMAJ, bool VEC4, bool EXPZ, bool BW = true, bool SPLIT = false>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 1) void nce_bwd_kernel(const float* __restrict__ Z, int64_t ldz, int64_t M, int64_t Kd,
                                                       int64_t diag_off, const float* __restrict__ lse, float shift,
                                                       const float* __restrict__ Bm, int64_t P, int64_t ldb,
                                                       const float* __restrict__ Im, int64_t ldi,
                                                       float coef, const float* __restrict__ g, float* __restrict__ C,
                                                       int64_t ldc, int64_t k_per_split, float* __restrict__ ws) {
   constexpr int BN = 128;
-  using TS = TileShape<BM, BN>;
-  __shared__ __attribute__((aligned(16))) float smem[TS::SMEM_FLOATS];
+  using TS = typename TileSel<SPLIT, BM, BN>::type;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int64_t tiles_n = (P + BN - 1) / BN;
   const int64_t tiles = (int64_t)gridDim.x;
   // workgroup b runs on XCD b % 8: keep the column tiles of one row tile on the same XCD and next to each other in
@@ -341,16 +376,29 @@ __global__ __launch_bounds__(256) void nce_bwd_kernel(const float* __restrict__ 
   f32x16 acc[TS::TM][TS::TN];
   zero_acc(acc);
   IdentityXf id;
+  // interior tiles with whole k-steps run the loop without edge handling (the split pipeline's ring needs it)
+  const bool full = SPLIT && m0 + BM <= M && n0 + BN <= P && (kend - kbeg) % BK == 0;
+  auto run = [&](auto fo, const auto& xa, const auto& xb) {
+    mainloop_sel<SPLIT, BM, BN, AMAJ, MNMAJOR, VEC4, fo.value>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, kbeg, kend, xa, xb, smem);
+  };
+  auto both = [&](const auto& xa, const auto& xb) {
+    if constexpr (SPLIT) {
+      if (full) run(std::true_type{}, xa, xb);
+      else run(std::false_type{}, xa, xb);
+    } else {
+      run(std::false_type{}, xa, xb);
+    }
+  };
   if constexpr (!EXPZ) {
     NceGradXf xf{lse, AMAJ == MNMAJOR, diag_off};
-    mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, kbeg, kend, xf, id, smem);
+    both(xf, id);
   } else if constexpr (AMAJ == KMAJOR) {
-    mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, kbeg, kend, id, id, smem);
+    both(id, id);
   } else if constexpr (BW) {   // teacher side, rows of fhat weighted while they are staged
     RowWeightXf xw{lse, shift};
-    mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, kbeg, kend, id, xw, smem);
+    both(id, xw);
   } else {                     // teacher side, Bm already holds w o fhat (nce_row_weight_kernel)
-    mainloop<BM, BN, AMAJ, MNMAJOR, VEC4>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, kbeg, kend, id, id, smem);
+    both(id, id);
   }
   const int lane = egnn_lane();
   const int wave = egnn_wave_id();
@@ -427,30 +475,37 @@ void launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag
   const int64_t ksteps = (Kd + BK - 1) / BK;
   const int64_t k_per_split = ((ksteps + nsplit - 1) / nsplit) * BK;
   const dim3 grid((unsigned)(big ? t128 : ((M + 63) / 64) * tiles_n), (unsigned)nsplit);
-  if constexpr (AMAJ == MNMAJOR) {
-    if (ws && expz && vec4 && big) {   // teacher side of the unit-rows form: weight the Kd student rows once, then a plain GEMM
-      float* wx = ws + (size_t)nsplit * M * P;
-      const int64_t blocks = (Kd * P + 255) / 256;
-      hipLaunchKernelGGL(nce_row_weight_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, Bm, ldb, lse, shift, Kd, P, wx);
-      hipLaunchKernelGGL((nce_bwd_kernel<128, AMAJ, true, true, false>), grid, dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, shift, wx, P, P,
-                         Im, ldi, coef, g, C, ldc, k_per_split, ws);
-      if (nsplit > 1) {
-        const int64_t rb = (M * P + 255) / 256;
-        hipLaunchKernelGGL((nce_bwd_reduce_kernel<AMAJ, true>), dim3((unsigned)(rb < 4096 ? rb : 4096)), dim3(256), 0, st, ws, nsplit, M, P, Kd,
-                           diag_off, lse, shift, Im, ldi, coef, g, C, ldc);
-      }
-      return;
+  const bool split = big && egnn_split_pipe();   // 128-row tiles: products on the bf16 pipe (gemm_split.h)
+  constexpr size_t shm_f32 = (size_t)TileShape<128, 128>::SMEM_FLOATS * 4, shm_split = (size_t)TileShapeS<128, 128>::SMEM_BYTES;
+  int rc = EGNN_OK;
+#define EGNN_NCE_BWD_ARGS(B_, LDB_) Z, ldz, M, Kd, diag_off, lse, shift, B_, P, LDB_, Im, ldi, coef, g, C, ldc, k_per_split, ws
+  if (AMAJ == MNMAJOR && ws && expz && vec4 && big) {   // teacher side of the unit-rows form: weight the Kd student rows once, then a plain GEMM
+    float* wx = ws + (size_t)nsplit * M * P;
+    const int64_t blocks = (Kd * P + 255) / 256;
+    hipLaunchKernelGGL(nce_row_weight_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, Bm, ldb, lse, shift, Kd, P, wx);
+    if (split) rc = launch_dyn_lds<nce_bwd_kernel<128, AMAJ, true, true, false, true>>(grid, dim3(256), shm_split, st, EGNN_NCE_BWD_ARGS(wx, P));
+    else rc = launch_dyn_lds<nce_bwd_kernel<128, AMAJ, true, true, false, false>>(grid, dim3(256), shm_f32, st, EGNN_NCE_BWD_ARGS(wx, P));
+    if (rc != EGNN_OK) return;
+    if (nsplit > 1) {
+      const int64_t rb = (M * P + 255) / 256;
+      hipLaunchKernelGGL((nce_bwd_reduce_kernel<AMAJ, true>), dim3((unsigned)(rb < 4096 ? rb : 4096)), dim3(256), 0, st, ws, nsplit, M, P, Kd,
+                         diag_off, lse, shift, Im, ldi, coef, g, C, ldc);
     }
+    return;
   }
-#define EGNN_NCE_BWD(BM_, V, E) hipLaunchKernelGGL((nce_bwd_kernel<BM_, AMAJ, V, E>), grid, dim3(256), 0, st, Z, ldz, M, Kd, diag_off, lse, shift, Bm, P, ldb, Im, ldi, coef, g, C, ldc, k_per_split, ws)
-  if (big) {
-    if (vec4) { if (expz) EGNN_NCE_BWD(128, true, true); else EGNN_NCE_BWD(128, true, false); }
-    else { if (expz) EGNN_NCE_BWD(128, false, true); else EGNN_NCE_BWD(128, false, false); }
+#define EGNN_NCE_BWD(BM_, V, E, S_) launch_dyn_lds<nce_bwd_kernel<BM_, AMAJ, V, E, true, S_>>(grid, dim3(256), S_ ? shm_split : (size_t)TileShape<BM_, 128>::SMEM_FLOATS * 4, st, EGNN_NCE_BWD_ARGS(Bm, ldb))
+  if (split) {
+    if (vec4) { if (expz) EGNN_NCE_BWD(128, true, true, true); else EGNN_NCE_BWD(128, true, false, true); }
+    else { if (expz) EGNN_NCE_BWD(128, false, true, true); else EGNN_NCE_BWD(128, false, false, true); }
+  } else if (big) {
+    if (vec4) { if (expz) EGNN_NCE_BWD(128, true, true, false); else EGNN_NCE_BWD(128, true, false, false); }
+    else { if (expz) EGNN_NCE_BWD(128, false, true, false); else EGNN_NCE_BWD(128, false, false, false); }
   } else {
-    if (vec4) { if (expz) EGNN_NCE_BWD(64, true, true); else EGNN_NCE_BWD(64, true, false); }
-    else { if (expz) EGNN_NCE_BWD(64, false, true); else EGNN_NCE_BWD(64, false, false); }
+    if (vec4) { if (expz) EGNN_NCE_BWD(64, true, true, false); else EGNN_NCE_BWD(64, true, false, false); }
+    else { if (expz) EGNN_NCE_BWD(64, false, true, false); else EGNN_NCE_BWD(64, false, false, false); }
   }
 #undef EGNN_NCE_BWD
+#undef EGNN_NCE_BWD_ARGS
   if (nsplit > 1) {
     const int64_t blocks = (M * P + 255) / 256;
     const dim3 rgrid((unsigned)(blocks < 4096 ? blocks : 4096));
@@ -493,7 +548,14 @@ extern "C" int egnn_nce_block_fwd_f32(const float* fhat, int64_t ld_f, const flo
   dim3 grid((unsigned)rb, (unsigned)nsplit);
   const bool fixed = nce_unit_form(tau, unit_rows);
   const bool aligned = Z && vec4 && fixed && Sr % FB == 0 && Sc % FB == 0 && P % BK == 0 && Sc < (1LL << 28);
-#define EGNN_NCE_FWD(V, F, A) hipLaunchKernelGGL((nce_fwd_kernel<V, F, A>), grid, dim3(256), 0, st, fhat, ld_f, that, ld_t, Sr, Sc, diag_off, P, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split)
+  const bool split = egnn_split_pipe() && (!aligned || P % (BK * PipelineS<FB, FB, KMAJOR, KMAJOR, true, true, IdentityXf, IdentityXf>::UNROLL) == 0);
+#define EGNN_NCE_FWD(V, F, A)                                                                                                              \
+  do {                                                                                                                                     \
+    if (split) launch_dyn_lds<nce_fwd_kernel<V, F, A, true>>(grid, dim3(256), (size_t)TileShapeS<FB, FB>::SMEM_BYTES, st, fhat, ld_f, that, ld_t, Sr, \
+                                                             Sc, diag_off, P, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split);           \
+    else launch_dyn_lds<nce_fwd_kernel<V, F, A, false>>(grid, dim3(256), (size_t)TileShape<FB, FB>::SMEM_FLOATS * 4, st, fhat, ld_f, that, ld_t, Sr,  \
+                                                        Sc, diag_off, P, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split);                \
+  } while (0)
   if (aligned) EGNN_NCE_FWD(true, true, true);
   else if (vec4) { if (fixed) EGNN_NCE_FWD(true, true, false); else EGNN_NCE_FWD(true, false, false); }
   else { if (fixed) EGNN_NCE_FWD(false, true, false); else EGNN_NCE_FWD(false, false, false); }

@@ -330,8 +330,10 @@ def gemm_raw(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False,
         split_k = 1 if tiles >= 128 or K < 4096 else max(1, min(64, 512 // max(tiles, 1), K // 1024))
     lib = _lib.load()
     ws = None
-    nws = lib.egnn_gemm_ws_floats(int(trans_a), int(trans_b), M, N, K, split_k) if (a_rows is None and b_rows is None) else \
-        (split_k * M * N if split_k > 1 else 0)
+    # split-K partials, the skinny kernels' row-chunk partials, the bf16 planes of a small B operand (gemm_split.h)
+    nws = lib.egnn_gemm_ws_floats(int(trans_a), int(trans_b), M, N, K, split_k)
+    if a_rows is not None or b_rows is not None:
+        nws = max(nws, split_k * M * N if split_k > 1 else 0)
     if nws > 0:
         ws = torch.empty(nws, dtype=torch.float32, device=a.device)
     if a_rows is None and b_rows is None:
