@@ -14,7 +14,7 @@ beta=0.1, nce_T=0.075, max_samples=16384, proj_dim=256).  Inputs are resident in
 Rank 0 prints ONE JSON line (contract in the task statement) carrying also
   "roofline":     the SpMM aggregate kernel (K=256 GCN layer) timed with HIP events on its own stream
                   inside the timed region; achieved = algorithmic bytes / avg launch time
-  "roofline_mfma": (extra) the G-CRD entry points -- the largest share of the step, fp32-MFMA-bound -- timed the same way;
+  "roofline_mfma": (extra) the G-CRD entry points -- the largest share of the step, matrix-pipe-bound -- timed the same way;
                   achieved = 6 S^2 P flops per step / their time
   "cpu_baseline": the CPU oracle (pure-PyTorch restatement of the reference path) timed on the host cores
                   on the SAME synthetic inputs, a bounded sample of epochs (rank 0, N=1 only).
@@ -436,9 +436,16 @@ def main():
     nsum = nce_probe.summary()
     if nsum:
         tf = nsum["flops"] / nsum["secs"] / 1e12
+        # the products run on the bf16 matrix pipe (csrc/gemm_split.h: three bf16 terms per fp32 operand, six exact partial
+        # products per fp32 product), unless EGNN_GEMM_PIPE=f32 pins them to the f32-input MFMA
+        split = not os.environ.get("EGNN_GEMM_PIPE", "").startswith("f")
+        peak = 2500.0 / 6.0 if split else 157.3
         roofline_mfma = dict(bound="mfma", kernel="nce_fwd_kernel + nce_bwd_kernel x2 + split-K reduce (egnn_nce_fwd_f32, egnn_nce_bwd_f32): "
-                                                  "the G-CRD loss, largest share of the step", achieved=round(tf, 1), peak=157.3,
-                             unit="TFLOP/s", frac=round(tf / 157.3, 4), dtype="f32 (v_mfma_f32_32x32x2_f32)",
+                                                  "the G-CRD loss, largest share of the step", achieved=round(tf, 1), peak=round(peak, 1),
+                             unit="TFLOP/s (fp32 products)", frac=round(tf / peak, 4),
+                             dtype="f32 operands and accumulators; products as 6 x v_mfma_f32_32x32x16_bf16 on a three-way bf16 split "
+                                   "(peak = 2500 dense bf16 TFLOP/s / 6)" if split else "f32 (v_mfma_f32_32x32x2_f32)",
+                             mfma_tflops_issued=round(tf * (6.0 if split else 1.0), 1),
                              flops_per_step=int(nsum["flops"] / max(1, n_probe)),
                              ms_per_step=round(1e3 * nsum["secs"] / max(1, n_probe), 3), calls_timed=nsum["calls"])
     roofline_local = None

@@ -396,6 +396,49 @@ def test_gemm_split_k_and_asymmetric_operand():
     assert torch.equal(o1, o2)
 
 
+_PIPE_SNIPPET = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import efficient_gnns_amd.ops as ops
+g = torch.Generator().manual_seed(5)
+out = []
+for (M, N, K, ta, tb) in [(4096, 256, 256, False, True), (3000, 384, 1000, False, False), (512, 256, 20000, True, False), (1500, 200, 750, True, True)]:
+    # twelve binades of dynamic range inside every dot product: the low planes of the split carry real weight
+    a = torch.randn((K, M) if ta else (M, K), generator=g) * torch.exp2(torch.randint(-6, 6, ((K, M) if ta else (M, K)), generator=g).float())
+    b = torch.randn((N, K) if tb else (K, N), generator=g) * torch.exp2(torch.randint(-6, 6, ((N, K) if tb else (K, N)), generator=g).float())
+    c = ops.gemm_raw(a.cuda(), b.cuda(), ta, tb).cpu().double()
+    A, B = (a.t() if ta else a).double(), (b.t() if tb else b).double()
+    err = ((c - A @ B).abs() / (A.abs() @ B.abs())).flatten()
+    out.append((float(err.mean()), float(err.max())))
+print("RESULT", out)
+"""
+
+
+def test_split_pipeline_error_is_not_above_the_f32_mfma_pipeline():
+    """csrc/gemm_split.h claims fp32 results from the bf16 matrix pipe (three bf16 terms per operand, six exact partial
+    products, dropped terms <= 2^-26 |a b|).  Both pipelines (EGNN_GEMM_PIPE selects one per process) are compared with a
+    float64 product on operands with a wide dynamic range; error unit = sum_k |a_k b_k|.  The split pipeline must not be
+    less accurate than the f32-input MFMA (it is slightly MORE accurate: its partial products are exact, only the
+    accumulation rounds)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for pipe in ("f32", "split"):
+        env = dict(os.environ, EGNN_GEMM_PIPE=pipe)
+        if pipe == "split":
+            env.pop("EGNN_GEMM_PIPE")
+        p = subprocess.run([sys.executable, "-c", _PIPE_SNIPPET % root], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1]
+        res[pipe] = eval(line[len("RESULT"):])
+    for (mean_s, max_s), (mean_f, max_f) in zip(res["split"], res["f32"]):
+        assert mean_s <= 1.10 * mean_f, res          # the same fp32 accumulation rounding, no extra term
+        assert max_s <= 1.5 * max_f and max_s < 2e-6, res
+        assert mean_f < 2e-7, res                    # sanity: the unit is fp32 rounding (6e-8), not bf16 (4e-3)
+
+
 def test_linear_and_matmul_autograd():
     g = torch.Generator().manual_seed(1)
     x = torch.randn(777, 128, generator=g)
