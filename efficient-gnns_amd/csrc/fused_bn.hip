@@ -215,15 +215,28 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const float* __restri
 }
 
 // dx = gamma * rstd * (d - (sum d + xhat * sum d xhat) / n_stat)    (train);   dx = gamma * rstd * d   (eval)
+// COLSUM: the block also leaves the column sums of the dx rows it wrote in part[blockIdx.x][c] (blocks 2i / 2i + 1 are the
+// two slots of pair i in merge_partials' layout; the grid is even): the gradient of a bias added in front of the BatchNorm (conv / Linear bias,
+// gnn.py:47-48,296-306) is the column sum of dx -- formed here, the separate pass over dx (gy.sum(0)) disappears.
+template <bool COLSUM>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const BnParams q, const float* __restrict__ dy, int64_t ldd,
                                                                const float* __restrict__ dbeta, const float* __restrict__ dgamma,
-                                                               float inv_n_stat, float* __restrict__ dx, int64_t ldx_out) {
+                                                               float inv_n_stat, float* __restrict__ dx, int64_t ldx_out,
+                                                               float* __restrict__ part) {
+  __shared__ float sh[COLSUM ? 4 : 1][COLSUM ? kMaxChunks * 256 : 1];
   const int lane = egnn_lane();
   const int wave = egnn_wave_id();
   const int chunks = (int)((q.C + 255) / 256);
   for (int j = 0; j < chunks; ++j) {
     const int64_t c = j * 256 + lane * 4;
-    if (c >= q.C) continue;
+    float so[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (COLSUM) {
+      if (c >= q.C) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh[wave][j * 256 + lane * 4 + k] = 0.f;
+        continue;
+      }
+    } else if (c >= q.C) continue;
     float mean[4], rstd[4], g[4], b[4], sb[4], sg[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -246,10 +259,41 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(const BnParams q,
         bn_elem(q, xv[k], mean[k], rstd[k], g[k], b[k], row, c + k, xhat, gate);
         const float d = gv[k] * gate;
         o[k] = g[k] * rstd[k] * (d - sb[k] - xhat * sg[k]);
+        if constexpr (COLSUM) so[k] += o[k];
       }
       *reinterpret_cast<float4*>(dx + row * ldx_out + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
+    if constexpr (COLSUM) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sh[wave][j * 256 + lane * 4 + k] = so[k];
+    }
   }
+  if constexpr (COLSUM) {
+    __syncthreads();
+    for (int64_t c = threadIdx.x; c < q.C; c += 256) part[(int64_t)blockIdx.x * q.C + c] = (sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c]);
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int nblocks, int64_t C, float* __restrict__ out) {
+  float a, b; bool owner; int64_t c;
+  merge_partials(part, nblocks, C, a, b, owner, c);   // nblocks = PAIRS of partial rows
+  if (owner) out[c] = a + b;
+}
+
+// nn.BatchNorm1d's state update of a training step in ONE launch (the ATen chain is five: add_, mul_, add_, mul_, add_):
+//   num_batches_tracked += 1;  running = (1 - m) running + m stat, with the unbiased variance n / (n - 1) var;
+//   momentum < 0: cumulative average, m = 1 / num_batches_tracked (momentum=None)
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ var, int64_t C,
+                                                                float unbias, float momentum, float* __restrict__ rmean,
+                                                                float* __restrict__ rvar, long long* __restrict__ tracked) {
+  const long long t = tracked ? tracked[0] + 1 : 1;
+  const float m = momentum < 0.f ? 1.f / (float)t : momentum;
+  for (int64_t c = threadIdx.x; c < C; c += 256) {
+    rmean[c] = (1.f - m) * rmean[c] + m * mean[c];
+    rvar[c] = (1.f - m) * rvar[c] + (m * unbias) * var[c];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && tracked) tracked[0] = t;
 }
 
 bool shape_ok(const void* p, int64_t ld, int64_t C) { return C > 0 && C % 4 == 0 && C <= kMaxChunks * 256 && ld % 4 == 0 && egnn_aligned16(p); }
@@ -340,8 +384,32 @@ extern "C" int egnn_bn_act_bwd_apply_f32(const float* x, int64_t ld, const float
   EGNN_CHECK_ARG(n > 0 && x && dy && mean && var && sum_dbeta && sum_dgamma && dx && ld >= C && ld_dy >= C && ld_dx >= C);
   if (!shape_ok(x, ld, C) || !shape_ok(dy, ld_dy, C) || !shape_ok(dx, ld_dx, C)) return EGNN_EALIGN;
   const BnParams q{x, ld, n, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed, (const unsigned long long*)seed_dev};
-  hipLaunchKernelGGL(bn_act_bwd_apply_kernel, dim3(row_blocks(n)), dim3(256), 0, (hipStream_t)stream, q, dy, ld_dy, sum_dbeta,
-                     sum_dgamma, inv_count, dx, ld_dx);
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel<false>, dim3(row_blocks(n)), dim3(256), 0, (hipStream_t)stream, q, dy, ld_dy, sum_dbeta,
+                     sum_dgamma, inv_count, dx, ld_dx, nullptr);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_bn_act_bwd_colsum_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
+                                          const float* mean, const float* var, float eps, const float* gamma, const float* beta, int relu,
+                                          float p, uint64_t seed, const uint64_t* seed_dev, int batch_stats, float* dgamma, float* dbeta,
+                                          float* dx, int64_t ld_dx, float* dx_colsum, float* ws, size_t ws_floats, void* stream) {
+  EGNN_CHECK_ARG(dx && ld_dx >= C);
+  const int rc = egnn_bn_act_bwd_reduce_f32(x, ld, dy, ld_dy, n, C, mean, var, eps, gamma, beta, relu, p, seed, seed_dev, dgamma, dbeta,
+                                            ws, ws_floats, stream);
+  if (rc != EGNN_OK) return rc;
+  const float inv_count = batch_stats ? 1.f / (float)n : 0.f;
+  if (!dx_colsum)
+    return egnn_bn_act_bwd_apply_f32(x, ld, dy, ld_dy, n, C, mean, var, eps, gamma, beta, relu, p, seed, seed_dev, dbeta, dgamma, inv_count, dx,
+                                     ld_dx, stream);
+  EGNN_CHECK_ARG(n > 0 && x && dy && mean && var && ld >= C && ld_dy >= C);
+  if (!shape_ok(dx, ld_dx, C)) return EGNN_EALIGN;
+  const BnParams q{x, ld, n, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed, (const unsigned long long*)seed_dev};
+  int nb = row_blocks(n);
+  if (nb > 2 * kStatBlocks) nb = 2 * kStatBlocks;   // the workspace holds 2 kStatBlocks partial rows (the reduce half is done with it: same stream)
+  nb = (nb + 1) & ~1;                               // whole pairs; a block past the rows writes zeros
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, dim3(nb), dim3(256), 0, st, q, dy, ld_dy, dbeta, dgamma, inv_count, dx, ld_dx, ws);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((C + kMergeCols - 1) / kMergeCols)), dim3(256), 0, st, ws, nb / 2, C, dx_colsum);
   return egnn_launch_status();
 }
 
@@ -349,10 +417,15 @@ extern "C" int egnn_bn_act_bwd_f32(const float* x, int64_t ld, const float* dy, 
                                    const float* mean, const float* var, float eps, const float* gamma, const float* beta, int relu,
                                    float p, uint64_t seed, const uint64_t* seed_dev, int batch_stats, float* dgamma, float* dbeta,
                                    float* dx, int64_t ld_dx, float* ws, size_t ws_floats, void* stream) {
-  EGNN_CHECK_ARG(dx && ld_dx >= C);
-  const int rc = egnn_bn_act_bwd_reduce_f32(x, ld, dy, ld_dy, n, C, mean, var, eps, gamma, beta, relu, p, seed, seed_dev, dgamma, dbeta,
-                                            ws, ws_floats, stream);
-  if (rc != EGNN_OK) return rc;
-  return egnn_bn_act_bwd_apply_f32(x, ld, dy, ld_dy, n, C, mean, var, eps, gamma, beta, relu, p, seed, seed_dev, dbeta, dgamma,
-                                   batch_stats ? 1.f / (float)n : 0.f, dx, ld_dx, stream);
+  return egnn_bn_act_bwd_colsum_f32(x, ld, dy, ld_dy, n, C, mean, var, eps, gamma, beta, relu, p, seed, seed_dev, batch_stats, dgamma, dbeta, dx,
+                                    ld_dx, nullptr, ws, ws_floats, stream);
+}
+
+extern "C" int egnn_bn_running_update_f32(const float* mean, const float* var, int64_t C, int64_t n, float momentum, float* running_mean,
+                                          float* running_var, int64_t* num_batches_tracked, void* stream) {
+  EGNN_CHECK_ARG(C > 0 && n > 0 && mean && var && running_mean && running_var);
+  const float unbias = n > 1 ? (float)n / (float)(n - 1) : 1.f;
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mean, var, C, unbias, momentum, running_mean,
+                     running_var, (long long*)num_batches_tracked);
+  return egnn_launch_status();
 }

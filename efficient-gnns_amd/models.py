@@ -47,6 +47,11 @@ class _Student(nn.Module):
             else:
                 x = F.dropout(F.relu(bn(x)), p=self.dropout, training=self.training)
             self.out_feat = x
+        if self.training and x.is_cuda:
+            # the last hidden state has two consumers (the last conv and student_proj(out_feat[train_idx]), gnn.py:150):
+            # the projection's row-compact input gradient is added into the conv's dense one instead of autograd's
+            # zero-fill + scatter + full-size add (ops._GradTap)
+            x = self.out_feat = ops.grad_tap(x)
         return self.convs[-1](x, adj_t)
 
 

@@ -227,7 +227,12 @@ class _SpMM(torch.autograd.Function):
 
 
 def colsum(g: Tensor) -> Tensor:
-    """Column sums of a [n, C] gradient (bias gradients)."""
+    """Column sums of a [n, C] gradient (bias gradients).  A gradient that comes straight out of the fused BatchNorm
+    backward carries them already (formed while dx was written: egnn_bn_act_bwd_colsum_f32), tagged with the tensor
+    version they belong to -- any in-place change of the gradient since then (autograd accumulation) voids the tag."""
+    tag = getattr(g, "_egnn_colsum", None)
+    if tag is not None and tag[1] == g._version and tag[0].shape[0] == g.shape[1]:
+        return tag[0]
     return g.sum(0)
 
 
@@ -380,15 +385,62 @@ def matmul(x: Tensor, w: Tensor, bias: Tensor | None = None) -> Tensor:
     return _MatMul.apply(x, w, bias, False)
 
 
-class _LinearRows(torch.autograd.Function):
-    """y = x[idx] @ weight^T + bias for UNIQUE row ids, without materialising x[idx] (egnn_gemm_rows_f32): the forward
-    gathers in the A-operand load, dW = dY^T x[idx] in the B-operand load, dx scatters the rows of dY W."""
+class _TapBox:
+    """Row-compact gradient pieces of one tapped tensor, waiting for its ``_GradTap.backward``."""
+    __slots__ = ("pending",)
+
+    def __init__(self):
+        self.pending = []
+
+
+class _GradTap(torch.autograd.Function):
+    """Identity with a side door for row-compact gradients.  The student's last hidden state h feeds the next conv AND
+    ``student_proj(h[train_idx])`` (gnn.py:150-156); autograd would add the two gradients as dense [N,C] tensors (zero
+    fill + scatter of the projection's rows + a full-size add: ~160 us at N = 169 343).  Consumers that only touch some
+    rows (``linear_rows``) leave (ids, rows) in the box and return NO gradient for the tapped tensor -- the graph edge
+    still orders them before this node -- and the rows are added into the dense gradient of the other consumer here."""
 
     @staticmethod
-    def forward(ctx, x, idx, weight, bias):
+    def forward(ctx, x, box):
+        ctx.box, ctx.meta = box, (x.shape, x.dtype, x.device)
+        ctx.set_materialize_grads(False)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        pend, ctx.box.pending = ctx.box.pending, []
+        if not pend:
+            return g, None
+        if g is None:
+            shape, dtype, dev = ctx.meta
+            g = torch.zeros(shape, dtype=dtype, device=dev)
+        elif g.is_sparse or not g.is_contiguous():
+            g = g.to_dense().contiguous() if g.is_sparse else g.contiguous()
+        for idx, rows in pend:
+            g.index_add_(0, idx, rows)   # unique ids: a plain read-modify-write of those rows, deterministic
+        return g, None
+
+
+def grad_tap(x: Tensor) -> Tensor:
+    """``x`` again, marked so that ``linear_rows(x, idx, ...)`` hands its input gradient over in row-compact form."""
+    if not (torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.dim() == 2):
+        return x
+    box = _TapBox()
+    y = _GradTap.apply(x, box)
+    y._egnn_tap = box
+    return y
+
+
+class _LinearRows(torch.autograd.Function):
+    """y = x[idx] @ weight^T + bias for UNIQUE row ids, without materialising x[idx] (egnn_gemm_rows_f32): the forward
+    gathers in the A-operand load, dW = dY^T x[idx] in the B-operand load, dx scatters the rows of dY W (or leaves
+    them with the tap of a ``grad_tap`` tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, weight, bias, box):
         w = pad_pitch(weight) if not _pitch_ok(weight) else weight   # 0.8 MB at 256 x 750: rows 16-byte aligned
         ctx.save_for_backward(x, idx, w)
-        ctx.has_bias = bias is not None
+        ctx.has_bias, ctx.box = bias is not None, box
         return gemm_raw(x, w, False, True, bias, a_rows=idx)
 
     @staticmethod
@@ -397,20 +449,24 @@ class _LinearRows(torch.autograd.Function):
         gy = _rowmajor(gy)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.zeros(x.shape, dtype=gy.dtype, device=gy.device)
-            gx.index_copy_(0, idx, gemm_raw(gy, w, False, False))
+            rows = gemm_raw(gy, w, False, False)
+            if ctx.box is not None:
+                ctx.box.pending.append((idx, rows))
+            else:
+                gx = torch.zeros(x.shape, dtype=gy.dtype, device=gy.device)
+                gx.index_copy_(0, idx, rows)
         if ctx.needs_input_grad[2]:
             gw = gemm_raw(gy, x, True, False, b_rows=idx)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gb = colsum(gy)
-        return gx, None, gw, gb
+        return gx, None, gw, gb, None
 
 
 def linear_rows(x: Tensor, idx: Tensor, weight: Tensor, bias: Tensor | None = None) -> Tensor:
     """``F.linear(x[idx], weight, bias)`` with the row gather fused into the GEMM (unique ``idx``)."""
     if gemm_backend() == "blas" or not x.is_cuda:
         return torch.nn.functional.linear(take_rows(x, idx), weight, bias)
-    return _LinearRows.apply(x, idx, weight, bias)
+    return _LinearRows.apply(x, idx, weight, bias, getattr(x, "_egnn_tap", None) if torch.is_grad_enabled() else None)
 
 
 def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None) -> Tensor:
@@ -644,10 +700,15 @@ class _BnAct(torch.autograd.Function):
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         nws = lib.egnn_bn_ws_floats(C)
         ws = torch.empty(nws, dtype=torch.float32, device=dev)
-        rc = lib.egnn_bn_act_bwd_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), eps,
-                                     _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), batch_stats, _lib.ptr(dgamma), _lib.ptr(dbeta),
-                                     _lib.ptr(dx), dx.stride(0), _lib.ptr(ws), nws, _lib.stream())
-        _lib.check(rc, "egnn_bn_act_bwd_f32")
+        # the producer of x usually added a bias (GCNConv / nn.Linear in front of the BatchNorm): its gradient is the column
+        # sum of dx, formed in the same pass (ops.colsum picks the tag up)
+        cs = torch.empty(C, dtype=torch.float32, device=dev) if batch_stats else None
+        rc = lib.egnn_bn_act_bwd_colsum_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), eps,
+                                            _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), batch_stats, _lib.ptr(dgamma),
+                                            _lib.ptr(dbeta), _lib.ptr(dx), dx.stride(0), _lib.ptr(cs), _lib.ptr(ws), nws, _lib.stream())
+        _lib.check(rc, "egnn_bn_act_bwd_colsum_f32")
+        if cs is not None:
+            dx._egnn_colsum = (cs, dx._version)
         return dx, dgamma, dbeta, None, None, None, None, None, None, None
 
 
@@ -676,11 +737,16 @@ def bn_act(x: Tensor, bn: "torch.nn.BatchNorm1d", relu: bool = True, p: float = 
             ws = torch.empty(nws, dtype=torch.float32, device=dev)
             _lib.check(lib.egnn_bn_stats_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(ws), nws, _lib.stream()),
                        "egnn_bn_stats_f32")
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
-            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
-            bn.running_var.mul_(1 - m).add_(var, alpha=m * n / max(n - 1, 1))
+        with torch.no_grad():   # nn.BatchNorm1d's state update, one launch (momentum=None: the cumulative average, formed on the device)
+            rm, rv, nbt = bn.running_mean, bn.running_var, bn.num_batches_tracked
+            if rm.dtype == torch.float32 and rv.dtype == torch.float32 and nbt.dtype == torch.int64 and rm.is_contiguous() and rv.is_contiguous():
+                _lib.check(lib.egnn_bn_running_update_f32(_lib.ptr(mean), _lib.ptr(var), C, n, -1.0 if bn.momentum is None else float(bn.momentum),
+                                                          _lib.ptr(rm), _lib.ptr(rv), _lib.ptr(nbt), _lib.stream()), "egnn_bn_running_update_f32")
+            else:
+                bn.num_batches_tracked += 1
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                bn.running_var.mul_(1 - m).add_(var, alpha=m * n / max(n - 1, 1))
     else:
         mean, var = bn.running_mean, bn.running_var
     drop = p if (training and p > 0) else 0.0

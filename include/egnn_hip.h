@@ -404,6 +404,20 @@ int egnn_bn_act_bwd_apply_f32(const float* x, int64_t ld, const float* dy, int64
                               float p, uint64_t seed, const uint64_t* seed_dev, const float* sum_dbeta, const float* sum_dgamma,
                               float inv_count, float* dx, int64_t ld_dx, void* stream);
 
+/* egnn_bn_act_bwd_f32 that also leaves dx_colsum[c] = sum over rows of dx[:,c] (nullable): the gradient of a bias added in
+ * front of the BatchNorm (GCNConv / nn.Linear bias, /root/reference/arxiv_pyg/gnn.py:47-48,296-306), formed while dx is
+ * written instead of by a second pass over it (ATen: gy.sum(0)).  Same workspace. */
+int egnn_bn_act_bwd_colsum_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C, const float* mean,
+                               const float* var, float eps, const float* gamma, const float* beta, int relu, float p, uint64_t seed,
+                               const uint64_t* seed_dev, int batch_stats, float* dgamma, float* dbeta, float* dx, int64_t ld_dx,
+                               float* dx_colsum, float* ws, size_t ws_floats, void* stream);
+
+/* nn.BatchNorm1d's training-step state update in one launch (torch/nn/modules/batchnorm.py: num_batches_tracked += 1,
+ * running = (1 - m) running + m stat with the unbiased variance n/(n-1) var):  mean / var [C] = this batch's statistics,
+ * momentum < 0 = cumulative average (momentum=None); num_batches_tracked: nullable device int64. */
+int egnn_bn_running_update_f32(const float* mean, const float* var, int64_t C, int64_t n, float momentum, float* running_mean,
+                               float* running_var, int64_t* num_batches_tracked, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,14 @@ def _reference_run(gnn, mode, steps=3, hp=None):
     return losses, logits, accs
 
 
+def _free_port() -> int:
+    """A port the kernel just handed out (bind to 0): no collisions between the tests of one session."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _worker(rank, world, port, gnn, mode, q, hp=None):
     HP = dict(globals()["HP"], **(hp or {}))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -140,7 +148,7 @@ def test_sharded_training_matches_single_process_oracle(gnn, mode, world, max_sa
     hp = dict(max_samples=max_samples)
     if max_samples < 0:
         hp = dict(max_samples=64, train_ids_below=-max_samples)
-    port = 29500 + (os.getpid() + hash((gnn, mode, world, max_samples))) % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, gnn, mode, q, hp)) for r in range(world)]
     for p in procs:
         p.start()
@@ -206,7 +214,7 @@ def test_bench_entry_point_runs_sharded_and_prints_contract_json(tmp_path, workl
     import json
     ctx = mp.get_context("spawn")
     path = str(tmp_path / "bench.json")
-    port = 31500 + (os.getpid() + hash((workload, world, overlap))) % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_bench_worker, args=(r, world, port, path, workload, overlap)) for r in range(world)]
     for p in procs:
         p.start()
@@ -260,7 +268,7 @@ def _plan_worker(rank, world, port, q):
 def test_collective_plan_from_local_rows_equals_the_global_plan(world):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
-    port = 33500 + (os.getpid() + world) % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_plan_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
