@@ -31,6 +31,7 @@ int skinny_kind(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, bool 
 
 bool gemm_split_pipe() { return egnn_split_pipe(); }
 
+
 struct GemmArgs {
   int64_t M, N, K;
   const float* A; int64_t lda;
@@ -146,20 +147,15 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GemmArgs
   zero_acc(acc);
   IdentityXf id;
   if constexpr (SPLIT) {
-    // interior tiles (all but the last row / column of tiles) run a loop without edge handling over the whole k-steps;
-    // a ragged end of the reduction (K % 16) is one more, guarded, step
-    if (m0 + BM <= g.M && n0 + BN <= g.N) {
-      const int64_t kfull = kbeg + ((kend - kbeg) / BK) * BK;
-      mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, true, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kfull, id, id,
-                                                                                 smem, g.rows, g.rows);
-      if (kfull < kend) {
-        __syncthreads();
-        mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kfull, kend, id, id,
-                                                                                    smem, g.rows, g.rows);
-      }
-    } else {
-      mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kend, id, id,
-                                                                                  smem, g.rows, g.rows);
+    // the whole k-steps run a loop without per-element guards (rows past the edge of the last tile are clamped to the
+    // last row and never stored); a ragged end of the reduction (K % 16) is one more, guarded, step
+    const int64_t kfull = kbeg + ((kend - kbeg) / BK) * BK;
+    mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, true, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kfull, id, id, smem,
+                                                                               g.rows, g.rows);
+    if (kfull < kend) {
+      __syncthreads();
+      mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kfull, kend, id, id, smem,
+                                                                                  g.rows, g.rows);
     }
   } else {
     mainloop<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kend, id, id,
@@ -189,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pb_kernel(const GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
   IdentityXf id;
-  if (m0 + 128 <= g.M && (kend - kbeg) % BK == 0) mainloop_pb<AMAJ, VEC4, true, GA>(acc, g.A, g.lda, m0, g.M, bp, kbeg, kend, id, smem, g.rows);
+  if ((kend - kbeg) % BK == 0) mainloop_pb<AMAJ, VEC4, true, GA>(acc, g.A, g.lda, m0, g.M, bp, kbeg, kend, id, smem, g.rows);
   else mainloop_pb<AMAJ, VEC4, false, GA>(acc, g.A, g.lda, m0, g.M, bp, kbeg, kend, id, smem, g.rows);
   const bool partial = g.split_k > 1;
   const float alpha = partial ? 1.f : g.alpha * (g.alpha_dev ? g.alpha_dev[0] : 1.f);
@@ -304,7 +300,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   static const bool narrow_forced = getenv("EGNN_GEMM_NARROW_STORE") != nullptr;   // A/B switch for the epilogue form
   GemmArgs g{M, N, K, A, lda, B, ldb, bias, C, ldc, alpha, nullptr, split_k,
              ((ksteps + split_k - 1) / split_k) * BK, ws, a_rows ? a_rows : b_rows, (wide && !narrow_forced) ? 1 : 0,
-             (gemm_split_pipe() && !(trans_a && !trans_b)) ? 1 : 0,   // dW = X^T dY (both operands row-major in k) stays on the f32 pipe: 267 vs 280 us
+             gemm_split_pipe() ? 1 : 0,
              nullptr};
   hipStream_t st = (hipStream_t)stream;
   const bool vec4 = (lda % 4 == 0) && (ldb % 4 == 0) && egnn_aligned16(A) && egnn_aligned16(B);

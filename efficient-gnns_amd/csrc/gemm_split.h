@@ -67,17 +67,10 @@ struct StagerS {
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       if constexpr (MAJOR == KMAJOR) {
-#if EGNN_ABL & 64
-        const int64_t r = r0 + (t >> 2) + 128 * i;                 // lab: a wave-load covers 16 rows x 128 B (full lines)
-        const int64_t k = ((k0 >> 5) << 5) + (t & 3) * 8;
-#else
-        const int64_t r = r0 + (t >> 1) + 128 * i;
+        int64_t r = r0 + (t >> 1) + 128 * i;
+        if (FULL && r >= rmax) r = rmax - 1;   // FULL = whole k-steps, no per-element guards: rows past the edge re-read the last row (never stored)
         const int64_t k = k0 + (t & 1) * 8;
-#endif
         int64_t rs = r;
-#if EGNN_ABL & 32
-        rs = r0 + ((t >> 1) & 7);                                 // lab: every load hits 8 rows (L1-resident)
-#endif
         if constexpr (GATHER) rs = (FULL || r < rmax) ? ridx[r] : 0;
         const float* q = p + rs * ld + k;
         if constexpr (FULL) {
@@ -96,7 +89,8 @@ struct StagerS {
           for (int j = 0; j < 8; ++j) v[i][j] = (r < rmax && k + j < kmax) ? xf(q[j], r, k + j) : 0.f;
         }
       } else {
-        const int64_t r = r0 + (t & 127) + 128 * i;
+        int64_t r = r0 + (t & 127) + 128 * i;
+        if (FULL && r >= rmax) r = rmax - 1;
         const int64_t k = k0 + (t >> 7) * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -115,7 +109,7 @@ struct StagerS {
     if constexpr (FULLONLY) {
       load_impl<true>(p, ld, r0, rmax, k0, kmax, xf, ridx);
     } else {
-      const bool full = (r0 + R <= rmax) && (k0 + BK <= kmax);  // block-uniform
+      const bool full = k0 + BK <= kmax;  // block-uniform (rows past the edge are clamped, see load_impl)
       if (full) load_impl<true>(p, ld, r0, rmax, k0, kmax, xf, ridx);
       else load_impl<false>(p, ld, r0, rmax, k0, kmax, xf, ridx);
     }
@@ -129,21 +123,11 @@ struct StagerS {
       const int row = (MAJOR == KMAJOR ? (t >> 1) : (t & 127)) + 128 * i;
       const int g = MAJOR == KMAJOR ? (t & 1) : (t >> 7);
       u32x4 p0, p1, p2;
-#if EGNN_ABL & 16
-      p0 = u32x4{__float_as_uint(v[i][0]), __float_as_uint(v[i][1]), __float_as_uint(v[i][2]), __float_as_uint(v[i][3])};
-      p1 = u32x4{__float_as_uint(v[i][4]), __float_as_uint(v[i][5]), __float_as_uint(v[i][6]), __float_as_uint(v[i][7])};
-      p2 = p0;
-#else
       split8(v[i], p0, p1, p2);
-#endif
       char* d = lds + row * S_ROW + g * 16;
-#if EGNN_ABL & 8
-      asm volatile("" ::"v"(p0), "v"(p1), "v"(p2), "v"(d));
-#else
       *reinterpret_cast<u32x4*>(d) = p0;
       *reinterpret_cast<u32x4*>(d + R * S_ROW) = p1;
       *reinterpret_cast<u32x4*>(d + 2 * R * S_ROW) = p2;
-#endif
     }
   }
 };
@@ -157,9 +141,6 @@ struct TileShapeS {
   static constexpr int SMEM_FLOATS = SMEM_BYTES / 4;
 };
 
-#ifndef EGNN_ABL
-#define EGNN_ABL 0   // lab only: bit 0 no B staging, bit 1 no B fragment reads, bit 2 no A staging (results wrong on purpose)
-#endif
 #ifndef EGNN_SPLIT_DEPTH
 #define EGNN_SPLIT_DEPTH 4   // k-steps of operand tiles in flight (register ring)
 #endif
@@ -200,12 +181,8 @@ struct PipelineS {
   template <int SLOT>
   __device__ __forceinline__ void commit(float* smem, int buf) const {
     char* s = reinterpret_cast<char*>(smem);
-#if !(EGNN_ABL & 4)
     sa[SLOT].store(s + buf * TS::A_BUF);
-#endif
-#if !(EGNN_ABL & 1)
     sb[SLOT].store(s + B_OFF + buf * TS::B_BUF);
-#endif
   }
   // one k-step out of LDS buffer `cur`; with `more`, ring slot SLOT is committed to buffer cur ^ 1 on the way and
   // refill() (the loads of the stage that takes the slot over) is called right behind it
@@ -221,13 +198,7 @@ struct PipelineS {
 #pragma unroll
       for (int tm = 0; tm < TS::TM; ++tm) a[tm][p] = *reinterpret_cast<const u32x4*>(sA + p * BM * S_ROW + tm * 32 * S_ROW);
 #pragma unroll
-      for (int tn = 0; tn < TS::TN; ++tn) {
-#if EGNN_ABL & 2
-        b[tn][p] = a[tn][p];
-#else
-        b[tn][p] = *reinterpret_cast<const u32x4*>(sB + p * BN * S_ROW + tn * 32 * S_ROW);
-#endif
-      }
+      for (int tn = 0; tn < TS::TN; ++tn) b[tn][p] = *reinterpret_cast<const u32x4*>(sB + p * BN * S_ROW + tn * 32 * S_ROW);
     }
     // the six kept partial products, smallest first; consecutive MFMAs go to different accumulators
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
@@ -314,7 +285,7 @@ __device__ __forceinline__ void mainloop_split(f32x16 (&acc)[TM_][TN_], const fl
 // so that a wave owning 32 output columns fetches its B fragments of a k-step with three coalesced 1 KB loads straight
 // into registers (L2-resident): no LDS, no split VALU and no barrier traffic for B; only the big A operand is staged and
 // cut in the loop.  Wave arrangement 1 x 4: every wave holds all 128 rows x 32 columns of the block tile.
-// (lab, 4096^3: without the B staging the loop runs 1.25 x faster; tools/lab/gemm_lab + EGNN_ABL)
+// (opt-in, EGNN_GEMM_PLANES=1: measured slower than the two-operand staging on the layer shapes, see gemm.hip)
 __host__ __device__ inline int64_t planes_nk(int64_t K) { return (K + BK - 1) / BK; }
 __host__ __device__ inline int64_t planes_nb(int64_t N) { return ((N + 127) / 128) * 4; }   // 32-column units, whole 128-column tiles
 __host__ __device__ inline size_t planes_bytes(int64_t N, int64_t K) { return (size_t)planes_nb(N) * (size_t)planes_nk(K) * 3 * 1024; }

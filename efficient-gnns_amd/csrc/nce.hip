@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void nce_bwd_kernel(const float
   zero_acc(acc);
   IdentityXf id;
   // interior tiles with whole k-steps run the loop without edge handling (the split pipeline's ring needs it)
-  const bool full = SPLIT && m0 + BM <= M && n0 + BN <= P && (kend - kbeg) % BK == 0;
+  const bool full = SPLIT && (kend - kbeg) % BK == 0;   // rows past the edge are clamped inside the unguarded loop
   auto run = [&](auto fo, const auto& xa, const auto& xb) {
     mainloop_sel<SPLIT, BM, BN, AMAJ, MNMAJOR, VEC4, fo.value>(acc, Z, ldz, m0, M, Bm, ldb, n0, P, kbeg, kend, xa, xb, smem);
   };

@@ -43,7 +43,7 @@ int main(int argc, char** argv) {
   const int64_t n = 169343;
   const Shape shapes[] = {
       {"xW1", 0, 1, n, 256, 128, 1},      {"xW2", 0, 1, n, 256, 256, 1},     {"xW2_kn", 0, 0, n, 256, 256, 1},
-      {"dX2", 0, 0, n, 256, 256, 1},      {"dW2", 1, 0, 256, 256, n, 64},    {"dW1", 1, 0, 128, 256, n, 64},
+      {"dX2", 0, 0, n, 256, 256, 1},      {"dW2", 1, 0, 256, 256, n, 64},    {"dW1", 1, 0, 128, 256, n, 64}, {"dW2_sk128", 1, 0, 256, 256, n, 128}, {"dW2_sk192", 1, 0, 256, 256, n, 192}, {"dWt_sk42", 1, 0, 256, 752, 90941, 42}, {"dWt_sk84", 1, 0, 256, 752, 90941, 84},
       {"proj_s", 0, 1, 16384, 128, 256, 1}, {"proj_t", 0, 1, 16384, 128, 768, 1}, {"sq4k", 0, 1, 4096, 4096, 4096, 1},
       {"small", 0, 1, 300, 200, 72, 1},   {"small_tn", 1, 0, 130, 257, 1000, 3}, {"small_nn", 0, 0, 129, 130, 50, 1},
       {"small_tt", 1, 1, 200, 140, 90, 1}, {"proj_t750", 0, 1, 90941, 256, 750, 1}, {"small_pb", 0, 1, 1000, 200, 72, 1}, {"small_pb_kn", 0, 0, 1203, 136, 200, 1},
