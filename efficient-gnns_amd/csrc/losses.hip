@@ -216,3 +216,117 @@ extern "C" int egnn_normalize_rows_bwd_f32(const float* xhat, int64_t ldh, const
                      inv_norm, idx, n, D, eps, dx, ldx, accumulate);
   return egnn_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// test() of the reference (gnn.py:198-218): y_pred = out.argmax(-1); Evaluator accuracy per split = hits / size.
+// One pass: 16 lanes per row (first maximal column, torch.argmax's rule), per-split hit / row counts per block, then a
+// fixed-order (integer, exact) sum of the block partials.  Replaces argmax + eq + cast + 3 x (index, mean) + cat.
+namespace {
+constexpr int kAccBlocks = 1024;
+
+__global__ __launch_bounds__(256) void split_accuracy_kernel(const float* __restrict__ logits, int64_t ld, int64_t n, int64_t C,
+                                                             const int64_t* __restrict__ y, const signed char* __restrict__ split_id,
+                                                             int* __restrict__ part) {
+  __shared__ int sh[4][6];
+  const int lane = egnn_lane(), wave = egnn_wave_id();
+  const int sub = lane >> 4, l16 = lane & 15;
+  int hits[3] = {0, 0, 0}, cnt[3] = {0, 0, 0};
+  for (int64_t r0 = (int64_t)blockIdx.x * 16; r0 < n; r0 += (int64_t)gridDim.x * 16) {
+    const int64_t row = r0 + wave * 4 + sub;
+    const bool live = row < n;
+    float best = -INFINITY;
+    int64_t arg = 0x7fffffffffffLL;
+    if (live) {
+      const float* lp = logits + row * ld;
+      for (int64_t c = l16; c < C; c += 16) {
+        const float v = lp[c];
+        if (v > best || (v != v && best == best)) { best = v; arg = c; }   // NaN counts as the maximum, like torch
+      }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {   // 16-lane butterfly: larger value wins, ties go to the smaller column
+      const float ov = __shfl_xor(best, o);
+      const int64_t oa = __shfl_xor(arg, o);
+      const bool take = (ov > best) || (ov != ov && best == best) || (ov == best && oa < arg) || (ov != ov && best != best && oa < arg);
+      if (take) { best = ov; arg = oa; }
+    }
+    if (live && l16 == 0) {
+      const int s = split_id[row];
+      if (s >= 0 && s < 3) {
+        cnt[s] += 1;
+        hits[s] += (arg == y[row]) ? 1 : 0;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { hits[k] += __shfl_xor(hits[k], o); cnt[k] += __shfl_xor(cnt[k], o); }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { sh[wave][k] = hits[k]; sh[wave][3 + k] = cnt[k]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void split_accuracy_final_kernel(const int* __restrict__ part, int nblocks, double* __restrict__ acc3) {
+  const int lane = threadIdx.x;
+  long long v[6] = {0, 0, 0, 0, 0, 0};
+  for (int b = lane; b < nblocks; b += 64)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] += part[b * 6 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+  if (lane < 3) acc3[lane] = v[3 + lane] > 0 ? (double)v[lane] / (double)v[3 + lane] : 0.0 / 0.0;   // empty split: nan, like mean of nothing
+}
+
+// dst[idx[r], :] += src[r, :] for UNIQUE ids (a row-compact gradient joining a dense one, ops._GradTap): one wave per row
+__global__ __launch_bounds__(256) void rows_add_kernel(float* __restrict__ dst, int64_t ldd, const int64_t* __restrict__ idx,
+                                                       const float* __restrict__ src, int64_t lds_, int64_t n, int64_t C, int vec4) {
+  const int lane = egnn_lane(), wave = egnn_wave_id();
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
+    float* d = dst + idx[r] * ldd;
+    const float* s = src + r * lds_;
+    if (vec4) {
+      for (int64_t c = lane * 4; c < C; c += 256) {
+        const float4 a = *reinterpret_cast<const float4*>(s + c);
+        float4 b = *reinterpret_cast<float4*>(d + c);
+        b.x += a.x; b.y += a.y; b.z += a.z; b.w += a.w;
+        *reinterpret_cast<float4*>(d + c) = b;
+      }
+    } else {
+      for (int64_t c = lane; c < C; c += 64) d[c] += s[c];
+    }
+  }
+}
+}  // namespace
+
+extern "C" size_t egnn_split_accuracy_ws_ints(void) { return (size_t)kAccBlocks * 6; }
+
+extern "C" int egnn_split_accuracy_f32(const float* logits, int64_t ld, int64_t n, int64_t C, const int64_t* y, const int8_t* split_id,
+                                       double* acc3, int32_t* ws, size_t ws_ints, void* stream) {
+  EGNN_CHECK_ARG(n > 0 && C > 0 && ld >= C && logits && y && split_id && acc3 && ws);
+  if (ws_ints < egnn_split_accuracy_ws_ints()) return EGNN_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t want = (n + 15) / 16;
+  const int nb = (int)(want < kAccBlocks ? want : kAccBlocks);
+  hipLaunchKernelGGL(split_accuracy_kernel, dim3(nb), dim3(256), 0, st, logits, ld, n, C, y, (const signed char*)split_id, (int*)ws);
+  hipLaunchKernelGGL(split_accuracy_final_kernel, dim3(1), dim3(64), 0, st, (const int*)ws, nb, acc3);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_rows_add_f32(float* dst, int64_t ld_dst, const int64_t* idx, const float* src, int64_t ld_src, int64_t n, int64_t C,
+                                 void* stream) {
+  EGNN_CHECK_ARG(n >= 0 && C > 0 && ld_dst >= C && ld_src >= C);
+  if (n == 0) return EGNN_OK;
+  EGNN_CHECK_ARG(dst && idx && src);
+  const int vec4 = (C % 4 == 0 && ld_dst % 4 == 0 && ld_src % 4 == 0 && egnn_aligned16(dst) && egnn_aligned16(src)) ? 1 : 0;
+  const int64_t want = (n + 3) / 4;
+  hipLaunchKernelGGL(rows_add_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, (hipStream_t)stream, dst, ld_dst, idx, src,
+                     ld_src, n, C, vec4);
+  return egnn_launch_status();
+}

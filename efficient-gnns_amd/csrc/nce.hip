@@ -285,13 +285,15 @@ __global__ __launch_bounds__(256, ALIGNED ? EGNN_NCE_FWD_WAVES : 1) void nce_fwd
   }
 }
 
-__global__ __launch_bounds__(1024) void nce_finalize_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
-                                                            const float* __restrict__ zdiag, int64_t S, int nsplit,
-                                                            float inv_count, float* __restrict__ lse,
-                                                            float* __restrict__ loss) {
-  __shared__ float red[1024];
+// lse_i = merge of the column-split partials; loss = inv_count * sum_i (lse_i - z_ii).  Two launches: rows in parallel with
+// one partial per block, then a fixed-order sum of the block partials (the former single-block kernel took 43 us at S = 16384).
+constexpr int kFinalBlocks = 1024;
+__global__ __launch_bounds__(256) void nce_finalize_rows_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
+                                                                const float* __restrict__ zdiag, int64_t S, int nsplit,
+                                                                float* __restrict__ lse, float* __restrict__ block_part) {
+  __shared__ float red[256];
   float local = 0.f;
-  for (int64_t row = threadIdx.x; row < S; row += 1024) {
+  for (int64_t row = blockIdx.x * 256LL + threadIdx.x; row < S; row += (int64_t)gridDim.x * 256) {
     float m = -INFINITY, s = 0.f;
     for (int k = 0; k < nsplit; ++k) lse_merge(m, s, pm[row * nsplit + k], ps[row * nsplit + k]);
     const float l = m + logf(s);
@@ -300,7 +302,21 @@ __global__ __launch_bounds__(1024) void nce_finalize_kernel(const float* __restr
   }
   red[threadIdx.x] = local;
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void nce_finalize_sum_kernel(const float* __restrict__ block_part, int nblocks, float inv_count,
+                                                               float* __restrict__ loss) {
+  __shared__ float red[256];
+  float local = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) local += block_part[i];
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
@@ -516,7 +532,7 @@ void launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag
 
 }  // namespace
 
-extern "C" size_t egnn_nce_ws_floats(int64_t S) { return (size_t)S * (1 + 2 * kMaxSplit); }
+extern "C" size_t egnn_nce_ws_floats(int64_t S) { return (size_t)S * (1 + 2 * kMaxSplit) + kFinalBlocks; }
 
 extern "C" size_t egnn_nce_bwd_ws_floats(int64_t Sr, int64_t Sc, int64_t P) {
   if (Sr <= 0 || Sc <= 0 || P <= 0) return 0;
@@ -560,7 +576,10 @@ extern "C" int egnn_nce_block_fwd_f32(const float* fhat, int64_t ld_f, const flo
   else if (vec4) { if (fixed) EGNN_NCE_FWD(true, true, false); else EGNN_NCE_FWD(true, false, false); }
   else { if (fixed) EGNN_NCE_FWD(false, true, false); else EGNN_NCE_FWD(false, false, false); }
 #undef EGNN_NCE_FWD
-  hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(1024), 0, st, pm, ps, zdiag, Sr, nsplit, inv_count, lse, loss);
+  float* block_part = ps + Sr * kMaxSplit;
+  const int fb = (int)((Sr + 255) / 256 < kFinalBlocks ? (Sr + 255) / 256 : kFinalBlocks);
+  hipLaunchKernelGGL(nce_finalize_rows_kernel, dim3(fb), dim3(256), 0, st, pm, ps, zdiag, Sr, nsplit, lse, block_part);
+  hipLaunchKernelGGL(nce_finalize_sum_kernel, dim3(1), dim3(256), 0, st, block_part, fb, inv_count, loss);
   return egnn_launch_status();
 }
 

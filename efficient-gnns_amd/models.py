@@ -204,6 +204,8 @@ def evaluate_tensors(model, x, adj_t, y, split_idx):
     """``test()`` (gnn.py:198-218) without the host read: (logits, device tensor of the three accuracies)."""
     model.eval()
     out = model(x, adj_t)
+    if out.is_cuda and y.dtype == torch.int64 and y.numel() == out.shape[0]:
+        return out, ops.split_accuracy(out, y, split_idx)   # argmax + the three Evaluator accuracies in one pass
     y_pred = out.argmax(dim=-1, keepdim=True)
     hit = (y_pred == y).view(-1).to(torch.float32)
     return out, torch.stack([hit[split_idx[k]].mean() for k in ("train", "valid", "test")])

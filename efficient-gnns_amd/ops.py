@@ -416,9 +416,50 @@ class _GradTap(torch.autograd.Function):
             g = torch.zeros(shape, dtype=dtype, device=dev)
         elif g.is_sparse or not g.is_contiguous():
             g = g.to_dense().contiguous() if g.is_sparse else g.contiguous()
-        for idx, rows in pend:
-            g.index_add_(0, idx, rows)   # unique ids: a plain read-modify-write of those rows, deterministic
+        for idx, rows in pend:   # unique ids: a plain read-modify-write of those rows, deterministic
+            rows = _rowmajor(rows)
+            _lib.check(_lib.load().egnn_rows_add_f32(_lib.ptr(g), g.stride(0), _lib.ptr(idx), _lib.ptr(rows), rows.stride(0), rows.shape[0],
+                                                     rows.shape[1], _lib.stream()), "egnn_rows_add_f32")
         return g, None
+
+
+_SPLIT_IDS: dict = {}
+
+
+def split_ids(split_idx: dict, n: int, device) -> Tensor:
+    """int8 [n]: 0 / 1 / 2 for the train / valid / test nodes of ``split_idx``, -1 elsewhere (a node listed twice keeps the
+    later split); built once per split dict (keyed on the identity and version of its index tensors, which the entry keeps alive)."""
+    names = ("train", "valid", "test")
+    key = (n, str(device)) + tuple((split_idx[k].data_ptr(), split_idx[k]._version, split_idx[k].numel()) for k in names)
+    hit = _SPLIT_IDS.get(key)
+    if hit is None:
+        if len(_SPLIT_IDS) > 8:
+            _SPLIT_IDS.clear()
+        sid = torch.full((n,), -1, dtype=torch.int8, device=device)
+        for i, k in enumerate(names):
+            sid[split_idx[k].to(device)] = i
+        hit = _SPLIT_IDS[key] = (sid, tuple(split_idx[k] for k in names))
+    return hit[0]
+
+
+def split_accuracy(logits: Tensor, y: Tensor, split_idx: dict) -> Tensor:
+    """float64 [3]: the Evaluator accuracies of test() (gnn.py:198-218) for train / valid / test in one pass over the
+    logits (egnn_split_accuracy_f32: first-max argmax, integer hit counts over split sizes)."""
+    _lib.require_gpu(logits, y)
+    logits = _rowmajor(logits)
+    n, C = logits.shape
+    yv = y.reshape(-1)
+    if yv.dtype != torch.int64 or yv.numel() != n:
+        raise TypeError("split_accuracy: labels must be int64 [n] or [n,1]")
+    yv = yv.contiguous()
+    sid = split_ids(split_idx, n, logits.device)
+    lib = _lib.load()
+    nws = lib.egnn_split_accuracy_ws_ints()
+    ws = torch.empty(nws, dtype=torch.int32, device=logits.device)
+    acc = torch.empty(3, dtype=torch.float64, device=logits.device)
+    _lib.check(lib.egnn_split_accuracy_f32(_lib.ptr(logits), logits.stride(0), n, C, _lib.ptr(yv), _lib.ptr(sid), _lib.ptr(acc), _lib.ptr(ws), nws,
+                                           _lib.stream()), "egnn_split_accuracy_f32")
+    return acc
 
 
 def grad_tap(x: Tensor) -> Tensor:

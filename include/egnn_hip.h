@@ -418,6 +418,19 @@ int egnn_bn_act_bwd_colsum_f32(const float* x, int64_t ld, const float* dy, int6
 int egnn_bn_running_update_f32(const float* mean, const float* var, int64_t C, int64_t n, float momentum, float* running_mean,
                                float* running_var, int64_t* num_batches_tracked, void* stream);
 
+/* test() of /root/reference/arxiv_pyg/gnn.py:198-218 in one pass: acc3[k] = |{i : split_id[i] == k, argmax_c logits[i,c] == y[i]}|
+ * / |{i : split_id[i] == k}| for the splits k = 0, 1, 2 (train / valid / test; any other id = not evaluated), as the ogb
+ * Evaluator forms it (integer hit count over split size, in double).  argmax = first maximal column (torch.argmax).
+ * ws: egnn_split_accuracy_ws_ints() int32. */
+size_t egnn_split_accuracy_ws_ints(void);
+int egnn_split_accuracy_f32(const float* logits, int64_t ld, int64_t n, int64_t C, const int64_t* y, const int8_t* split_id,
+                            double* acc3, int32_t* ws, size_t ws_ints, void* stream);
+
+/* dst[idx[r], :] += src[r, :], r < n, for UNIQUE ids: the row-compact gradient of x[idx] joins the dense gradient of x
+ * (the backward of gnn.py:150 `feat[train_idx]` next to the conv's gradient) without a zero-filled [N,C] temporary. */
+int egnn_rows_add_f32(float* dst, int64_t ld_dst, const int64_t* idx, const float* src, int64_t ld_src, int64_t n, int64_t C,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

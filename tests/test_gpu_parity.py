@@ -439,6 +439,77 @@ def test_split_pipeline_error_is_not_above_the_f32_mfma_pipeline():
         assert mean_f < 2e-7, res                    # sanity: the unit is fp32 rounding (6e-8), not bf16 (4e-3)
 
 
+def test_split_accuracy_one_pass_matches_evaluator_arithmetic():
+    """egnn_split_accuracy_f32 = argmax (first maximal column) + per-split hit count / split size in double, the ogb
+    Evaluator's arithmetic (gnn.py:198-218), incl. ties, an all-equal row, nodes in no split and an odd class count."""
+    g = torch.Generator().manual_seed(3)
+    for n, C in ((1000, 40), (777, 7), (5000, 349), (33, 1)):
+        logits = torch.randn(n, C, generator=g).round(decimals=1)          # one decimal: many exact ties
+        logits[5 % n] = 0.25                                                 # all columns equal -> column 0
+        y = torch.randint(0, C, (n, 1), generator=g)
+        perm = torch.randperm(n, generator=g)
+        a, b = n // 2, n // 2 + n // 5
+        split = {"train": perm[:a].clone(), "valid": perm[a:b].clone(), "test": perm[b:b + n // 10].clone()}   # the rest: unlabelled
+        acc = ops.split_accuracy(logits.to(DEV), y.to(DEV), {k: v.to(DEV) for k, v in split.items()}).cpu()
+        pred = logits.argmax(dim=-1)
+        for i, k in enumerate(("train", "valid", "test")):
+            idx = split[k]
+            want = float((pred[idx] == y[idx, 0]).sum()) / max(idx.numel(), 1) if idx.numel() else float("nan")
+            assert (acc[i] != acc[i] and want != want) or float(acc[i]) == want, (n, C, k, float(acc[i]), want)
+
+
+@pytest.mark.parametrize("momentum", [0.1, None])
+def test_bn_state_update_kernel_matches_nn_batchnorm(momentum):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(3000, 64, generator=g) * 2 + 0.5
+    ref = torch.nn.BatchNorm1d(64, momentum=momentum)
+    got = torch.nn.BatchNorm1d(64, momentum=momentum).to(DEV)
+    ref.train(); got.train()
+    for step in range(3):
+        xs = x * (1 + step)
+        ref(xs)
+        ops.bn_act(xs.to(DEV), got, relu=False, p=0.0, training=True)
+    close(got.running_mean, ref.running_mean, rtol=1e-5, atol_scale=1e-6)
+    close(got.running_var, ref.running_var, rtol=1e-5, atol_scale=1e-6)
+    assert int(got.num_batches_tracked) == int(ref.num_batches_tracked) == 3
+
+
+def test_bias_gradient_formed_in_the_bn_backward_and_row_compact_tap():
+    """(1) The fused BatchNorm backward tags dx with its column sums (the gradient of a bias in front of the BatchNorm):
+    the tag equals dx.sum(0) to rounding and ops.colsum returns it.  (2) linear_rows on a grad_tap tensor hands its
+    input gradient over row-compact: the tapped tensor's gradient equals the plain dense accumulation."""
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(5000, 256, generator=g).to(DEV).requires_grad_()
+    bn = torch.nn.BatchNorm1d(256).to(DEV)
+    seen = []
+    x.register_hook(lambda gr: seen.append(gr))
+    y = ops.bn_act(x, bn, relu=True, p=0.0, training=True)
+    (y * torch.randn(5000, 256, generator=g).to(DEV)).sum().backward()
+    gr = seen[0]
+    tag = getattr(gr, "_egnn_colsum", None)
+    assert tag is not None and tag[1] == gr._version
+    scale = gr.abs().sum(0)
+    assert float(((tag[0] - gr.double().sum(0).float()).abs() / scale).max()) < 1e-6
+    assert ops.colsum(gr) is tag[0]
+    gr.add_(1.0)                                  # an in-place change voids the tag
+    assert ops.colsum(gr) is not tag[0]
+
+    def run(tap):
+        torch.manual_seed(0)
+        h0 = torch.randn(4000, 64, generator=torch.Generator().manual_seed(7)).to(DEV).requires_grad_()
+        w1 = torch.randn(32, 64, generator=torch.Generator().manual_seed(8)).to(DEV).requires_grad_()
+        w2 = torch.randn(16, 64, generator=torch.Generator().manual_seed(9)).to(DEV).requires_grad_()
+        idx = torch.randperm(4000, generator=torch.Generator().manual_seed(10))[:1500].to(DEV)
+        h = h0 * 2.0
+        h = ops.grad_tap(h) if tap else h
+        out = ops.linear(h, w1).square().sum() + ops.linear_rows(h, idx, w2).square().sum()
+        out.backward()
+        return h0.grad, w1.grad, w2.grad
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        close(u, v, rtol=1e-6, atol_scale=1e-6)
+
+
 def test_linear_and_matmul_autograd():
     g = torch.Generator().manual_seed(1)
     x = torch.randn(777, 128, generator=g)
