@@ -340,7 +340,12 @@ def main():
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
         import efficient_gnns_amd.dist as dist_mod
-        return dist_mod.bench_main(args, hp, MODEL, rank, world, device)
+        dist_mod.bench_main(args, hp, MODEL, rank, world, device)   # prints the line on rank 0; ends with barrier + destroy_process_group
+        # leave without the interpreter / static-destructor teardown: communicator background threads have been seen racing it
+        # (exit code -6 after all results were delivered) and the launcher reads every rank's exit code
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
     seed_all(args.seed)
     data = D.arxiv_like(args.scale, seed=args.seed)

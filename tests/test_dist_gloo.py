@@ -102,6 +102,20 @@ def _free_port() -> int:
         return sk.getsockname()[1]
 
 
+def _quiet_exit():
+    """End a rank: all ranks first meet at a barrier (none tears its connections down while a peer still talks), then the
+    process leaves WITHOUT running the interpreter / C++ static destructors: gloo's background threads otherwise race the
+    teardown now and then ('terminate called without an active exception', exit code -6, after every result was
+    delivered).  The SimpleQueue payload is written synchronously, nothing is left to flush."""
+    try:
+        dist.barrier()
+        dist.destroy_process_group()
+    finally:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+
+
 def _worker(rank, world, port, gnn, mode, q, hp=None):
     HP = dict(globals()["HP"], **(hp or {}))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -131,8 +145,11 @@ def _worker(rank, world, port, gnn, mode, q, hp=None):
         dist.all_gather_object(gathered, out.numpy())
         if rank == 0:
             q.put((losses, np.concatenate(gathered, 0), accs, prob.adj.plan.n_halo))
-    finally:
-        dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+    _quiet_exit()
 
 
 @pytest.mark.parametrize("gnn,mode,world,max_samples", [
@@ -202,9 +219,18 @@ def _bench_worker(rank, world, port, path, workload="arxiv", overlap="1"):
     hp = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=128, proj_dim=16, kernel="rbf")
     cfg = dict(hidden=32, layers=3 if workload == "arxiv" else 2, dropout=0.5, lr=0.01)
     lines = []
-    DD.bench_main(args, hp, cfg, rank, world, "cpu", backend="gloo", emit=lines.append)
-    if rank == 0:
-        open(path, "w").write(lines[0])
+    try:
+        DD.bench_main(args, hp, cfg, rank, world, "cpu", backend="gloo", emit=lines.append)   # ends with barrier + destroy_process_group
+        if rank == 0:
+            with open(path, "w") as f:
+                f.write(lines[0])
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)   # see _quiet_exit
 
 
 @pytest.mark.parametrize("workload,world,overlap", [("arxiv", 2, "1"), ("arxiv", 2, "0"), ("mag", 2, "1"), ("mag", 4, "1")])
@@ -260,8 +286,11 @@ def _plan_worker(rank, world, port, q):
         dist.all_gather_object(got, (same, same_gcn, ok_scatter))
         if rank == 0:
             q.put(got)
-    finally:
-        dist.destroy_process_group()
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+    _quiet_exit()
 
 
 @pytest.mark.parametrize("world", [2, 3])
