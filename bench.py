@@ -243,7 +243,10 @@ def parity_check(args, data, d, device, hp, PM):
     np.random.seed(args.seed + 17)
     got = PM.train_step(pm, d.x, d.adj_t, d.y, d.split_idx["train"], popt, args.training, hp, d.teacher_out_feat,
                         d.teacher_logits, psp, ptp, edge_p)
-    rel = max(abs(a - b) / max(abs(b), 1e-12) for a, b in zip(got, ref))
+    # relative error of each of the three terms; a term that is numerically zero next to the total (LSP with the rbf kernel on
+    # the synthetic features: both edge distributions are uniform, KL = 0 +- 1e-10) is measured against 1e-6 of the total
+    floor = 1e-6 * max(abs(ref[0]), 1.0)
+    rel = max(abs(a - b) / max(abs(b), floor) for a, b in zip(got, ref))
     ok = bool(rel <= 2e-4 and logit_err <= 1e-4 and all(abs(a - b) <= 1e-4 for a, b in zip(accs_p, accs_o)))
     return dict(ok=ok, what="first train step (dropout 0) + initial eval, GPU path vs CPU oracle, full size, same seeds/draw/weights",
                 loss=dict(gpu=got[0], cpu=ref[0]), loss_cls=dict(gpu=got[1], cpu=ref[1]), loss_aux=dict(gpu=got[2], cpu=ref[2]),

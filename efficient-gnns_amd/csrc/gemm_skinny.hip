@@ -21,7 +21,7 @@ __device__ __forceinline__ f4 mfma16(float a, float b, f4 c) { return __builtin_
 // Workgroup = 4 waves x 64 rows.  sW[K][NP + 4]: the +4 makes the per-step fragment read (rows 4q + j, q = lane >> 4)
 // conflict-free for ds_read_b32 (half-wave q = {0,1}: banks 0-15 / 16-31).
 template <int NT>
-__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
+__global__ __launch_bounds__(256, 2) void skinny_fwd_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ W,
                                                          int64_t ldw, int w_kmajor, const float* __restrict__ bias,
                                                          float* __restrict__ Y, int64_t ldy, int64_t M, int N, int K, float alpha) {
   extern __shared__ float sW[];
@@ -68,29 +68,45 @@ __global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[t][n] = f4{0.f, 0.f, 0.f, 0.f};
-  float4 a_cur[4], a_nxt[4];
+  // X is streamed in pairs of k-steps (two 16-byte loads per row group in flight per wave and pair, the next pair issued
+  // before the current one is consumed): with one step in flight per wave the kernel was latency-bound at 2.6 TB/s
+  float4 a_cur[2][4], a_nxt[2][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) a_cur[t] = *reinterpret_cast<const float4*>(xp[t]);
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    if (k0 + 16 < K) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) a_nxt[t] = *reinterpret_cast<const float4*>(xp[t] + k0 + 16);
-    }
-    const float* wrow = sW + (k0 + 4 * q) * LDW + r16;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {   // step j: k = k0 + 4q + j on both operands
-      float b[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) b[n] = wrow[j * LDW + n * 16];
+  for (int t = 0; t < 4; ++t) {
+    a_cur[0][t] = *reinterpret_cast<const float4*>(xp[t]);
+    a_cur[1][t] = *reinterpret_cast<const float4*>(xp[t] + (K > 16 ? 16 : 0));
+  }
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    if (k0 + 32 < K) {
+      const int k1 = k0 + 48 < K ? k0 + 48 : k0 + 32;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const float a = j == 0 ? a_cur[t].x : (j == 1 ? a_cur[t].y : (j == 2 ? a_cur[t].z : a_cur[t].w));
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[t][n] = mfma16(a, b[n], acc[t][n]);
+        a_nxt[0][t] = *reinterpret_cast<const float4*>(xp[t] + k0 + 32);
+        a_nxt[1][t] = *reinterpret_cast<const float4*>(xp[t] + k1);
       }
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) a_cur[t] = a_nxt[t];
+    for (int h = 0; h < 2; ++h) {
+      if (k0 + 16 * h < K) {   // block-uniform
+        const float* wrow = sW + (k0 + 16 * h + 4 * q) * LDW + r16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // step j: k = k0 + 16 h + 4q + j on both operands
+          float b[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) b[n] = wrow[j * LDW + n * 16];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float a = j == 0 ? a_cur[h][t].x : (j == 1 ? a_cur[h][t].y : (j == 2 ? a_cur[h][t].z : a_cur[h][t].w));
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[t][n] = mfma16(a, b[n], acc[t][n]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a_cur[h][t] = a_nxt[h][t];
   }
   // C layout: col = lane & 15, row = 4 * (lane >> 4) + reg
 #pragma unroll

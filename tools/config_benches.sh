@@ -9,5 +9,4 @@ try:
     d=json.loads(l); print(json.dumps({k:d[k] for k in ('value','ms_per_step','phases_ms','last_losses')}), d['config']['workload'][:100])
 except Exception as e: print('FAILED', l[:300])
 "; done
-echo "== opt-in memoisation"; EGNN_GCN_MEMOISE_AX=1 EGNN_CACHE_CONST_ROWS=1 timeout 600 python bench.py --steps 20 --warmup 3 --cpu-epochs 0 2>&1 | tail -1 | cut -c1-400
 echo "== S=8192 (script default max_samples)"; timeout 600 python bench.py --steps 20 --warmup 3 --cpu-epochs 0 --max-samples 8192 2>&1 | tail -1 | cut -c1-400
