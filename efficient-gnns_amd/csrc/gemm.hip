@@ -50,23 +50,24 @@ struct GemmArgs {
 };
 
 // epilogue of one output tile (or of one split-K partial)
-template <int BM, int BN, int TM_, int TN_>
+template <int BM, int BN, int WAVES_M = 2, int TM_, int TN_>
 __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TM_][TN_], const GemmArgs& g, int64_t m0, int64_t n0, int split,
                                            int lane, int wm, int wn) {
+  constexpr int WM = BM / WAVES_M, WN = BN / 2;
   const bool partial = g.split_k > 1;
   const float alpha = partial ? 1.f : g.alpha * (g.alpha_dev ? g.alpha_dev[0] : 1.f);
   float* out = partial ? g.ws + (int64_t)split * g.M * g.N : g.C;
   const int64_t ldo = partial ? g.N : g.ldc;
 #pragma unroll
   for (int tn = 0; tn < TN_; ++tn) {
-    const int64_t c = n0 + acc_col<BM, BN>(wn, tn, lane);
+    const int64_t c = n0 + wn * WN + tn * 32 + (lane & 31);
     if (c >= g.N) continue;
     const float bv = (!partial && g.bias) ? g.bias[c] : 0.f;
 #pragma unroll
     for (int tm = 0; tm < TM_; ++tm) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + acc_row<BM, BN>(wm, tm, r, lane);
+        const int64_t row = m0 + wm * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < g.M) out[row * ldo + c] = alpha * acc[tm][tn][r] + bv;
       }
     }
@@ -77,11 +78,12 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TM_][TN_], const 
 // into rows in the operand buffers, which are free once the main loop has finished, and leave as 16-byte stores -- 256 B
 // contiguous per 16 lanes, 16 store instructions per wave instead of 64.  (The narrow stores were ~14 % of a K = 256 GEMM:
 // profiles/r01_gemm_mainloop_ablation.txt, "no epilogue".)  Needs 16-byte aligned output rows; else store_tile.
-template <int BM, int BN, int TM_, int TN_>
+template <int BM, int BN, int WAVES_M = 2, int TM_, int TN_>
 __device__ __forceinline__ void store_tile_wide(const f32x16 (&acc)[TM_][TN_], const GemmArgs& g, int64_t m0, int64_t n0, int split,
                                                 int lane, int wm, int wn, float* smem) {
-  constexpr int WM = BM / 2, WN = BN / 2, LD = WN + 4, F4 = WN / 4, RPI = 64 / F4;   // float4 per row, rows per store instruction
-  static_assert(4 * 32 * LD <= TileShape<BM, BN>::SMEM_FLOATS, "epilogue staging must fit the operand buffers");   // (the split image is larger)
+  constexpr int WM = BM / WAVES_M, WN = BN / 2, LD = WN + 4, F4 = WN / 4, RPI = 64 / F4;   // float4 per row, rows per store instruction
+  // the smaller of the two LDS images a kernel with this tile can have (f32 pipeline 4 waves; the 8-wave form is split-only)
+  static_assert(2 * WAVES_M * 32 * LD <= (WAVES_M == 2 ? 2 * (BM + BN) * LDS_LD : 2 * 3 * (BM + BN) * S_ROW / 4), "epilogue staging must fit the operand buffers");
   const bool partial = g.split_k > 1;
   const float alpha = partial ? 1.f : g.alpha * (g.alpha_dev ? g.alpha_dev[0] : 1.f);
   float* out = partial ? g.ws + (int64_t)split * g.M * g.N : g.C;
@@ -123,9 +125,12 @@ __device__ __forceinline__ void store_tile_wide(const f32x16 (&acc)[TM_][TN_], c
 
 // SPLIT: products on the bf16 matrix pipe from a three-way split of the fp32 operands (gemm_split.h); its LDS image
 // (72 KB for 128 x 128) is dynamic shared memory.
-template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER = 0, bool SPLIT = false>
-__global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GemmArgs g) {
-  using TS = typename TileSel<SPLIT, BM, BN>::type;
+// NTHR = 512: the 8-wave form of the split pipeline (waves 4 x 2, 256 x 128 block tile: 25 % less operand staging per FLOP)
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER = 0, bool SPLIT = false, int NTHR = 256>
+__global__ __launch_bounds__(NTHR, (SPLIT && NTHR == 256) ? 2 : 1) void gemm_kernel(const GemmArgs g) {
+  static_assert(NTHR == 256 || (SPLIT && BM == 256 && BN == 128), "the 8-wave form is the 256 x 128 split tile");
+  constexpr int WAVES_M = NTHR / 128;
+  using TS = typename std::conditional<NTHR == 256, typename TileSel<SPLIT, BM, BN>::type, TileShapeS<BM, BN, WAVES_M>>::type;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int64_t tiles_n = (g.N + BN - 1) / BN;
   // workgroup b runs on XCD b % 8: give every XCD a contiguous run of tiles, so that the column tiles of one row tile
@@ -150,20 +155,20 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GemmArgs
     // the whole k-steps run a loop without per-element guards (rows past the edge of the last tile are clamped to the
     // last row and never stored); a ragged end of the reduction (K % 16) is one more, guarded, step
     const int64_t kfull = kbeg + ((kend - kbeg) / BK) * BK;
-    mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, true, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kfull, id, id, smem,
-                                                                               g.rows, g.rows);
+    mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, true, GATHER == 1, GATHER == 2, NTHR>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kfull, id, id,
+                                                                                     smem, g.rows, g.rows);
     if (kfull < kend) {
       __syncthreads();
-      mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kfull, kend, id, id, smem,
-                                                                                  g.rows, g.rows);
+      mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2, NTHR>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kfull, kend, id,
+                                                                                        id, smem, g.rows, g.rows);
     }
   } else {
     mainloop<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kend, id, id,
                                                                           smem, g.rows, g.rows);
   }
   const int wave = egnn_wave_id();
-  if (g.wide_store) store_tile_wide<BM, BN>(acc, g, m0, n0, split, egnn_lane(), wave >> 1, wave & 1, smem);
-  else store_tile<BM, BN>(acc, g, m0, n0, split, egnn_lane(), wave >> 1, wave & 1);
+  if (g.wide_store) store_tile_wide<BM, BN, WAVES_M>(acc, g, m0, n0, split, egnn_lane(), wave >> 1, wave & 1, smem);
+  else store_tile<BM, BN, WAVES_M>(acc, g, m0, n0, split, egnn_lane(), wave >> 1, wave & 1);
 }
 
 // B pre-split into planes (a small, much-reused operand): 128 x 128 block tile, waves 1 x 4, only A staged through LDS
@@ -234,17 +239,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
   }
 }
 
-template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER, bool SPLIT>
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER, bool SPLIT, int NTHR = 256>
 int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
-  using TS = typename TileSel<SPLIT, BM, BN>::type;
+  using TS = typename std::conditional<NTHR == 256, typename TileSel<SPLIT, BM, BN>::type, TileShapeS<BM, BN, NTHR / 128>>::type;
   constexpr size_t shm = (size_t)TS::SMEM_FLOATS * sizeof(float);
-  auto* fn = gemm_kernel<BM, BN, AMAJ, BMAJ, VEC4, GATHER, SPLIT>;
+  auto* fn = gemm_kernel<BM, BN, AMAJ, BMAJ, VEC4, GATHER, SPLIT, NTHR>;
   if constexpr (shm > 65536) {
     static const hipError_t attr = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (attr != hipSuccess) return EGNN_ELAUNCH;
   }
-  hipLaunchKernelGGL(fn, grid, dim3(256), shm, st, g);
+  hipLaunchKernelGGL(fn, grid, dim3(NTHR), shm, st, g);
   return EGNN_OK;
+}
+
+// 8-wave 256 x 128 tiles: lab switch EGNN_GEMM_TILE=256 (default 128)
+bool wide_tile() {
+  static const bool on = getenv("EGNN_GEMM_TILE") && atoi(getenv("EGNN_GEMM_TILE")) == 256;
+  return on;
 }
 
 template <int BM, int BN, int AMAJ, int BMAJ, int GATHER = 0>
@@ -252,6 +263,14 @@ int launch_tile(const GemmArgs& g, bool vec4, hipStream_t st) {
   const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   if (tiles > 0x7fffffffLL) return EGNN_EINVAL;
   dim3 grid((unsigned)tiles, (unsigned)g.split_k);
+  if constexpr (BM == 128 && BN == 128) {
+    if (g.split_pipe && wide_tile() && g.M >= 1024) {
+      const int64_t tiles8 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
+      dim3 grid8((unsigned)tiles8, (unsigned)g.split_k);
+      return vec4 ? launch_one<256, 128, AMAJ, BMAJ, true, GATHER, true, 512>(g, grid8, st)
+                  : launch_one<256, 128, AMAJ, BMAJ, false, GATHER, true, 512>(g, grid8, st);
+    }
+  }
   if constexpr (BM % 128 == 0 && BN % 128 == 0) {
     if (g.split_pipe) {
       return vec4 ? launch_one<BM, BN, AMAJ, BMAJ, true, GATHER, true>(g, grid, st)

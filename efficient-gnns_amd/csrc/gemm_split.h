@@ -54,22 +54,38 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& p0, u32x4& p1
 }
 
 // Stages one operand tile of R rows x 16 k: global (fp32) -> registers -> three bf16 planes in LDS.
-template <int R, int MAJOR, bool VEC4, class XF, bool GATHER = false>
+// NTHR = threads of the workgroup (256: 4 waves; 512: the 8-wave 256 x 128 tile).  An operand with fewer than NTHR
+// (row, chunk) items is staged by the first waves only (wave-uniform).
+template <int R, int MAJOR, bool VEC4, class XF, bool GATHER = false, int NTHR = 256>
 struct StagerS {
   static_assert(R % 128 == 0, "split tiles are multiples of 128 rows");
-  static constexpr int NC = R / 128;   // (row, 8-k chunk) items per thread per k-step
+  static constexpr int ITEMS = 2 * R;                                  // (row, 8-k chunk) items per k-step
+  static constexpr int NC = ITEMS >= NTHR ? ITEMS / NTHR : 1;          // items per (active) thread
+  static constexpr bool PARTIAL = ITEMS < NTHR;                        // only threads < ITEMS take part
   float v[NC][8];
+
+  // item i of thread t -> (row inside the tile, chunk)
+  static __device__ __forceinline__ int item_row(int t, int i) {
+    if constexpr (MAJOR == KMAJOR) return (t >> 1) + (NTHR / 2) * i;
+    else return (t + NTHR * i) % R;
+  }
+  static __device__ __forceinline__ int item_chunk(int t, int i) {
+    if constexpr (MAJOR == KMAJOR) return t & 1;
+    else return ((t + NTHR * i) / R) & 1;
+  }
+  static __device__ __forceinline__ bool active(int t) { return !PARTIAL || t < ITEMS; }
 
   template <bool FULL>
   __device__ __forceinline__ void load_impl(const float* __restrict__ p, int64_t ld, int64_t r0, int64_t rmax, int64_t k0,
                                             int64_t kmax, const XF& xf, const int64_t* __restrict__ ridx) {
     const int t = threadIdx.x;
+    if (!active(t)) return;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       if constexpr (MAJOR == KMAJOR) {
-        int64_t r = r0 + (t >> 1) + 128 * i;
+        int64_t r = r0 + item_row(t, i);
         if (FULL && r >= rmax) r = rmax - 1;   // FULL = whole k-steps, no per-element guards: rows past the edge re-read the last row (never stored)
-        const int64_t k = k0 + (t & 1) * 8;
+        const int64_t k = k0 + item_chunk(t, i) * 8;
         int64_t rs = r;
         if constexpr (GATHER) rs = (FULL || r < rmax) ? ridx[r] : 0;
         const float* q = p + rs * ld + k;
@@ -89,9 +105,9 @@ struct StagerS {
           for (int j = 0; j < 8; ++j) v[i][j] = (r < rmax && k + j < kmax) ? xf(q[j], r, k + j) : 0.f;
         }
       } else {
-        int64_t r = r0 + (t & 127) + 128 * i;
+        int64_t r = r0 + item_row(t, i);
         if (FULL && r >= rmax) r = rmax - 1;
-        const int64_t k = k0 + (t >> 7) * 8;
+        const int64_t k = k0 + item_chunk(t, i) * 8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           int64_t ks = k + j;
@@ -118,10 +134,11 @@ struct StagerS {
   // LDS image: [3][R][S_ROW bytes]; chunk g of a row sits at byte 16 g
   __device__ __forceinline__ void store(char* lds) const {
     const int t = threadIdx.x;
+    if (!active(t)) return;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
-      const int row = (MAJOR == KMAJOR ? (t >> 1) : (t & 127)) + 128 * i;
-      const int g = MAJOR == KMAJOR ? (t & 1) : (t >> 7);
+      const int row = item_row(t, i);
+      const int g = item_chunk(t, i);
       u32x4 p0, p1, p2;
       split8(v[i], p0, p1, p2);
       char* d = lds + row * S_ROW + g * 16;
@@ -132,9 +149,9 @@ struct StagerS {
   }
 };
 
-template <int BM, int BN>
+template <int BM, int BN, int WAVES_M = 2>
 struct TileShapeS {
-  static constexpr int WM = BM / 2, WN = BN / 2;
+  static constexpr int WM = BM / WAVES_M, WN = BN / 2;   // waves WAVES_M x 2
   static constexpr int TM = WM / 32, TN = WN / 32;
   static constexpr int A_BUF = 3 * BM * S_ROW, B_BUF = 3 * BN * S_ROW;   // bytes per buffer
   static constexpr int SMEM_BYTES = 2 * (A_BUF + B_BUF);
@@ -154,13 +171,13 @@ struct TileShapeS {
 // D steps earlier) and the loads of stage kt + 1 + D are issued into the registers it frees.  Slots are compile-time
 // (the drivers unroll by lcm(D, 2)), so the ring lives in registers and the compiler's vmcnt counts stay exact.
 template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY, class XFA, class XFB, bool GA = false, bool GB = false,
-          int D = EGNN_SPLIT_DEPTH>
+          int D = EGNN_SPLIT_DEPTH, int NTHR = 256>
 struct PipelineS {
-  using TS = TileShapeS<BM, BN>;
+  using TS = TileShapeS<BM, BN, NTHR / 128>;
   static constexpr int DEPTH = D, UNROLL = (D % 2 == 0) ? D : 2 * D;
   static constexpr int B_OFF = 2 * TS::A_BUF;
-  StagerS<BM, AMAJ, VEC4, XFA, GA> sa[D];
-  StagerS<BN, BMAJ, VEC4, XFB, GB> sb[D];
+  StagerS<BM, AMAJ, VEC4, XFA, GA, NTHR> sa[D];
+  StagerS<BN, BMAJ, VEC4, XFB, GB, NTHR> sb[D];
   const float* __restrict__ A;
   const float* __restrict__ B;
   int64_t lda, ldb, M, N, kend;
@@ -227,13 +244,13 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // acc += A[m0:m0+BM, kbeg:kend] * B[kbeg:kend, n0:n0+BN] on the split pipeline (all 256 threads call with equal bounds)
-template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY = false, bool GA = false, bool GB = false, class XFA, class XFB,
-          int TM_, int TN_>
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, bool FULLONLY = false, bool GA = false, bool GB = false, int NTHR = 256,
+          class XFA, class XFB, int TM_, int TN_>
 __device__ __forceinline__ void mainloop_split(f32x16 (&acc)[TM_][TN_], const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
                                                const float* __restrict__ B, int64_t ldb, int64_t n0, int64_t N, int64_t kbeg,
                                                int64_t kend, const XFA& xfa, const XFB& xfb, float* smem,
                                                const int64_t* arows = nullptr, const int64_t* brows = nullptr) {
-  using P = PipelineS<BM, BN, AMAJ, BMAJ, VEC4, FULLONLY, XFA, XFB, GA, GB>;
+  using P = PipelineS<BM, BN, AMAJ, BMAJ, VEC4, FULLONLY, XFA, XFB, GA, GB, EGNN_SPLIT_DEPTH, NTHR>;
   P pipe(A, lda, M, B, ldb, N, kend, xfa, xfb);
   pipe.arows = arows;
   pipe.brows = brows;

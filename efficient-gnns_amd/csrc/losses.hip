@@ -9,14 +9,30 @@ namespace {
 constexpr int kRowsPerBlock = 4;     // one wave per row
 constexpr int kMaxBlocks = 1024;     // partial sums per launch (fixed => deterministic finalize)
 
-// log-sum-exp of (x * s) over a row distributed lane-strided; returns lse, every lane gets it
-__device__ __forceinline__ float row_lse(const float* p, int64_t C, float s, int lane) {
+// A row is walked by a sub-group of SUB lanes (64: one row per wave; 16: four rows per wave -- class counts <= 64, where a
+// whole wave per 40-column row left the kernels latency-bound: 37 + 32 us for 90 941 x 40).
+template <int SUB>
+__device__ __forceinline__ float sub_max(float v) {
+#pragma unroll
+  for (int o = SUB / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+template <int SUB>
+__device__ __forceinline__ float sub_sum(float v) {
+#pragma unroll
+  for (int o = SUB / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// log-sum-exp of (x * s) over a row distributed lane-strided over the sub-group; every lane of the sub-group gets it
+template <int SUB>
+__device__ __forceinline__ float row_lse(const float* p, int64_t C, float s, int sl) {
   float m = -INFINITY;
-  for (int64_t c = lane; c < C; c += 64) m = fmaxf(m, p[c] * s);
-  m = egnn_wave_max(m);
+  for (int64_t c = sl; c < C; c += SUB) m = fmaxf(m, p[c] * s);
+  m = sub_max<SUB>(m);
   float z = 0.f;
-  for (int64_t c = lane; c < C; c += 64) z += expf(p[c] * s - m);
-  z = egnn_wave_sum(z);
+  for (int64_t c = sl; c < C; c += SUB) z += expf(p[c] * s - m);
+  z = sub_sum<SUB>(z);
   return m + logf(z);
 }
 
@@ -24,36 +40,46 @@ __device__ __forceinline__ float row_lse(const float* p, int64_t C, float s, int
 // `out[train_idx]`, `y[train_idx]`, `teacher_logits[train_idx]` gathers of train() (gnn.py:107-116) happen in the operand
 // loads.  A label outside [0, C) is IGNORED (F.cross_entropy's ignore_index = -100 semantics: no loss, no gradient, not
 // counted in the mean) instead of being used as an address.
+template <int SUB>
 __global__ __launch_bounds__(256) void ce_kd_fwd_kernel(const float* __restrict__ logits, int64_t ldl,
                                                         const float* __restrict__ teacher, int64_t ldt,
                                                         const int64_t* __restrict__ labels, const int64_t* __restrict__ rows,
                                                         int64_t n, int64_t C, float T, float* __restrict__ partials) {
+  constexpr int RPW = 64 / SUB;   // rows per wave
   __shared__ float s_ce[kRowsPerBlock], s_kd[kRowsPerBlock], s_nv[kRowsPerBlock];
   const int lane = egnn_lane();
   const int wave = egnn_wave_id();
+  const int sl = lane % SUB, sg = lane / SUB;
   const float invT = 1.f / T;
-  float ce = 0.f, kd = 0.f, nv = 0.f;  // lane 0 of each wave carries the wave's running sums
-  for (int64_t i = blockIdx.x * (int64_t)kRowsPerBlock + wave; i < n; i += (int64_t)gridDim.x * kRowsPerBlock) {
-    const int64_t row = rows ? rows[i] : i;
+  float ce = 0.f, kd = 0.f, nv = 0.f;  // lane 0 of each sub-group carries its running sums
+  for (int64_t i0 = (blockIdx.x * (int64_t)kRowsPerBlock + wave) * RPW; i0 < n; i0 += (int64_t)gridDim.x * kRowsPerBlock * RPW) {
+    const int64_t i = i0 + sg;
+    const bool live = i < n;
+    const int64_t row = live ? (rows ? rows[i] : i) : 0;
     const float* lp = logits + row * ldl;
-    const float lse1 = row_lse(lp, C, 1.f, lane);
-    const int64_t y = labels[row];
+    const float lse1 = row_lse<SUB>(lp, live ? C : 0, 1.f, sl);
+    const int64_t y = live ? labels[row] : -1;
     const bool valid = y >= 0 && y < C;
-    if (lane == 0 && valid) { ce += lse1 - lp[y]; nv += 1.f; }
+    if (sl == 0 && valid) { ce += lse1 - lp[y]; nv += 1.f; }
     if (teacher != nullptr) {
       const float* tp = teacher + row * ldt;
-      const float lseq = row_lse(lp, C, invT, lane);
-      const float lsep = row_lse(tp, C, invT, lane);
+      const float lseq = row_lse<SUB>(lp, live ? C : 0, invT, sl);
+      const float lsep = row_lse<SUB>(tp, live ? C : 0, invT, sl);
       float acc = 0.f;
-      for (int64_t c = lane; c < C; c += 64) {
+      for (int64_t c = sl; c < (live ? C : 0); c += SUB) {
         const float logp = tp[c] * invT - lsep;
         const float logq = lp[c] * invT - lseq;
         const float p = expf(logp);
         acc += p > 0.f ? p * (logp - logq) : 0.f;  // F.kl_div: 0 where target == 0
       }
-      acc = egnn_wave_sum(acc);
-      if (lane == 0) kd += acc;
+      acc = sub_sum<SUB>(acc);
+      if (sl == 0) kd += acc;
     }
+  }
+  if constexpr (RPW > 1) {   // the sub-group leaders of the wave, fixed order
+    ce = egnn_wave_sum(sl == 0 ? ce : 0.f);
+    kd = egnn_wave_sum(sl == 0 ? kd : 0.f);
+    nv = egnn_wave_sum(sl == 0 ? nv : 0.f);
   }
   if (lane == 0) { s_ce[wave] = ce; s_kd[wave] = kd; s_nv[wave] = nv; }
   __syncthreads();
@@ -86,31 +112,37 @@ __global__ __launch_bounds__(256) void ce_kd_finalize_kernel(const float* __rest
   }
 }
 
+template <int SUB>
 __global__ __launch_bounds__(256) void ce_kd_bwd_kernel(const float* __restrict__ logits, int64_t ldl,
                                                         const float* __restrict__ teacher, int64_t ldt,
                                                         const int64_t* __restrict__ labels, const int64_t* __restrict__ rows,
                                                         int64_t n, int64_t C, float T, const float* __restrict__ out3,
                                                         const float* __restrict__ g_cls, const float* __restrict__ g_kd,
                                                         float* __restrict__ dl, int64_t ldd) {
+  constexpr int RPW = 64 / SUB;
   const int lane = egnn_lane();
   const int wave = egnn_wave_id();
+  const int sl = lane % SUB, sg = lane / SUB;
   const float invT = 1.f / T;
   const float gc = g_cls ? g_cls[0] / out3[2] : 0.f;
   const float gk = (g_kd && teacher) ? g_kd[0] * invT / ((float)n * (float)C) : 0.f;
-  for (int64_t i = blockIdx.x * (int64_t)kRowsPerBlock + wave; i < n; i += (int64_t)gridDim.x * kRowsPerBlock) {
-    const int64_t row = rows ? rows[i] : i;
+  for (int64_t i0 = (blockIdx.x * (int64_t)kRowsPerBlock + wave) * RPW; i0 < n; i0 += (int64_t)gridDim.x * kRowsPerBlock * RPW) {
+    const int64_t i = i0 + sg;
+    const bool live = i < n;
+    const int64_t row = live ? (rows ? rows[i] : i) : 0;
+    const int64_t Cr = live ? C : 0;
     const float* lp = logits + row * ldl;
-    const float lse1 = row_lse(lp, C, 1.f, lane);
-    const int64_t y = labels[row];
+    const float lse1 = row_lse<SUB>(lp, Cr, 1.f, sl);
+    const int64_t y = live ? labels[row] : -1;
     const float gcr = (y >= 0 && y < C) ? gc : 0.f;
     float lseq = 0.f, lsep = 0.f;
     const float* tp = nullptr;
     if (gk != 0.f) {
       tp = teacher + row * ldt;
-      lseq = row_lse(lp, C, invT, lane);
-      lsep = row_lse(tp, C, invT, lane);
+      lseq = row_lse<SUB>(lp, Cr, invT, sl);
+      lsep = row_lse<SUB>(tp, Cr, invT, sl);
     }
-    for (int64_t c = lane; c < C; c += 64) {
+    for (int64_t c = sl; c < Cr; c += SUB) {
       float g = gcr * (expf(lp[c] - lse1) - (c == y ? 1.f : 0.f));
       if (gk != 0.f) g += gk * (expf(lp[c] * invT - lseq) - expf(tp[c] * invT - lsep));
       dl[row * ldd + c] = g;
@@ -168,10 +200,12 @@ extern "C" int egnn_ce_kd_fwd_f32(const float* logits, int64_t ld_logits, const 
                                   float* partials, void* stream) {
   EGNN_CHECK_ARG(n > 0 && C > 0 && logits && labels && out3 && partials && ld_logits >= C && T > 0.f);
   EGNN_CHECK_ARG(teacher == nullptr || ld_teacher >= C);
-  const int64_t want = (n + kRowsPerBlock - 1) / kRowsPerBlock;
+  const int rpb = kRowsPerBlock * (C <= 64 ? 4 : 1);   // rows per block-iteration
+  const int64_t want = (n + rpb - 1) / rpb;
   const int nblocks = (int)(want < kMaxBlocks ? want : kMaxBlocks);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ce_kd_fwd_kernel, dim3(nblocks), dim3(256), 0, st, logits, ld_logits, teacher, ld_teacher, labels, rows, n, C, T, partials);
+  if (C <= 64) hipLaunchKernelGGL(ce_kd_fwd_kernel<16>, dim3(nblocks), dim3(256), 0, st, logits, ld_logits, teacher, ld_teacher, labels, rows, n, C, T, partials);
+  else hipLaunchKernelGGL(ce_kd_fwd_kernel<64>, dim3(nblocks), dim3(256), 0, st, logits, ld_logits, teacher, ld_teacher, labels, rows, n, C, T, partials);
   hipLaunchKernelGGL(ce_kd_finalize_kernel, dim3(1), dim3(256), 0, st, partials, nblocks, n, C, teacher != nullptr, out3);
   return egnn_launch_status();
 }
@@ -190,10 +224,13 @@ extern "C" int egnn_ce_kd_bwd_f32(const float* logits, int64_t ld_logits, const 
       return EGNN_ELAUNCH;
     }
   }
-  const int64_t want = (n + kRowsPerBlock - 1) / kRowsPerBlock;
+  const int rpb = kRowsPerBlock * (C <= 64 ? 4 : 1);
+  const int64_t want = (n + rpb - 1) / rpb;
   const int nblocks = (int)(want < 4096 ? want : 4096);
-  hipLaunchKernelGGL(ce_kd_bwd_kernel, dim3(nblocks), dim3(256), 0, st, logits, ld_logits, teacher, ld_teacher,
-                     labels, rows, n, C, T, out3, g_cls, g_kd, dlogits, ld_dlogits);
+  if (C <= 64) hipLaunchKernelGGL(ce_kd_bwd_kernel<16>, dim3(nblocks), dim3(256), 0, st, logits, ld_logits, teacher, ld_teacher,
+                                  labels, rows, n, C, T, out3, g_cls, g_kd, dlogits, ld_dlogits);
+  else hipLaunchKernelGGL(ce_kd_bwd_kernel<64>, dim3(nblocks), dim3(256), 0, st, logits, ld_logits, teacher, ld_teacher,
+                          labels, rows, n, C, T, out3, g_cls, g_kd, dlogits, ld_dlogits);
   return egnn_launch_status();
 }
 
