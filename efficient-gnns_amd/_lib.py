@@ -27,7 +27,7 @@ SIGNATURES = {
     "egnn_spmm_blk_window_i32": (_i32, [_p, _p, _i64, _i32, _p, _i64, _p, _p]),
     "egnn_bn_stats_merge_ws_floats": (_sz, [_i64]),
     "egnn_bn_stats_merge_f32": (_i32, [_p, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _sz, _p]),
-    "egnn_spmm_combine_f32": (_i32, [_i64, _i64, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i64, _p, _p, _i64, _p, _i64, _p, _p]),
+    "egnn_spmm_combine_f32": (_i32, [_i64, _i64, _p, _i32, _p, _p, _i64, _i32, _p, _p, _i64, _p, _p, _i64, _p, _i64, _p, _i32, _p]),
     "egnn_spmm_csr_max_bwd_f32": (_i32, [_i64, _i64, _p, _i32, _p, _p, _p, _i64, _p, _i64, _p]),
     "egnn_spmm_algorithmic_bytes": (_i64, [_i64, _i64, _i64, _i64, _i32, _i32]),
     "egnn_csr_from_coo_ws_bytes": (_sz, [_i64, _i64, _i32]),
@@ -41,6 +41,8 @@ SIGNATURES = {
     "egnn_gcn_norm_values_i64": (_i32, [_p, _p, _i64, _p, _p, _p]),
     "egnn_gemm_ws_floats": (_sz, [_i32, _i32, _i64, _i64, _i64, _i32]),
     "egnn_gemm_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _p]),
+    "egnn_gemm_ex_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _i32, _p]),
+    "egnn_bn_fold_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _f32, _p, _i64, _p, _p]),
     "egnn_gemm_rows_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _p, _i64, _p, _p, _p, _i64, _i32, _p, _sz, _p]),
     "egnn_ce_kd_ws_floats": (_sz, [_i64]),
     "egnn_ce_kd_fwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _f32, _p, _p, _p]),
@@ -103,7 +105,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.egnn_abi_version() != 3:
+    if lib.egnn_abi_version() != 4:
         raise HipExtensionError("libegnn_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -47,6 +47,7 @@ struct GemmArgs {
   int wide_store;          // output rows 16-byte aligned: epilogue through LDS with 16-byte stores
   int split_pipe;          // 1: products on the bf16 pipe (three-way operand split, gemm_split.h); 0: f32-input MFMA
   const u32x4* planes;     // pre-split B (gemm_split.h, "planes" form) or null
+  int relu;                // C = max(alpha A B + bias, 0)
 };
 
 // epilogue of one output tile (or of one split-K partial)
@@ -68,7 +69,10 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TM_][TN_], const 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < g.M) out[row * ldo + c] = alpha * acc[tm][tn][r] + bv;
+        if (row < g.M) {
+          const float v = alpha * acc[tm][tn][r] + bv;
+          out[row * ldo + c] = (g.relu && !partial) ? fmaxf(v, 0.f) : v;
+        }
       }
     }
   }
@@ -98,7 +102,10 @@ __device__ __forceinline__ void store_tile_wide(const f32x16 (&acc)[TM_][TN_], c
       const int64_t c = n0 + wn * WN + tn * 32 + (lane & 31);
       const float bv = (!partial && g.bias && c < g.N) ? g.bias[c] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sm[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LD + tn * 32 + (lane & 31)] = alpha * acc[tm][tn][r] + bv;
+      for (int r = 0; r < 16; ++r) {
+        const float v = alpha * acc[tm][tn][r] + bv;
+        sm[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LD + tn * 32 + (lane & 31)] = (g.relu && !partial) ? fmaxf(v, 0.f) : v;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the wave's LDS stores are ordered before its loads (other lanes' data)
     __builtin_amdgcn_wave_barrier();
@@ -204,7 +211,10 @@ __global__ __launch_bounds__(256, 2) void gemm_pb_kernel(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < g.M) out[row * ldo + c] = alpha * acc[tm][r] + bv;
+        if (row < g.M) {
+          const float v = alpha * acc[tm][r] + bv;
+          out[row * ldo + c] = (g.relu && !partial) ? fmaxf(v, 0.f) : v;
+        }
       }
   }
 }
@@ -235,7 +245,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
     float s = 0.f;
     for (int k = 0; k < g.split_k; ++k) s += g.ws[(int64_t)k * total + t];  // fixed order
     const int64_t row = t / g.N, c = t % g.N;
-    g.C[row * g.ldc + c] = alpha * s + (g.bias ? g.bias[c] : 0.f);
+    const float v = alpha * s + (g.bias ? g.bias[c] : 0.f);
+    g.C[row * g.ldc + c] = g.relu ? fmaxf(v, 0.f) : v;
   }
 }
 
@@ -292,7 +303,7 @@ int launch_major(const GemmArgs& g, bool vec4, hipStream_t st) {
 
 static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
                      const int64_t* a_rows, const float* B, int64_t ldb, const int64_t* b_rows, const float* bias, float* C,
-                     int64_t ldc, int split_k, float* ws, size_t ws_bytes, void* stream) {
+                     int64_t ldc, int split_k, float* ws, size_t ws_bytes, void* stream, int flags = 0) {
   EGNN_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
   if (M == 0 || N == 0) return EGNN_OK;
   EGNN_CHECK_ARG(A && B && C && ldc >= N);
@@ -300,7 +311,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   // fused row gathers: rows of an [M,K]-stored A (the operand of x[idx] @ W^T) or of a [K,N]-stored B (dW = dY^T x[idx])
   EGNN_CHECK_ARG(!(a_rows && b_rows) && !(a_rows && trans_a) && !(b_rows && trans_b));
   hipStream_t st0 = (hipStream_t)stream;
-  if (!a_rows && !b_rows) {   // class-count-wide shapes: dedicated HBM-bound kernels (gemm_skinny.hip); rc 1 = shape not taken
+  if (!a_rows && !b_rows && flags == 0) {   // class-count-wide shapes: dedicated HBM-bound kernels (gemm_skinny.hip); rc 1 = shape not taken
     const int kind = skinny_kind(trans_a, trans_b, M, N, K, bias != nullptr);
     int rc = 1;
     if (kind == 1) rc = egnn_skinny_fwd(A, lda, B, ldb, trans_b, bias, C, ldc, M, N, K, alpha, st0);
@@ -320,7 +331,7 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   GemmArgs g{M, N, K, A, lda, B, ldb, bias, C, ldc, alpha, nullptr, split_k,
              ((ksteps + split_k - 1) / split_k) * BK, ws, a_rows ? a_rows : b_rows, (wide && !narrow_forced) ? 1 : 0,
              gemm_split_pipe() ? 1 : 0,
-             nullptr};
+             nullptr, (flags & 1) ? 1 : 0};
   hipStream_t st = (hipStream_t)stream;
   const bool vec4 = (lda % 4 == 0) && (ldb % 4 == 0) && egnn_aligned16(A) && egnn_aligned16(B);
   const int amaj = trans_a ? MNMAJOR : KMAJOR;   // A stored [K,M] when transposed
@@ -367,6 +378,12 @@ extern "C" int egnn_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int
                              int64_t lda, const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc,
                              int split_k, float* ws, size_t ws_bytes, void* stream) {
   return gemm_impl(trans_a, trans_b, M, N, K, alpha, A, lda, nullptr, B, ldb, nullptr, bias, C, ldc, split_k, ws, ws_bytes, stream);
+}
+
+extern "C" int egnn_gemm_ex_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                                const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc, int split_k, float* ws,
+                                size_t ws_bytes, int flags, void* stream) {
+  return gemm_impl(trans_a, trans_b, M, N, K, alpha, A, lda, nullptr, B, ldb, nullptr, bias, C, ldc, split_k, ws, ws_bytes, stream, flags);
 }
 
 extern "C" int egnn_gemm_rows_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A,

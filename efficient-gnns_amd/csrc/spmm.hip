@@ -42,6 +42,7 @@ struct SpmmArgs {
   float* stat_part;         // combine kernel only: [*, 2, K] rows stat_base + i receive (y - shift), (y - shift)^2 of combined row i
   const float* stat_shift;  // [K] nullable
   int64_t stat_base;
+  int relu;                 // combine kernel only: max(y, 0) on the way out (eval-mode BatchNorm folded into the weights + ReLU)
   int logG;      // lanes per neighbour = 1 << logG
   int NS;        // number of column slices
   int map_mode;  // 0: slice = b % NS ; 1: NS divides 8 ; 2: NS multiple of 8
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(const SpmmArgs<IdxT> 
       if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + cv * 4);
       float4 y = make_float4(s.x * inv + b.x, s.y * inv + b.y, s.z * inv + b.z, s.w * inv + b.w);
       if (a.addend) { const float4 ad = *reinterpret_cast<const float4*>(a.addend + row * a.ld_add + cv * 4); y.x += ad.x; y.y += ad.y; y.z += ad.z; y.w += ad.w; }
+      if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
       *reinterpret_cast<float4*>(a.Y + row * a.ldy + cv * 4) = y;
       if (a.stat_part) {   // BatchNorm statistics of the aggregation epilogue: a hub row is one partial row of its own
         float4 sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -629,7 +631,7 @@ extern "C" int egnn_spmm_csr_seg_f32(int64_t n_rows, int64_t n_src, int64_t K, c
 extern "C" int egnn_spmm_combine_f32(int64_t n_rows, int64_t K, const void* rowptr, int index_bits, const float* bias, float* Y,
                                      int64_t ldy, int reduce, const int64_t* comb_rows, const int64_t* comb_ptr, int64_t n_comb,
                                      const float* partial, const float* addend, int64_t ld_addend, float* stat_part, int64_t stat_base,
-                                     const float* stat_shift, void* stream) {
+                                     const float* stat_shift, int flags, void* stream) {
   EGNN_CHECK_ARG(n_rows >= 0 && K >= 0 && ldy >= K && n_comb >= 0 && stat_base >= 0);
   EGNN_CHECK_ARG(index_bits == 32 || index_bits == 64);
   EGNN_CHECK_ARG(reduce == EGNN_SUM || reduce == EGNN_MEAN);
@@ -644,11 +646,11 @@ extern "C" int egnn_spmm_combine_f32(int64_t n_rows, int64_t K, const void* rowp
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (index_bits == 32) {
     SpmmArgs<int32_t> a{n_rows, K, (const int32_t*)rowptr, nullptr, nullptr, nullptr, bias, nullptr, 0, Y, ldy, reduce == EGNN_MEAN, nullptr,
-                        nullptr, 0, nullptr, const_cast<float*>(partial), addend, ld_addend, stat_part, stat_shift, stat_base, 0, 0, 0};
+                        nullptr, 0, nullptr, const_cast<float*>(partial), addend, ld_addend, stat_part, stat_shift, stat_base, (flags & 8) ? 1 : 0, 0, 0, 0};
     hipLaunchKernelGGL((spmm_combine_kernel<int32_t>), dim3((unsigned)n_comb), dim3(256), 0, st, a, comb_rows, comb_ptr, kvp_log);
   } else {
     SpmmArgs<int64_t> a{n_rows, K, (const int64_t*)rowptr, nullptr, nullptr, nullptr, bias, nullptr, 0, Y, ldy, reduce == EGNN_MEAN, nullptr,
-                        nullptr, 0, nullptr, const_cast<float*>(partial), addend, ld_addend, stat_part, stat_shift, stat_base, 0, 0, 0};
+                        nullptr, 0, nullptr, const_cast<float*>(partial), addend, ld_addend, stat_part, stat_shift, stat_base, (flags & 8) ? 1 : 0, 0, 0, 0};
     hipLaunchKernelGGL((spmm_combine_kernel<int64_t>), dim3((unsigned)n_comb), dim3(256), 0, st, a, comb_rows, comb_ptr, kvp_log);
   }
   return egnn_launch_status();

@@ -61,6 +61,7 @@ struct BlkArgs {
 
 constexpr int kFlagStoreNt = 2;     // Y rows: non-temporal stores
 constexpr int kFlagStoreSc1 = 4;    // Y rows: write-through (sc1) stores, line dropped from L2
+constexpr int kFlagRelu = 8;        // Y rows: max(y, 0) on the way out (eval-mode BatchNorm folded into weights / bias + ReLU); not with stat_part
 constexpr uint32_t kOob = 0x80000000u;   // >= num_records of any descriptor built here (X is < 2^31 bytes): reads return 0
 
 // broadcast lane (8*g + J) of every 8-lane group g to the lanes of that group: ds_swizzle in bit-mask mode
@@ -147,13 +148,14 @@ __device__ __forceinline__ void lds_chunk(const float4* sX, uint32_t idx_l, floa
 }
 
 __device__ __forceinline__ void store_row4(float* p, const float4& v, int flags) {
-  const v4f w = {v.x, v.y, v.z, v.w};
+  v4f w = {v.x, v.y, v.z, v.w};
+  if (flags & kFlagRelu) w = v4f{fmaxf(w.x, 0.f), fmaxf(w.y, 0.f), fmaxf(w.z, 0.f), fmaxf(w.w, 0.f)};
   if (flags & kFlagStoreSc1) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");   // s_nop: store-data hazard the assembler does not see
   } else if (flags & kFlagStoreNt) {
     asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
   } else {
-    *reinterpret_cast<float4*>(p) = v;
+    *reinterpret_cast<float4*>(p) = make_float4(w.x, w.y, w.z, w.w);
   }
 }
 

@@ -19,6 +19,9 @@ from .nn import DGLGATConv, GATConv, GCNConv, RGCNConv, SAGEConv
 from .sparse import SparseTensor
 
 
+_EVAL_BN_FOLD = os.environ.get("EGNN_EVAL_BN_FOLD", "1") == "1"   # A/B switch of the eval-mode BatchNorm fold
+
+
 class _Student(nn.Module):
     def __init__(self, make_conv, in_channels, hidden_channels, out_channels, num_layers, dropout):
         super().__init__()
@@ -34,6 +37,11 @@ class _Student(nn.Module):
 
     def forward(self, x, adj_t):
         for conv, bn in zip(self.convs[:-1], self.bns):
+            if (_EVAL_BN_FOLD and not self.training and not torch.is_grad_enabled() and isinstance(conv, GCNConv) and type(bn) is nn.BatchNorm1d
+                    and bn.track_running_stats and x.is_cuda and isinstance(adj_t, SparseTensor) and not conv._uses_memoised_input(x)):
+                # test(): BatchNorm on running statistics folded into the conv's weights, ReLU in the last kernel's store
+                x = self.out_feat = conv(x, adj_t, eval_bn=bn)
+                continue
             if (isinstance(conv, GCNConv) and isinstance(bn, nn.BatchNorm1d) and x.is_cuda and self.training
                     and isinstance(adj_t, SparseTensor)):
                 # BatchNorm follows (gnn.py:47-48): its batch statistics come out of the aggregation's store epilogue

@@ -96,12 +96,28 @@ class GCNConv(nn.Module):
         self._cached_adj_t = None
         self._cached_ax = None
 
-    def forward(self, x: Tensor, edge_index, edge_weight=None, bn_stats_shift: Tensor | None = None, want_bn_stats: bool = False) -> Tensor:
+    def forward(self, x: Tensor, edge_index, edge_weight=None, bn_stats_shift: Tensor | None = None, want_bn_stats: bool = False,
+                eval_bn=None) -> Tensor:
         """``bn_stats_shift`` / ``want_bn_stats`` (extension, off by default): the caller applies a BatchNorm to the result next
-        and wants its column statistics formed in the aggregation's epilogue (``ops.spmm``)."""
+        and wants its column statistics formed in the aggregation's epilogue (``ops.spmm``).
+        ``eval_bn`` (extension, no autograd): an eval-mode ``BatchNorm1d`` that follows, with a ReLU behind it (gnn.py:47-49 under
+        ``model.eval()``): returns ``relu(eval_bn(conv(x)))`` with the BatchNorm folded into W / b (``ops.bn_fold``) and the ReLU
+        in the last kernel's store -- the separate normalisation pass disappears from ``test()``."""
         if edge_weight is not None:
             raise NotImplementedError("GCNConv with edge_weight is not used by the reference")
         agg_first = self.in_channels < self.out_channels
+        if eval_bn is not None:
+            if torch.is_grad_enabled() or eval_bn.training or not isinstance(edge_index, SparseTensor) or not x.is_cuda:
+                raise ValueError("eval_bn: inference only (no_grad, BatchNorm in eval mode, SparseTensor adjacency on the GPU)")
+            norm = self._cached_adj_t
+            if norm is None:
+                norm = gcn_norm(edge_index)
+                if self.cached:
+                    self._cached_adj_t = norm
+            w, b = ops.bn_fold(self.weight, self.bias, eval_bn)
+            if agg_first:
+                return ops.gemm_raw(ops.spmm_raw(norm, x, "sum")[0], w, False, False, b, relu=True)
+            return ops.spmm_raw(norm, ops.gemm_raw(x, w), "sum", bias=b, relu=True)[0]
         if hasattr(edge_index, "gcn_normalized"):  # node-range shard (dist.ShardedAdj): halo exchange + local rows of A^
             if agg_first:
                 return ops.matmul(edge_index.gcn_normalized().aggregate(x, "sum"), self.weight, self.bias)
@@ -134,6 +150,10 @@ class GCNConv(nn.Module):
             return ops.matmul(ops.spmm(norm, x, "sum"), self.weight, self.bias)
         return ops.spmm(norm, ops.matmul(x, self.weight), "sum", bias=self.bias,  # bias added in the kernel's store
                         bn_stats_shift=bn_stats_shift, want_bn_stats=want_bn_stats)
+
+    def _uses_memoised_input(self, x: Tensor) -> bool:
+        """True when forward() would take the opt-in memoised ``A^ x`` route for this input (EGNN_GCN_MEMOISE_AX)."""
+        return bool(self.cached and _MEMOISE_AX and not x.requires_grad and self.in_channels <= self.out_channels)
 
     def __repr__(self):
         return f"GCNConv({self.in_channels}, {self.out_channels})"

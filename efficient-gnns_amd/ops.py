@@ -46,7 +46,18 @@ class HipStatsUnavailable(RuntimeError):
 
 def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = None, use_plan: bool = True,
              bias: Tensor | None = None, out: Tensor | None = None, stat_shift: Tensor | None = None, want_stats: bool = False,
-             addend: Tensor | None = None):
+             addend: Tensor | None = None, relu: bool = False):
+    """``relu``: Y = max(REDUCE(adj, X) + bias, 0), fused into the block kernel's store (eval-mode BatchNorm folded into the
+    weights + ReLU, ``bn_fold``); on the other schedules a clamp follows."""
+    res = _spmm_raw(adj, x, reduce, src_scale, use_plan, bias, out, stat_shift, want_stats, addend, relu)
+    if relu and not getattr(res[0], "_egnn_relu_done", False):
+        res[0].clamp_(min=0)
+    return res
+
+
+def _spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = None, use_plan: bool = True,
+              bias: Tensor | None = None, out: Tensor | None = None, stat_shift: Tensor | None = None, want_stats: bool = False,
+              addend: Tensor | None = None, relu: bool = False):
     """Y = REDUCE(adj, X) on the GPU.  Returns (Y, argmax | None), or (Y, None, (mean, biased var)) with ``want_stats``.
 
     Schedules: 'blocks' (default; egnn_spmm_csr_blk_f32: one launch over hub segments + row blocks, int32 indices, then the
@@ -102,7 +113,7 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
         rows_blk = loc[0] if use_lds else BLK_ROWS
         n_blk = (n_rows + rows_blk - 1) // rows_blk
         # Y rows are stored write-through (dropped from L2: they are not re-read here and would only evict gathered X lines)
-        flags = 4
+        flags = 4 | (8 if (relu and not want_stats) else 0)
         n_stat = lib.egnn_spmm_blk_stat_rows(n_rows, rows_blk, int(use_lds)) if want_stats else 0
         n_hub = crow.numel()
         stat_part = adj._scratch("stat", (n_stat + n_hub, 2, K)) if want_stats else None   # one partial row per wave + per hub row
@@ -118,8 +129,10 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
                 _lib.check(lib.egnn_spmm_combine_f32(n_rows, K, _lib.ptr(rowptr), bits, _lib.ptr(bias), _lib.ptr(y), y.stride(0), red,
                                                      _lib.ptr(crow), _lib.ptr(cptr), n_hub, _lib.ptr(partial), _lib.ptr(addend),
                                                      0 if addend is None else addend.stride(0), _lib.ptr(stat_part), n_stat,
-                                                     _lib.ptr(stat_shift) if want_stats else None, _lib.stream()), "egnn_spmm_combine_f32")
+                                                     _lib.ptr(stat_shift) if want_stats else None, flags, _lib.stream()), "egnn_spmm_combine_f32")
             if not want_stats:
+                if flags & 8:
+                    y._egnn_relu_done = True
                 return y, None
             mean = torch.empty(K, dtype=torch.float32, device=x.device)
             var = torch.empty(K, dtype=torch.float32, device=x.device)
@@ -311,7 +324,8 @@ def pad_pitch(t: Tensor) -> Tensor:
 
 
 def gemm_raw(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False, bias: Tensor | None = None,
-             alpha: float = 1.0, split_k: int | None = None, a_rows: Tensor | None = None, b_rows: Tensor | None = None) -> Tensor:
+             alpha: float = 1.0, split_k: int | None = None, a_rows: Tensor | None = None, b_rows: Tensor | None = None,
+             relu: bool = False) -> Tensor:
     """C = alpha * op(a) @ op(b) (+ bias) via egnn_gemm_f32 / egnn_gemm_rows_f32.
 
     a_rows [M] (trans_a False): op(a) = a[a_rows];  b_rows [K] (trans_b False): b = b[b_rows] -- the gather is fused
@@ -342,17 +356,35 @@ def gemm_raw(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False,
     if nws > 0:
         ws = torch.empty(nws, dtype=torch.float32, device=a.device)
     if a_rows is None and b_rows is None:
-        rc = lib.egnn_gemm_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.ptr(a), a.stride(0), _lib.ptr(b),
-                               b.stride(0), _lib.ptr(bias), _lib.ptr(c), c.stride(0), split_k, _lib.ptr(ws),
-                               0 if ws is None else ws.numel() * 4, _lib.stream())
-        _lib.check(rc, "egnn_gemm_f32")
+        rc = lib.egnn_gemm_ex_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.ptr(a), a.stride(0), _lib.ptr(b),
+                                  b.stride(0), _lib.ptr(bias), _lib.ptr(c), c.stride(0), split_k, _lib.ptr(ws),
+                                  0 if ws is None else ws.numel() * 4, 1 if relu else 0, _lib.stream())
+        _lib.check(rc, "egnn_gemm_ex_f32")
     else:
         _lib.require_gpu(*(t for t in (a_rows, b_rows) if t is not None))
         rc = lib.egnn_gemm_rows_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.ptr(a), a.stride(0), _lib.ptr(a_rows),
                                     _lib.ptr(b), b.stride(0), _lib.ptr(b_rows), _lib.ptr(bias), _lib.ptr(c), c.stride(0), split_k,
                                     _lib.ptr(ws), 0 if ws is None else ws.numel() * 4, _lib.stream())
         _lib.check(rc, "egnn_gemm_rows_f32")
+        if relu:
+            c.clamp_(min=0)
     return c
+
+
+def bn_fold(weight: Tensor, bias: Tensor | None, bn: "torch.nn.BatchNorm1d"):
+    """(W', b') with  relu(bn_eval(x W + b)) == relu(x W' + b')  (egnn_bn_fold_f32): an eval-mode BatchNorm1d folded into the
+    [in, out] weight and the bias of the layer in front of it -- also across a (linear) aggregation between the two."""
+    _lib.require_gpu(weight, bn.running_mean)
+    w = _rowmajor(weight.detach())
+    rows, C = w.shape
+    wo = torch.empty(rows, C, dtype=torch.float32, device=w.device)
+    bo = torch.empty(C, dtype=torch.float32, device=w.device)
+    rc = _lib.load().egnn_bn_fold_f32(_lib.ptr(w), w.stride(0), rows, C, _lib.ptr(None if bias is None else bias.detach()),
+                                      _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), _lib.ptr(None if bn.weight is None else bn.weight.detach()),
+                                      _lib.ptr(None if bn.bias is None else bn.bias.detach()), float(bn.eps), _lib.ptr(wo), wo.stride(0), _lib.ptr(bo),
+                                      _lib.stream())
+    _lib.check(rc, "egnn_bn_fold_f32")
+    return wo, bo
 
 
 class _MatMul(torch.autograd.Function):

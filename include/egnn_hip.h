@@ -34,7 +34,7 @@ extern "C" {
 #define EGNN_EWORKSPACE (-3) /* caller-provided workspace too small */
 #define EGNN_EALIGN (-4)   /* pointer / leading dimension not aligned as the entry point requires */
 
-#define EGNN_ABI_VERSION 3
+#define EGNN_ABI_VERSION 4
 int egnn_abi_version(void);
 const char* egnn_error_string(int code);
 /* Number of distinct kernels-families compiled in; used by the loader's self check. */
@@ -116,7 +116,9 @@ int egnn_spmm_csr_seg_f32(int64_t n_rows, int64_t n_src, int64_t K,
  *              aggregation epilogue (gnn.py:47-48), finished by egnn_bn_stats_merge_f32 (n_blk = that row count);
  *              stat_shift: nullable [K] (any vector near the column means, e.g. BatchNorm's running_mean; exactness does
  *              not depend on it, only the conditioning of the variance)
- *   flags      bit 1: non-temporal Y stores; bit 2: write-through (sc1) Y stores (tuning knobs, results are identical) */
+ *   flags      bit 1 (2): non-temporal Y stores; bit 2 (4): write-through (sc1) Y stores (tuning knobs, results are identical);
+ *              bit 3 (8): Y = max(Y, 0) on the way out -- ReLU fused into the store (an eval-mode BatchNorm folded into the
+ *              weights / bias by egnn_bn_fold_f32 + ReLU, gnn.py:47-49 under model.eval()); not together with stat_part */
 int egnn_spmm_csr_blk_f32(int64_t n_rows, int64_t n_src, int64_t K,
                           const int32_t* rowptr, const int32_t* col, const float* val, const float* src_scale, const float* bias,
                           const float* X, int64_t ldx, float* Y, int64_t ldy, int reduce,
@@ -139,11 +141,12 @@ int egnn_bn_stats_merge_f32(const float* stat_part, int64_t n_blk, int64_t C, co
  * of row r = comb_rows[i], added in slot order) * (1 / rowcount for EGNN_MEAN) + bias (+ addend[r], nullable).  K % 4 == 0,
  * 16-byte aligned rows.
  * stat_part != NULL: row (stat_base + i) of the [*, 2, K] statistics partials receives (y - shift) and (y - shift)^2 of
- * combined row i (one partial row per hub row, folded by egnn_bn_stats_merge_f32 together with the block kernel's). */
+ * combined row i (one partial row per hub row, folded by egnn_bn_stats_merge_f32 together with the block kernel's).
+ * flags: bit 3 (8) = ReLU on the way out, as in egnn_spmm_csr_blk_f32. */
 int egnn_spmm_combine_f32(int64_t n_rows, int64_t K, const void* rowptr, int index_bits, const float* bias, float* Y, int64_t ldy,
                           int reduce, const int64_t* comb_rows, const int64_t* comb_ptr, int64_t n_comb, const float* partial,
                           const float* addend, int64_t ld_addend, float* stat_part, int64_t stat_base, const float* stat_shift,
-                          void* stream);
+                          int flags, void* stream);
 
 /* Backward of EGNN_MAX: dX[col[argmax[i,k]], k] += val * dY[i,k].  dX must be zero-filled by the
  * caller.  Uses float atomics (the only entry point that does); max-aggregation is never exercised
@@ -216,6 +219,12 @@ int egnn_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, flo
                   const float* A, int64_t lda, const float* B, int64_t ldb,
                   const float* bias, float* C, int64_t ldc,
                   int split_k, float* ws, size_t ws_bytes, void* stream);
+
+/* egnn_gemm_f32 with an epilogue option: flags bit 0 (1) = C = max(alpha op(A) op(B) + bias, 0) -- the ReLU that follows an
+ * eval-mode BatchNorm whose scale / shift were folded into B and bias (egnn_bn_fold_f32). */
+int egnn_gemm_ex_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                     const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc, int split_k, float* ws,
+                     size_t ws_bytes, int flags, void* stream);
 /* The same GEMM with a row gather fused into one operand's load, for the `feat[train_idx]` gathers in front of the
  * projection heads (/root/reference/arxiv_pyg/gnn.py:150-156: `out_feat[train_idx]`, `teacher_out_feat[train_idx]`,
  * the latter 273 MB read + written per step in the reference):
@@ -417,6 +426,13 @@ int egnn_bn_act_bwd_colsum_f32(const float* x, int64_t ld, const float* dy, int6
  * momentum < 0 = cumulative average (momentum=None); num_batches_tracked: nullable device int64. */
 int egnn_bn_running_update_f32(const float* mean, const float* var, int64_t C, int64_t n, float momentum, float* running_mean,
                                float* running_var, int64_t* num_batches_tracked, void* stream);
+
+/* Eval-mode BatchNorm1d folded into the layer in front of it (model.eval(): y = (x W + b - running_mean) * gamma /
+ * sqrt(running_var + eps) + beta, gnn.py:47-49,198-201):  W_out[i,c] = W[i,c] * s_c,  bias_out[c] = (bias[c] - mean[c]) * s_c
+ * + beta[c],  s_c = gamma[c] / sqrt(var[c] + eps).  W [rows, C] row-major (GCNConv layout [in, out]); bias / gamma / beta
+ * nullable (0 / 1 / 0).  The aggregation is linear, so the fold also holds with A^ between W and the BatchNorm. */
+int egnn_bn_fold_f32(const float* W, int64_t ldw, int64_t rows, int64_t C, const float* bias, const float* mean, const float* var,
+                     const float* gamma, const float* beta, float eps, float* W_out, int64_t ld_out, float* bias_out, void* stream);
 
 /* test() of /root/reference/arxiv_pyg/gnn.py:198-218 in one pass: acc3[k] = |{i : split_id[i] == k, argmax_c logits[i,c] == y[i]}|
  * / |{i : split_id[i] == k}| for the splits k = 0, 1, 2 (train / valid / test; any other id = not evaluated), as the ogb

@@ -510,6 +510,49 @@ def test_bias_gradient_formed_in_the_bn_backward_and_row_compact_tap():
         close(u, v, rtol=1e-6, atol_scale=1e-6)
 
 
+def test_eval_mode_batchnorm_fold_and_relu_epilogues():
+    """test() (gnn.py:198-218): the eval-mode BatchNorm folded into the conv's weights (egnn_bn_fold_f32) + ReLU in the last
+    kernel's store (GEMM / aggregation / hub-row combine) equals the unfused chain conv -> bn_act; plus the two relu
+    epilogues on their own, incl. the K < 64 aggregation (clamp after the segment kernel)."""
+    d = D.arxiv_like(scale=0.05, seed=5)
+    adj = d.adj_t.to(DEV)
+    torch.manual_seed(3)
+    model = PM.GCN(d.num_features, 64, d.num_classes, 3, 0.5).to(DEV)
+    with torch.no_grad():
+        for bn in model.bns:                      # running statistics / affine parameters away from their initial values
+            bn.running_mean.copy_(torch.randn(64, device=DEV) * 0.3)
+            bn.running_var.copy_(torch.rand(64, device=DEV) + 0.5)
+            bn.weight.copy_(torch.rand(64, device=DEV) + 0.5)
+            bn.bias.copy_(torch.randn(64, device=DEV) * 0.2)
+        for conv in model.convs:
+            conv.bias.copy_(torch.randn_like(conv.bias) * 0.1)
+    model.eval()
+    x = d.x.to(DEV)
+    outs = {}
+    for fold in (True, False):
+        PM._EVAL_BN_FOLD = fold
+        try:
+            with torch.no_grad():
+                outs[fold] = model(x, adj).clone()
+                feat = model.out_feat.clone()
+            outs[(fold, "feat")] = feat
+        finally:
+            PM._EVAL_BN_FOLD = True
+    close(outs[True], outs[False], rtol=1e-5, atol_scale=2e-6)
+    close(outs[(True, "feat")], outs[(False, "feat")], rtol=1e-5, atol_scale=2e-6)
+    assert float(outs[(True, "feat")].min()) >= 0.0
+    g = torch.Generator().manual_seed(1)
+    a, b, bias = torch.randn(3000, 96, generator=g), torch.randn(96, 200, generator=g), torch.randn(200, generator=g)
+    close(ops.gemm_raw(a.to(DEV), b.to(DEV), False, False, bias.to(DEV), relu=True), torch.relu(a.double() @ b.double() + bias.double()),
+          rtol=1e-5, atol_scale=2e-6)
+    for K in (256, 40):
+        xx = torch.randn(d.num_nodes, K, generator=g)
+        bb = torch.randn(K, generator=g)
+        y = ops.spmm_raw(adj, xx.to(DEV), "sum", bias=bb.to(DEV), relu=True)[0]
+        ref = torch.relu(ops.spmm_raw(adj, xx.to(DEV), "sum", bias=bb.to(DEV))[0])
+        assert torch.equal(y, ref), K
+
+
 def test_linear_and_matmul_autograd():
     g = torch.Generator().manual_seed(1)
     x = torch.randn(777, 128, generator=g)

@@ -239,7 +239,7 @@ int main(int argc, char** argv) {
       const int64_t n_stat = v.stats ? egnn_spmm_blk_stat_rows(n, v.R, v.lds) : 0;
       if (!sp.crow.empty())   // the hub rows: fixed-order sum of the partial slots the block kernel's launch filled
         rc = egnn_spmm_combine_f32(n, K, d_rp, 32, nullptr, d_y, K, EGNN_SUM, d_crow, d_cptr, (int64_t)sp.crow.size(), d_partial, nullptr, 0,
-                                   v.stats ? d_stat : nullptr, n_stat, v.stats ? d_shift : nullptr, st);
+                                   v.stats ? d_stat : nullptr, n_stat, v.stats ? d_shift : nullptr, 0, st);
       if (rc) return rc;
       if (v.stats)
         rc = egnn_bn_stats_merge_f32(d_stat, n_stat + (int64_t)sp.crow.size(), K, nullptr, 0, nullptr, 0, d_shift, n, d_mean, d_var, d_fold,
