@@ -453,6 +453,53 @@ class _DistNCE(torch.autograd.Function):
         return df, dt_all[off:off + Sr].contiguous(), None, None, None, None
 
 
+class _GatherSampledRows(torch.autograd.Function):
+    """This rank's sampled rows -> the [S, P] matrix of ALL ranks' sampled rows (rank blocks in order).  The consumer (GSP)
+    evaluates the full all-pairs loss on every rank -- S <= 4096 rows: milliseconds, no row-block kernel needed -- so every
+    rank holds the complete gradient of the GLOBAL loss; the backward hands back the rows of this rank's block, and the
+    gradient all-reduce of the parameters adds the ranks' row blocks up to the full gradient (no extra collective)."""
+
+    @staticmethod
+    def forward(ctx, x, counts, rank, group):
+        ctx.meta = (int(sum(counts[:rank])), x.shape[0])
+        return _all_gather_rows(x.contiguous(), counts, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        off, n = ctx.meta
+        return g[off:off + n].contiguous(), None, None, None
+
+
+class _TrainSubgraph:
+    """LSP on shards (criterion.py:95-126 over ``subgraph(train_idx, edge_index)``, gnn.py:246-250): this rank's slice of the
+    train-node subgraph = the entries (row r, column c) of its own rows with r and c both train nodes.  The softmax groups
+    (edges sharing ``dst``) are whole on the owner of ``dst``; the ``src`` features of remote train neighbours come through
+    the same halo exchange as the convs' (own plan: only train neighbours travel).  Built once per problem (collective)."""
+
+    def __init__(self, prob: "ShardedProblem", rowptr_local: Tensor, col_global: Tensor, train_global: Tensor):
+        n, world, rank, dev = prob.n, prob.world, prob.rank, prob.device
+        is_train = torch.zeros(n, dtype=torch.bool)
+        is_train[train_global] = True
+        n_local = prob.hi - prob.lo
+        rows = torch.repeat_interleave(torch.arange(n_local), rowptr_local[1:] - rowptr_local[:-1])
+        keep = is_train[rows + prob.lo] & is_train[col_global]
+        rows_k, cols_k = rows[keep], col_global[keep]
+        rp = torch.zeros(n_local + 1, dtype=torch.int64)
+        rp[1:] = torch.cumsum(torch.bincount(rows_k, minlength=n_local), 0)
+        self.sadj = ShardedAdj(rp, cols_k, n, world, rank, dev, prob.group, with_gcn=False)
+        pl = self.sadj.plan
+        # edge (src = neighbour in extended numbering, dst = the local row): groups by dst, as the reference's softmax does
+        self.edge_index = torch.stack([pl.col_ext.to(torch.int64), rows_k.to(torch.int64)]).to(dev)
+        e = torch.tensor([float(rows_k.numel())], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(e, group=prob.group)
+        self.e_local, self.e_global = int(rows_k.numel()), int(e.item())
+        self.teacher_ext = None
+
+    def extend(self, x_local: Tensor) -> Tensor:
+        return _HaloExchange.apply(x_local, self.sadj)
+
+
 # ------------------------------------------------------------------------------------------------
 # sharded problem + train / eval step
 # ------------------------------------------------------------------------------------------------
@@ -481,6 +528,8 @@ class ShardedProblem:
         rowptr, col, _ = data.adj_t.csr()
         e0, e1 = int(rowptr[lo]), int(rowptr[hi])
         self.adj = ShardedAdj((rowptr[lo:hi + 1] - e0), col[e0:e1], n, world, rank, device, group, with_gcn=need_gcn)
+        self._rows_cpu = ((rowptr[lo:hi + 1] - e0).clone(), col[e0:e1].clone(), data.split_idx["train"].clone())   # for the LSP subgraph plan
+        self._train_sub = None
         self.x = data.x[lo:hi].to(device)
         self.adj.register_static(self.x)          # input features never change: halo copy fetched once
         self.y = data.y[lo:hi].to(device)
@@ -505,6 +554,12 @@ class ShardedProblem:
             m = (idx >= lo) & (idx < hi)
             self.split_local[k] = (idx[m] - lo).to(device)
             self.split_sizes[k] = idx.numel()
+
+
+def _train_subgraph(prob: ShardedProblem) -> _TrainSubgraph:
+    if prob._train_sub is None:
+        prob._train_sub = _TrainSubgraph(prob, *prob._rows_cpu)
+    return prob._train_sub
 
 
 def allreduce_grads(params, group=None):
@@ -603,6 +658,43 @@ def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: di
         # loss_aux is already the global value on every rank: scale its gradient contribution once (1/world per rank
         # would double count the all-reduce of parameter grads), so only the local row block's graph carries grad
         loss = loss_cls + hp["beta"] * loss_aux
+    elif mode == "gpw":
+        # GSP (criterion.py:57-92): the sampled rows of all ranks are gathered and the all-pairs loss is evaluated in full on
+        # every rank (same NumPy draw everywhere; S <= 4096 in the configuration of record)
+        from . import ops_pairwise
+        loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else attached_zero
+        if hasattr(student_proj, "forward_rows") and prob.x.is_cuda:
+            f = student_proj.forward_rows(model.out_feat, prob.train_local)
+            t = teacher_proj.forward_rows(prob.teacher_out_feat, prob.train_local)
+        else:
+            f = student_proj(take(model.out_feat, prob.train_local))
+            t = teacher_proj(take(prob.teacher_out_feat, prob.train_local))
+        S = hp["max_samples"]
+        ntr = prob.n_train_global
+        pick = np.random.choice(ntr, S, replace=False) if S < ntr else np.arange(ntr)   # same draw on every rank
+        pick_t = torch.from_numpy(pick)
+        owner = prob.train_owner[pick_t]
+        counts = torch.bincount(owner, minlength=prob.world).tolist()
+        idx = prob.train_localpos[pick_t[owner == prob.rank]].to(dev)
+        fs = _GatherSampledRows.apply(f[idx], counts, prob.rank, group)
+        ts = _GatherSampledRows.apply(t[idx], counts, prob.rank, group)
+        loss_aux = ops_pairwise.gsp_loss(fs, ts, None, hp["kernel"])      # the GLOBAL value on every rank
+        loss = loss_cls + hp["beta"] * loss_aux
+    elif mode == "lpw":
+        # LSP (criterion.py:95-126): every rank owns the softmax groups of its train nodes; remote train neighbours' rows of the
+        # student's hidden state arrive by a halo exchange (autograd: reverse exchange), the teacher's once
+        from . import ops_edge
+        loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else attached_zero
+        sub = _train_subgraph(prob)
+        f_ext = sub.extend(model.out_feat)
+        if sub.teacher_ext is None:
+            with torch.no_grad():
+                sub.teacher_ext = sub.extend(prob.teacher_out_feat.contiguous())
+        if sub.e_local > 0:
+            loss_aux = ops_edge.lsp_loss(f_ext, sub.teacher_ext, sub.edge_index, hp["kernel"]) * (sub.e_local / max(sub.e_global, 1))
+        else:
+            loss_aux = f_ext.sum() * 0.0          # no edge here: an exact zero that keeps the exchange's backward in the graph
+        loss = loss_cls + hp["beta"] * loss_aux
     else:
         raise NotImplementedError(f"sharded training mode '{mode}'")
     fg = _flat_grads_of(optimizer)
@@ -610,14 +702,15 @@ def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: di
     loss.backward()
     fg.all_reduce(group)
     optimizer.step()
-    rep = torch.stack([loss_cls.detach(), loss_aux.detach() if mode != "nce" else zero, loss_aux.detach()])
-    dist.all_reduce(rep[:2], group=group)                     # loss_aux of nce is already global: not reduced
+    aux_is_global = mode in ("nce", "gpw")
+    rep = torch.stack([loss_cls.detach(), loss_aux.detach() if not aux_is_global else zero, loss_aux.detach()])
+    dist.all_reduce(rep[:2], group=group)                     # loss_aux of nce / gpw is already global: not reduced
     vals = rep.tolist()                                       # one device->host read per step
     loss_cls_g = vals[0]
-    loss_aux_g = vals[2] if mode == "nce" else vals[1]
+    loss_aux_g = vals[2] if aux_is_global else vals[1]
     if mode == "kd":
         loss_g = loss_aux_g * (hp["alpha"] * hp["kd_T"] ** 2) + loss_cls_g * (1 - hp["alpha"])
-    elif mode == "nce":
+    elif mode in ("nce", "gpw", "lpw"):
         loss_g = loss_cls_g + hp["beta"] * loss_aux_g
     else:
         loss_g = loss_cls_g

@@ -54,6 +54,18 @@ def _patch_ops_with_oracle():
         return scale * g * (p @ t_all), scale * g * (p.t() @ fhat)
     ops.nce_block_fwd, ops.nce_block_bwd = nce_block_fwd, nce_block_bwd
 
+    import efficient_gnns_amd.ops_edge as ops_edge
+    import efficient_gnns_amd.ops_pairwise as ops_pairwise
+    import oracle.criterion as OC
+
+    def lsp_loss(feat, teacher_feat, edge_index, kernel, criterion="kld"):
+        src, dst = edge_index
+        p_s = OC._segment_softmax(OC._edge_sim(feat, src, dst, kernel), dst)
+        p_t = OC._segment_softmax(OC._edge_sim(teacher_feat, src, dst, kernel), dst)
+        return F.kl_div(torch.log(p_s), p_t, log_target=False)
+    ops_edge.lsp_loss = lsp_loss
+    ops_pairwise.gsp_loss = lambda fs, ts, idx, kernel: F.mse_loss(OC._pairwise(fs, kernel), OC._pairwise(ts, kernel))
+
 
 def _make_data(seed=3, train_ids_below=None):
     import types
@@ -84,13 +96,19 @@ def _reference_run(gnn, mode, steps=3, hp=None):
     model = (OM.GCN if gnn == "gcn" else OM.SAGE)(d.num_features, 32, d.num_classes, 3, 0.0)
     sp = tp = None
     groups = [{"params": model.parameters(), "lr": 0.01}]
-    if mode == "nce":
+    if mode in ("nce", "gpw"):
         sp, tp = OM.make_projection(32, 16), OM.make_projection(750, 16)
         groups += [{"params": sp.parameters(), "lr": 0.01}, {"params": tp.parameters(), "lr": 0.01}]
     opt = torch.optim.Adam(groups)
+    edge_index = None
+    if mode == "lpw":   # gnn.py:246-250: the train-node subgraph, relabelled to train positions
+        import oracle.utils as OU
+        rowptr, col, _ = d.adj_t.csr()
+        row = torch.repeat_interleave(torch.arange(d.num_nodes), rowptr[1:] - rowptr[:-1])
+        edge_index = OU.subgraph(d.split_idx["train"], torch.stack([row, col]), relabel_nodes=True, num_nodes=d.num_nodes)[0]
     logits, accs = OM.evaluate(model, d.x, d.oracle_adj, d.y, d.split_idx)   # eval at the initial state
     losses = [OM.train_step(model, d.x, d.oracle_adj, d.y, d.split_idx["train"], opt, mode, HP, d.teacher_out_feat,
-                            d.teacher_logits, sp, tp) for _ in range(steps)]
+                            d.teacher_logits, sp, tp, edge_index) for _ in range(steps)]
     return losses, logits, accs
 
 
@@ -131,7 +149,7 @@ def _worker(rank, world, port, gnn, mode, q, hp=None):
         model = (PM.GCN if gnn == "gcn" else PM.SAGE)(d.num_features, 32, d.num_classes, 3, 0.0)
         sp = tp = None
         groups = [{"params": model.parameters(), "lr": 0.01}]
-        if mode == "nce":
+        if mode in ("nce", "gpw"):
             sp, tp = PM.make_projection(32, 16), PM.make_projection(750, 16)
             groups += [{"params": sp.parameters(), "lr": 0.01}, {"params": tp.parameters(), "lr": 0.01}]
         DD.swap_batchnorm(model)
@@ -158,13 +176,17 @@ def _worker(rank, world, port, gnn, mode, q, hp=None):
     ("gcn", "nce", 4, 5),      # 5 samples over 4 ranks: some ranks own no sampled row (empty row block, collectives still run)
     # every train node in the first 300 ids: the last rank(s) own NO train row -- their loss terms must stay attached to
     # the graph so that all ranks run the same backward collectives (no 'does not require grad', no hang)
-    ("gcn", "kd", 3, -300), ("gcn", "nce", 3, -300), ("sage", "supervised", 2, -300)])
+    ("gcn", "kd", 3, -300), ("gcn", "nce", 3, -300), ("sage", "supervised", 2, -300),
+    # GSP (all-pairs loss on the gathered sample, evaluated on every rank) and LSP (train-subgraph edges, own halo plan)
+    ("gcn", "gpw", 2, 96), ("gcn", "gpw", 3, 40), ("sage", "lpw", 2, 96), ("gcn", "lpw", 3, 96), ("gcn", "lpw", 3, -300)])
 def test_sharded_training_matches_single_process_oracle(gnn, mode, world, max_samples):
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     hp = dict(max_samples=max_samples)
     if max_samples < 0:
         hp = dict(max_samples=64, train_ids_below=-max_samples)
+    if mode in ("gpw", "lpw"):   # the weights of record (scripts/run_gcn.sh: beta = 100): the auxiliary gradient dominates the step
+        hp.update(kernel="cosine", beta=100.0)
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, gnn, mode, q, hp)) for r in range(world)]
     for p in procs:

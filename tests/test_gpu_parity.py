@@ -1013,10 +1013,11 @@ def test_nce_row_block_kernels_vs_torch(Sr, Sc, off, P, unit_rows):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gnn,mode", [("gcn", "nce"), ("sage", "kd")])
+@pytest.mark.parametrize("gnn,mode", [("gcn", "nce"), ("sage", "kd"), ("gcn", "gpw"), ("sage", "lpw")])
 def test_sharded_path_with_one_rank_over_rccl_matches_single_gpu_path(gnn, mode):
-    """The node-range sharded code (dist.py: halo plan, SyncBN, row-block G-CRD, flat gradient all-reduce) on the real
-    RCCL backend with world_size 1 must reproduce the single-GPU step; the N = 2 logic is covered on gloo."""
+    """The node-range sharded code (dist.py: halo plan, SyncBN, row-block G-CRD, gathered-sample GSP, train-subgraph LSP,
+    flat gradient all-reduce) on the real RCCL backend with world_size 1 must reproduce the single-GPU step; the
+    N = 2 / 3 / 4 logic is covered on gloo."""
     import torch.distributed as dist
     import efficient_gnns_amd.dist as DD
     created = False
@@ -1025,7 +1026,14 @@ def test_sharded_path_with_one_rank_over_rccl_matches_single_gpu_path(gnn, mode)
         created = True
     try:
         hp = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=256, kernel="rbf")
+        if mode in ("gpw", "lpw"):
+            hp.update(kernel="cosine", beta=100.0)
         d = D.arxiv_like(scale=0.02, seed=5)
+        edge_index = None
+        if mode == "lpw":   # gnn.py:246-250
+            from efficient_gnns_amd.utils import subgraph
+            edge_index = subgraph(d.split_idx["train"].to(DEV), torch.stack(d.adj_t.to(DEV).coo()[:2]), relabel_nodes=True,
+                                  num_nodes=d.num_nodes)[0]
 
         def build():
             torch.manual_seed(0)
@@ -1033,7 +1041,7 @@ def test_sharded_path_with_one_rank_over_rccl_matches_single_gpu_path(gnn, mode)
             model = (PM.GCN if gnn == "gcn" else PM.SAGE)(d.num_features, 64, d.num_classes, 3, 0.0).to(DEV)
             sp = tp = None
             groups = [{"params": model.parameters(), "lr": 0.01}]
-            if mode == "nce":
+            if mode in ("nce", "gpw"):
                 sp, tp = PM.make_projection(64, 32).to(DEV), PM.make_projection(750, 32).to(DEV)
                 groups += [{"params": sp.parameters(), "lr": 0.01}, {"params": tp.parameters(), "lr": 0.01}]
             return model, sp, tp, groups
@@ -1045,7 +1053,7 @@ def test_sharded_path_with_one_rank_over_rccl_matches_single_gpu_path(gnn, mode)
         split = {k: v.to(DEV) for k, v in d.split_idx.items()}
         ref_logits, ref_accs = PM.evaluate(model, x, adj, y, split)
         ref = [PM.train_step(model, x, adj, y, split["train"], opt, mode, hp, d.teacher_out_feat.to(DEV), d.teacher_logits.to(DEV),
-                             sp, tp) for _ in range(3)]
+                             sp, tp, edge_index) for _ in range(3)]
 
         model, sp, tp, groups = build()
         for m in (model, sp, tp):
