@@ -489,7 +489,7 @@ class _TrainSubgraph:
         self.sadj = ShardedAdj(rp, cols_k, n, world, rank, dev, prob.group, with_gcn=False)
         pl = self.sadj.plan
         # edge (src = neighbour in extended numbering, dst = the local row): groups by dst, as the reference's softmax does
-        self.edge_index = torch.stack([pl.col_ext.to(torch.int64), rows_k.to(torch.int64)]).to(dev)
+        self.edge_index = torch.stack([pl.col_ext.to(device=dev, dtype=torch.int64), rows_k.to(device=dev, dtype=torch.int64)])
         e = torch.tensor([float(rows_k.numel())], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(e, group=prob.group)
@@ -778,7 +778,7 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
     swap_batchnorm(model)
     sp = tp = None
     groups = [{"params": model.parameters(), "lr": model_cfg["lr"]}]
-    if args.training == "nce":
+    if args.training in ("nce", "gpw"):
         sp = swap_batchnorm(PM.make_projection(model_cfg["hidden"], hp["proj_dim"]).to(device))
         tp = swap_batchnorm(PM.make_projection(data.teacher_out_feat.shape[1], hp["proj_dim"]).to(device))
         groups += [{"params": sp.parameters(), "lr": model_cfg["lr"]}, {"params": tp.parameters(), "lr": model_cfg["lr"]}]

@@ -236,8 +236,9 @@ def _bench_worker(rank, world, port, path, workload="arxiv", overlap="1"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), EGNN_DIST_OVERLAP=overlap)
     _patch_ops_with_oracle()
     import efficient_gnns_amd.dist as DD
-    args = types.SimpleNamespace(seed=0, scale=0.004 if workload == "arxiv" else 0.0006, gnn="gcn", training="nce", warmup=1, steps=2,
-                                 workload=workload)
+    workload, _, training = workload.partition("-")          # "arxiv-gpw": the arxiv workload with another loss
+    args = types.SimpleNamespace(seed=0, scale=0.004 if workload == "arxiv" else 0.0006, gnn="gcn", training=training or "nce", warmup=1,
+                                 steps=2, workload=workload)
     hp = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=128, proj_dim=16, kernel="rbf")
     cfg = dict(hidden=32, layers=3 if workload == "arxiv" else 2, dropout=0.5, lr=0.01)
     lines = []
@@ -255,7 +256,8 @@ def _bench_worker(rank, world, port, path, workload="arxiv", overlap="1"):
     os._exit(0)   # see _quiet_exit
 
 
-@pytest.mark.parametrize("workload,world,overlap", [("arxiv", 2, "1"), ("arxiv", 2, "0"), ("mag", 2, "1"), ("mag", 4, "1")])
+@pytest.mark.parametrize("workload,world,overlap", [("arxiv", 2, "1"), ("arxiv", 2, "0"), ("mag", 2, "1"), ("mag", 4, "1"),
+                                                    ("arxiv-gpw", 2, "1"), ("arxiv-lpw", 2, "1")])
 def test_bench_entry_point_runs_sharded_and_prints_contract_json(tmp_path, workload, world, overlap):
     """bench.py's multi-rank entry (dist.bench_main) over gloo: the headline workload with and without the halo / compute
     overlap, and BASELINE.json configs[4] (MAG-shaped graph, SAGE-mean + logit KD) on 2 and 4 node-range shards."""
@@ -274,7 +276,7 @@ def test_bench_entry_point_runs_sharded_and_prints_contract_json(tmp_path, workl
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in out
     assert out["n_gpus"] == world and out["scaling"] == "strong" and out["value"] > 0 and "workload" in out["config"]
-    assert ("mag" in out["config"]["workload"]) == (workload == "mag")
+    assert ("mag" in out["config"]["workload"]) == (workload == "mag")   # ("arxiv-gpw" etc. are arxiv workloads)
     assert all(np.isfinite(out["last_losses"]))
 
 
