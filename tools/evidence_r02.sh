@@ -14,6 +14,7 @@ echo "== rocprof kernel stats of bench"; rm -rf /tmp/profev; (cd /tmp && timeout
 find /tmp/profev -name "*kernel_stats*" -exec cp {} $O/bench_kernel_stats.csv \; ; find /tmp/profev -name "*domain_stats*" -exec cp {} $O/bench_domain_stats.csv \;
 echo "== one eager epoch"; bash tools/epoch_kernels.sh > $O/epoch_kernels.log 2>&1; cp gpurun_out/epoch_kernels/last_epoch.txt $O/epoch_kernels.txt; head -1 $O/epoch_kernels.txt
 echo "== secondary configs"; bash tools/config_benches.sh > $O/config_benches.txt 2>&1; grep -c value $O/config_benches.txt
-echo "== sharded path, one rank over RCCL"; timeout 600 python bench.py --force-sharded --steps 10 --warmup 3 --cpu-epochs 0 2>&1 | tail -1 > $O/sharded_1rank_arxiv.json; cut -c1-200 $O/sharded_1rank_arxiv.json
-timeout 900 python bench.py --force-sharded --workload mag --steps 5 --warmup 2 --cpu-epochs 0 2>&1 | tail -1 > $O/sharded_1rank_mag.json; cut -c1-200 $O/sharded_1rank_mag.json
+echo "== sharded path, one rank over RCCL"; timeout 600 python bench.py --force-sharded --steps 10 --warmup 3 --cpu-epochs 0 2>&1 | grep "^{" | tail -1 > $O/sharded_1rank_arxiv.json; cut -c1-200 $O/sharded_1rank_arxiv.json
+timeout 900 python bench.py --force-sharded --workload mag --steps 5 --warmup 2 --cpu-epochs 0 2>&1 | grep "^{" | tail -1 > $O/sharded_1rank_mag.json; cut -c1-200 $O/sharded_1rank_mag.json
+for m in gpw lpw; do timeout 600 python bench.py --force-sharded --training $m --steps 10 --warmup 3 --cpu-epochs 0 2>&1 | grep "^{" | tail -1 > $O/sharded_1rank_arxiv_$m.json; cut -c1-200 $O/sharded_1rank_arxiv_$m.json; done
 du -sh $O
