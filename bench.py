@@ -333,6 +333,8 @@ def main():
     hp = dict(HP, max_samples=args.max_samples)
     if args.training in MODE_HP:
         hp.update(MODE_HP[args.training])
+        if args.max_samples != HP["max_samples"]:   # an explicit --max-samples wins over the mode's value of record
+            hp["max_samples"] = args.max_samples
 
     import efficient_gnns_amd  # noqa: F401  (fails loudly if libegnn_hip.so is missing)
     import efficient_gnns_amd.data as D
