@@ -471,6 +471,11 @@ def main():
         value=round(args.steps / elapsed, 3), unit="epochs/s", n_gpus=1, steps=args.steps, warmup=args.warmup,
         ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True, scaling="strong", vs_baseline=None,
         dtype="f32", data="synthetic",
+        arithmetic=("fp32 tensors, fp32 accumulation everywhere; GEMM / G-CRD products formed on the bf16 matrix pipe as the six exact "
+                    "partial products of a three-way bf16 split of each fp32 operand (error vs float64 not above the f32-input MFMA's: "
+                    "tests/test_gpu_parity.py::test_split_pipeline_error_is_not_above_the_f32_mfma_pipeline; DESIGN.md 3.2); "
+                    "EGNN_GEMM_PIPE=f32 pins them to v_mfma_f32_32x32x2_f32")
+                   if not os.environ.get("EGNN_GEMM_PIPE", "").startswith("f") else "fp32 tensors and accumulation; products on the f32-input MFMA",
         config=dict(workload=f"ogbn-arxiv-shaped synthetic graph (N={d.num_nodes}, nnz_sym={d.adj_t.nnz()}), "
                              f"3-layer {args.gnn.upper()}-256 student + {args.training}"
                              f"{' (G-CRD)' if args.training == 'nce' else ''} loss (max_samples={hp['max_samples']}, "
