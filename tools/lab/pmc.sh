@@ -4,7 +4,7 @@
 set +e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-GRAPH=$1; VAR=$2; OUT=$3; shift 3
+GRAPH=$1; VAR=$2; OUT=$(realpath -m $3); shift 3
 GROUPS_ALL="sq_time sq_inst tcp1 tcp3 tcc1 tcc2 ta"
 declare -A G
 G[sq_time]="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"
