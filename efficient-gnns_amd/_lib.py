@@ -81,6 +81,7 @@ SIGNATURES = {
     "egnn_split_accuracy_ws_ints": (_sz, []),
     "egnn_split_accuracy_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     "egnn_rows_add_f32": (_i32, [_p, _i64, _p, _p, _i64, _i64, _i64, _p]),
+    "egnn_probe_gather_lines_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i64, _i32, _p, _p]),
     "egnn_bn_act_bwd_reduce_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _p, _p, _sz, _p]),
     "egnn_bn_act_bwd_apply_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _p, _f32, _p, _i64, _p]),
 }
@@ -131,6 +132,23 @@ def require_gpu(*tensors: torch.Tensor) -> None:
             raise HipExtensionError(
                 "efficient-gnns_amd kernels run on an MI355X only: got a CPU tensor (no CPU fallback exists; "
                 "move the tensor to the GPU)")
+
+
+# Host stand-ins: the multi-process gloo tests (tests/test_dist_gloo.py) replace the kernel entry points of `ops` with CPU
+# functions to exercise the DISTRIBUTED LOGIC (partition plan, collectives, SyncBN) without a GPU, and switch this on for the
+# few torch-operator branches the model code needs next to them.  Nothing in the package sets it: with the switch off (always,
+# outside those tests) every one of these branches raises like a kernel call on a CPU tensor does.
+HOST_STANDINS = False
+
+
+def on_gpu(t: torch.Tensor) -> bool:
+    """True for a GPU tensor.  For a CPU tensor: False under the tests' stand-in switch, HipExtensionError otherwise."""
+    if t.is_cuda:
+        return True
+    if HOST_STANDINS:
+        return False
+    require_gpu(t)
+    return False
 
 
 def build_info() -> str:

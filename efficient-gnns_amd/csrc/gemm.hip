@@ -254,13 +254,7 @@ template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER, bool SPLIT,
 int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
   using TS = typename std::conditional<NTHR == 256, typename TileSel<SPLIT, BM, BN>::type, TileShapeS<BM, BN, NTHR / 128>>::type;
   constexpr size_t shm = (size_t)TS::SMEM_FLOATS * sizeof(float);
-  auto* fn = gemm_kernel<BM, BN, AMAJ, BMAJ, VEC4, GATHER, SPLIT, NTHR>;
-  if constexpr (shm > 65536) {
-    static const hipError_t attr = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    if (attr != hipSuccess) return EGNN_ELAUNCH;
-  }
-  hipLaunchKernelGGL(fn, grid, dim3(NTHR), shm, st, g);
-  return EGNN_OK;
+  return launch_dyn_lds<gemm_kernel<BM, BN, AMAJ, BMAJ, VEC4, GATHER, SPLIT, NTHR>>(grid, dim3(NTHR), shm, st, g);
 }
 
 // 8-wave 256 x 128 tiles: lab switch EGNN_GEMM_TILE=256 (default 128)

@@ -414,13 +414,24 @@ static inline bool egnn_split_pipe() {
   return on;
 }
 
+// The opt-in for more than 64 KB of dynamic LDS is a per-device attribute of the kernel: set once per (kernel, device) --
+// a process that drives several GPUs reaches every one of them (0 = not yet set, 1 = set, -1 = refused).
+template <auto Kernel>
+static inline bool allow_big_lds(int bytes) {
+  constexpr int kMaxDev = 64;
+  static signed char state[kMaxDev] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return false;
+  if (dev >= kMaxDev) return hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  if (state[dev] == 0)
+    state[dev] = hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 1 : -1;
+  return state[dev] == 1;
+}
+
 // launch with dynamic LDS (the split image of a 128 x 128 tile is 72 KB: above the 64 KB that need no opt-in)
 template <auto Kernel, class... Args>
 static inline int launch_dyn_lds(dim3 grid, dim3 block, size_t shm, hipStream_t st, Args... args) {
-  if (shm > 65536) {
-    static const hipError_t attr = hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (attr != hipSuccess) return EGNN_ELAUNCH;
-  }
+  if (shm > 65536 && !allow_big_lds<Kernel>(160 * 1024)) return EGNN_ELAUNCH;
   hipLaunchKernelGGL(Kernel, grid, block, shm, st, args...);
   return EGNN_OK;
 }

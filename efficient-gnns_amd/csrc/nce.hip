@@ -565,17 +565,19 @@ extern "C" int egnn_nce_block_fwd_f32(const float* fhat, int64_t ld_f, const flo
   const bool fixed = nce_unit_form(tau, unit_rows);
   const bool aligned = Z && vec4 && fixed && Sr % FB == 0 && Sc % FB == 0 && P % BK == 0 && Sc < (1LL << 28);
   const bool split = egnn_split_pipe() && (!aligned || P % (BK * PipelineS<FB, FB, KMAJOR, KMAJOR, true, true, IdentityXf, IdentityXf>::UNROLL) == 0);
+  int rc_fwd = EGNN_OK;
 #define EGNN_NCE_FWD(V, F, A)                                                                                                              \
   do {                                                                                                                                     \
-    if (split) launch_dyn_lds<nce_fwd_kernel<V, F, A, true>>(grid, dim3(256), (size_t)TileShapeS<FB, FB>::SMEM_BYTES, st, fhat, ld_f, that, ld_t, Sr, \
+    if (split) rc_fwd = launch_dyn_lds<nce_fwd_kernel<V, F, A, true>>(grid, dim3(256), (size_t)TileShapeS<FB, FB>::SMEM_BYTES, st, fhat, ld_f, that, ld_t, Sr, \
                                                              Sc, diag_off, P, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split);           \
-    else launch_dyn_lds<nce_fwd_kernel<V, F, A, false>>(grid, dim3(256), (size_t)TileShape<FB, FB>::SMEM_FLOATS * 4, st, fhat, ld_f, that, ld_t, Sr,  \
+    else rc_fwd = launch_dyn_lds<nce_fwd_kernel<V, F, A, false>>(grid, dim3(256), (size_t)TileShape<FB, FB>::SMEM_FLOATS * 4, st, fhat, ld_f, that, ld_t, Sr,  \
                                                         Sc, diag_off, P, 1.f / tau, Z, zdiag, pm, ps, nsplit, cb_per_split);                \
   } while (0)
   if (aligned) EGNN_NCE_FWD(true, true, true);
   else if (vec4) { if (fixed) EGNN_NCE_FWD(true, true, false); else EGNN_NCE_FWD(true, false, false); }
   else { if (fixed) EGNN_NCE_FWD(false, true, false); else EGNN_NCE_FWD(false, false, false); }
 #undef EGNN_NCE_FWD
+  if (rc_fwd != EGNN_OK) return rc_fwd;
   float* block_part = ps + Sr * kMaxSplit;
   const int fb = (int)((Sr + 255) / 256 < kFinalBlocks ? (Sr + 255) / 256 : kFinalBlocks);
   hipLaunchKernelGGL(nce_finalize_rows_kernel, dim3(fb), dim3(256), 0, st, pm, ps, zdiag, Sr, nsplit, lse, block_part);

@@ -124,11 +124,20 @@ def community_edges(n: int, e: int, gamma: float = 2.2, max_degree: int | None =
     return np.stack([src, dst]), community
 
 
-def arxiv_like(scale: float = 1.0, seed: int = 0, with_teacher: bool = True, graph: str = "chunglu"):
+TEACHER_FEAT_SCALE = 1.0 / 16.0
+
+
+def arxiv_like(scale: float = 1.0, seed: int = 0, with_teacher: bool = True, graph: str = "chunglu",
+               teacher_feat_scale: float = TEACHER_FEAT_SCALE):
     """Synthetic ogbn-arxiv-shaped node-classification problem (CPU tensors).  ``scale`` < 1 shrinks N and E
     proportionally (test sizes); scale=1 is the BASELINE.json workload.  ``graph``: 'chunglu' (the headline workload of
     SURVEY 8d: power law, no locality at all) | 'local' (same degree law + community structure, ids shuffled: locality
-    must be found by ``SparseTensor.reorder``) | 'local-sorted' (the same graph with ids already in community order)."""
+    must be found by ``SparseTensor.reorder``) | 'local-sorted' (the same graph with ids already in community order).
+    ``teacher_feat_scale``: the [N,750] teacher features are relu(N(0,1)) * scale.  At scale 1 two rows are ~22 apart
+    (||a-b||^2 ~ 510), so the rbf similarities exp(-||a-b||^2 / 2) of the LSP / GSP losses (criterion.py:78,111) underflow to
+    exactly 0 and those configurations compare nothing; 1/16 puts the median ||a-b||^2 at ~2 (similarities ~0.37, edge
+    distributions far from uniform).  Non-negative with ~50 % zeros either way; the projection heads start
+    with a BatchNorm, so G-CRD / GSP-cosine see the same normalised inputs at any scale."""
     from .transforms import to_sparse_tensor
     n = max(64, int(round(ARXIV["num_nodes"] * scale)))
     e = max(128, int(round(ARXIV["num_edges"] * scale)))
@@ -156,7 +165,7 @@ def arxiv_like(scale: float = 1.0, seed: int = 0, with_teacher: bool = True, gra
     d.adj_t = to_sparse_tensor(ei, n).to_symmetric()  # gnn.py:237-240
     d.edge_index = None
     if with_teacher:
-        d.teacher_out_feat = torch.relu(torch.randn(n, ARXIV["teacher_dim"], generator=g))
+        d.teacher_out_feat = torch.relu(torch.randn(n, ARXIV["teacher_dim"], generator=g)) * teacher_feat_scale
         d.teacher_logits = torch.randn(n, d.num_classes, generator=g) * 3.0
     return d
 

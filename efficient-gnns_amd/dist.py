@@ -28,7 +28,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor, nn
 
-from . import ops
+from . import _lib, ops
 from .sparse import SparseTensor
 
 
@@ -230,6 +230,10 @@ class ShardedAdj:
             raise RuntimeError("ShardedAdj with world > 1 needs an initialised process group (or a plan built by ShardPlan.from_global)")
         self._finish()
         self._gcn = None
+        if with_gcn and make is None:
+            # A^ needs deg^-1/2 of the halo nodes from their owners (one exchange) and its own send lists: both are collectives
+            raise RuntimeError("ShardedAdj(_plan=..., with_gcn=True) with world > 1 needs an initialised process group for the "
+                               "normalised adjacency; pass with_gcn=False for the raw adjacency only")
         if with_gcn:
             self._gcn = ShardedAdj.__new__(ShardedAdj)
             self._gcn.group, self._gcn.device = group, self.device
@@ -394,7 +398,7 @@ class SyncBatchNorm1d(nn.Module):
     def fused_act(self, x: Tensor, relu: bool, p: float, training: bool) -> Tensor:
         """dropout(relu(self(x)), p) -- on the GPU through the fused BN + ReLU + dropout kernels (ops.sync_bn_act /
         ops.bn_act), elsewhere (gloo tests) through the torch operators above."""
-        if not (x.is_cuda and ops.bn_shape_ok(x)):
+        if not (_lib.on_gpu(x) and ops.bn_shape_ok(x)):
             y = self(x)
             y = torch.relu(y) if relu else y
             return torch.nn.functional.dropout(y, p, training) if p > 0 else y
@@ -616,7 +620,7 @@ def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: di
         if p is not None:
             p.train()
     group = prob.group
-    take = ops.take_rows if prob.x.is_cuda else (lambda t, i: t[i])   # train ids are unique: gather / scatter without a sort
+    take = ops.take_rows if _lib.on_gpu(prob.x) else (lambda t, i: t[i])   # train ids are unique: gather / scatter without a sort
     out = take(model(prob.x, prob.adj), prob.train_local)
     labels = prob.y.squeeze(1)[prob.train_local]
     frac = out.shape[0] / prob.n_train_global               # local mean -> contribution to the global mean

@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib
 from . import criterion as C
 from . import ops
 from .nn import DGLGATConv, GATConv, GCNConv, RGCNConv, SAGEConv
@@ -52,7 +53,8 @@ class _Student(nn.Module):
                 x = ops.bn_act(x, bn, relu=True, p=self.dropout, training=self.training)
             elif hasattr(bn, "fused_act"):                      # dist.SyncBatchNorm1d on sharded runs (all-rank statistics)
                 x = bn.fused_act(x, True, self.dropout, self.training)
-            else:
+            else:                                               # another norm module on the GPU; CPU tensors: tests' stand-in switch only
+                _lib.on_gpu(x)
                 x = F.dropout(F.relu(bn(x)), p=self.dropout, training=self.training)
             self.out_feat = x
         if self.training and x.is_cuda:
@@ -97,14 +99,14 @@ class ProjectionHead(nn.Sequential):
         lin, bn = self[0], self[1]
         if x.is_cuda and hasattr(bn, "fused_act"):              # dist.SyncBatchNorm1d
             return bn.fused_act(ops.linear(x, lin.weight, lin.bias), True, 0.0, self.training)
-        if not x.is_cuda or not isinstance(bn, nn.BatchNorm1d):
+        if not _lib.on_gpu(x) or not isinstance(bn, nn.BatchNorm1d):
             return super().forward(x)
         return ops.bn_act(ops.linear(x, lin.weight, lin.bias), bn, relu=True, p=0.0, training=self.training)
 
     def forward_rows(self, x, idx):
         """``self(x[idx])`` for unique row ids: the gather is fused into the GEMM's operand load (gnn.py:150-156)."""
         lin, bn = self[0], self[1]
-        if not x.is_cuda:
+        if not _lib.on_gpu(x):
             return self(x[idx])
         y = ops.linear_rows(x, idx, lin.weight, lin.bias)
         if hasattr(bn, "fused_act"):                            # dist.SyncBatchNorm1d
@@ -221,7 +223,7 @@ def evaluate_tensors(model, x, adj_t, y, split_idx):
 
 @torch.no_grad()
 def evaluate(model, x, adj_t, y, split_idx):
-    if x.is_cuda:   # the three Evaluator accuracies with ONE device->host read instead of three
+    if _lib.on_gpu(x):   # the three Evaluator accuracies with ONE device->host read instead of three
         out, accs = evaluate_tensors(model, x, adj_t, y, split_idx)
         return out, tuple(accs.tolist())
     model.eval()

@@ -49,15 +49,16 @@ def spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = Non
              addend: Tensor | None = None, relu: bool = False):
     """``relu``: Y = max(REDUCE(adj, X) + bias, 0), fused into the block kernel's store (eval-mode BatchNorm folded into the
     weights + ReLU, ``bn_fold``); on the other schedules a clamp follows."""
-    res = _spmm_raw(adj, x, reduce, src_scale, use_plan, bias, out, stat_shift, want_stats, addend, relu)
-    if relu and not getattr(res[0], "_egnn_relu_done", False):
+    fused = []   # filled by _spmm_raw when the kernel applied the ReLU in its store (a value, not a tag on the -- possibly caller-owned -- output buffer)
+    res = _spmm_raw(adj, x, reduce, src_scale, use_plan, bias, out, stat_shift, want_stats, addend, relu, fused)
+    if relu and not fused:
         res[0].clamp_(min=0)
     return res
 
 
 def _spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = None, use_plan: bool = True,
               bias: Tensor | None = None, out: Tensor | None = None, stat_shift: Tensor | None = None, want_stats: bool = False,
-              addend: Tensor | None = None, relu: bool = False):
+              addend: Tensor | None = None, relu: bool = False, relu_fused: list | None = None):
     """Y = REDUCE(adj, X) on the GPU.  Returns (Y, argmax | None), or (Y, None, (mean, biased var)) with ``want_stats``.
 
     Schedules: 'blocks' (default; egnn_spmm_csr_blk_f32: one launch over hub segments + row blocks, int32 indices, then the
@@ -131,8 +132,8 @@ def _spmm_raw(adj, x: Tensor, reduce: str = "sum", src_scale: Tensor | None = No
                                                      0 if addend is None else addend.stride(0), _lib.ptr(stat_part), n_stat,
                                                      _lib.ptr(stat_shift) if want_stats else None, flags, _lib.stream()), "egnn_spmm_combine_f32")
             if not want_stats:
-                if flags & 8:
-                    y._egnn_relu_done = True
+                if flags & 8 and relu_fused is not None:
+                    relu_fused.append(True)
                 return y, None
             mean = torch.empty(K, dtype=torch.float32, device=x.device)
             var = torch.empty(K, dtype=torch.float32, device=x.device)
@@ -236,7 +237,15 @@ class _SpMM(torch.autograd.Function):
                                                        _lib.ptr(gy), gy.stride(0), _lib.ptr(gx), gx.stride(0), _lib.stream())
             _lib.check(rc, "egnn_spmm_csr_max_bwd_f32")
         gb = colsum(gy) if ctx.has_bias and ctx.needs_input_grad[3] else None
-        return gx, None, None, gb, None, None
+        return _fresh(gx), None, None, gb, None, None
+
+
+def _fresh(g):
+    """Marks a gradient this package has just allocated in a backward: nobody else holds it yet, so ``_GradTap`` may add
+    its row-compact pieces into it in place (a gradient without the mark is copied first)."""
+    if g is not None:
+        g._egnn_fresh = True
+    return g
 
 
 def colsum(g: Tensor) -> Tensor:
@@ -267,7 +276,7 @@ def spmm(adj, x: Tensor, reduce: str = "sum", bias: Tensor | None = None, bn_sta
         return _SpMM.apply(x, adj, reduce, None)[0] + bias
     y, mean, var = _SpMM.apply(x, adj, reduce, bias, bn_stats_shift, bool(want_bn_stats) and reduce != "max")
     if mean is not None:
-        y._egnn_bn_stats = (mean, var)
+        y._egnn_bn_stats = (mean, var, y._version)   # version-checked by bn_act: an in-place edit of y voids the statistics
     return y
 
 
@@ -296,8 +305,9 @@ def take_rows(x: Tensor, idx: Tensor) -> Tensor:
 # dense GEMM (fp32 MFMA)
 # ------------------------------------------------------------------------------------------------
 def gemm_backend() -> str:
-    """'hip' = hand-written fp32-MFMA kernel (default); 'blas' = torch.matmul (rocBLAS/hipBLASLt)."""
-    return os.environ.get("EGNN_GEMM", "hip")
+    """Always 'hip': every GEMM of the package runs on the hand-written kernels (egnn_gemm_f32 and relatives).  The
+    rocBLAS comparison lives in tools/kernel_bench.py, outside the product."""
+    return "hip"
 
 
 def _pitch_ok(t: Tensor) -> bool:
@@ -407,13 +417,11 @@ class _MatMul(torch.autograd.Function):
             gw = gemm_raw(gy, x, True, False) if ctx.transposed else gemm_raw(x, gy, True, False)  # dW = dY^T X | X^T dY
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = colsum(gy)
-        return gx, gw, gb, None
+        return _fresh(gx), gw, gb, None
 
 
 def matmul(x: Tensor, w: Tensor, bias: Tensor | None = None) -> Tensor:
     """x [M,K] @ w [K,N] (+ bias [N], added in the GEMM's store)."""
-    if gemm_backend() == "blas":
-        return x @ w if bias is None else torch.addmm(bias, x, w)
     return _MatMul.apply(x, w, bias, False)
 
 
@@ -448,6 +456,11 @@ class _GradTap(torch.autograd.Function):
             g = torch.zeros(shape, dtype=dtype, device=dev)
         elif g.is_sparse or not g.is_contiguous():
             g = g.to_dense().contiguous() if g.is_sparse else g.contiguous()
+        elif not getattr(g, "_egnn_fresh", False):
+            # autograd forbids changing a grad_output in place: a consumer whose backward hands its own grad_output through
+            # (add, a view, identity) or a caller-supplied gradient would be corrupted.  Only a tensor one of this package's
+            # backward functions has just allocated (``_fresh``) is added into directly.
+            g = g.clone()
         for idx, rows in pend:   # unique ids: a plain read-modify-write of those rows, deterministic
             rows = _rowmajor(rows)
             _lib.check(_lib.load().egnn_rows_add_f32(_lib.ptr(g), g.stride(0), _lib.ptr(idx), _lib.ptr(rows), rows.stride(0), rows.shape[0],
@@ -537,15 +550,13 @@ class _LinearRows(torch.autograd.Function):
 
 def linear_rows(x: Tensor, idx: Tensor, weight: Tensor, bias: Tensor | None = None) -> Tensor:
     """``F.linear(x[idx], weight, bias)`` with the row gather fused into the GEMM (unique ``idx``)."""
-    if gemm_backend() == "blas" or not x.is_cuda:
+    if not _lib.on_gpu(x):
         return torch.nn.functional.linear(take_rows(x, idx), weight, bias)
     return _LinearRows.apply(x, idx, weight, bias, getattr(x, "_egnn_tap", None) if torch.is_grad_enabled() else None)
 
 
 def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None) -> Tensor:
     """x @ weight^T + bias with ``weight`` in nn.Linear layout [out, in]."""
-    if gemm_backend() == "blas":
-        return torch.nn.functional.linear(x, weight, bias)
     return _MatMul.apply(x, weight, bias, True)
 
 
@@ -801,8 +812,8 @@ def bn_act(x: Tensor, bn: "torch.nn.BatchNorm1d", relu: bool = True, p: float = 
     if use_batch:
         lib, dev = _lib.load(), x.device
         pre = getattr(x_in, "_egnn_bn_stats", None)   # formed in the producing aggregation's epilogue (ops.spmm)
-        if pre is not None and pre[0].shape[0] == C:
-            mean, var = pre
+        if pre is not None and pre[0].shape[0] == C and pre[2] == x_in._version:
+            mean, var = pre[0], pre[1]
         else:
             mean = torch.empty(C, dtype=torch.float32, device=dev)
             var = torch.empty(C, dtype=torch.float32, device=dev)

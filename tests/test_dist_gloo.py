@@ -22,6 +22,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def _patch_ops_with_oracle():
     import efficient_gnns_amd.ops as ops
+    from efficient_gnns_amd import _lib
+    _lib.HOST_STANDINS = True    # the torch-operator branches next to the patched kernel entry points (see _lib.on_gpu)
     import oracle.sparse as OS
     import torch.nn.functional as F
 
@@ -229,6 +231,24 @@ def test_shard_plan_integer_logic():
             pq = plans[q_]
             so = sum(pq.send_counts[:r])
             assert torch.equal(pq.send_idx[so:so + pq.send_counts[r]] + pq.lo, ids)
+
+
+def test_sharded_adj_from_a_prebuilt_plan_without_a_process_group():
+    """``ShardPlan.from_global`` + ``ShardedAdj(_plan=...)`` (single-process tools): the raw adjacency is built without any
+    collective; the normalised one needs the peers' degrees, so asking for it without a process group is a clear error."""
+    import efficient_gnns_amd.dist as DD
+    d = _make_data(seed=7)
+    rowptr, col, _ = d.adj_t.csr()
+    n, world, rank = d.num_nodes, 2, 1
+    plan = DD.ShardPlan.from_global(rowptr, col, None, n, world, rank)
+    lo, hi, _ = DD.node_range(n, world, rank)
+    e0, e1 = int(rowptr[lo]), int(rowptr[hi])
+    sadj = DD.ShardedAdj(rowptr[lo:hi + 1] - e0, col[e0:e1], n, world, rank, "cpu", with_gcn=False, _plan=plan)
+    assert sadj.plan is plan and sadj.raw.sparse_sizes() == (plan.n_local, plan.n_local + plan.n_halo)
+    with pytest.raises(RuntimeError, match="with_gcn=False"):
+        sadj.gcn_normalized()
+    with pytest.raises(RuntimeError, match="process group"):
+        DD.ShardedAdj(rowptr[lo:hi + 1] - e0, col[e0:e1], n, world, rank, "cpu", with_gcn=True, _plan=plan)
 
 
 def _bench_worker(rank, world, port, path, workload="arxiv", overlap="1"):

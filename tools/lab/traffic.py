@@ -3,15 +3,21 @@
 passes, counters only), calibrated on the two 256 MiB device-to-device copies the lab driver issues in the same pass
 (MI355X_MICROARCH.md, HBM section: FETCH_SIZE tallies 128-byte requests at 64 B on gfx950; WRITE_SIZE is calibrated likewise).
 
-    python tools/lab/traffic.py gpurun_out/r02/lab3/pmc chunglu default 367506008 > profiles/r02_spmm_traffic.json"""
+    python tools/lab/traffic.py gpurun_out/r03/pmc chunglu default 367506008 > profiles/spmm_traffic.json
+
+The JSON records ``lib_sha16`` (SHA-256 of the libegnn_hip.so the passes ran on): bench.py reports the traffic only when it
+runs on that very build."""
 import csv
+import hashlib
 import json
 import os
 import sys
 
 d, graph, var, alg = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 COPY = 256 << 20
-out = {"graph": graph, "variant": var, "algorithmic_bytes_per_call": alg}
+LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "efficient-gnns_amd", "lib", "libegnn_hip.so")
+out = {"graph": graph, "variant": var, "algorithmic_bytes_per_call": alg,
+       "lib_sha16": hashlib.sha256(open(LIB, "rb").read()).hexdigest()[:16]}
 total = 0.0
 for key, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     rows = [r for r in csv.DictReader(open(os.path.join(d, f"{graph}_{var}_{key}.csv"))) if r["Counter_Name"] == counter]
