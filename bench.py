@@ -223,33 +223,56 @@ def cpu_baseline(args, data, hp):
 PARITY_BARS = dict(loss_rtol=1e-5, loss_rtol_pairwise=2e-5, logits=1e-5, grad_rtol=1e-4, grad_atol_over_max=2e-5)
 
 
-def grad_errors(named_got, named_ref):
-    """Per-parameter gradient comparison after one step (the gradients are still in .grad: zero_grad() runs before
-    backward).  A parameter whose reference gradient is pure rounding noise next to the rest (a bias in front of a
-    BatchNorm: mathematically zero) is not a measurement and is skipped.  Returns (worst violation ratio, worst tensor,
-    max |got - ref| / max |ref| over the compared tensors)."""
-    ref = {k: v.grad.detach().double().cpu() for k, v in named_ref if v.grad is not None}
-    got = {k: v.grad.detach().double().cpu() for k, v in named_got if v.grad is not None}
-    top = max((float(v.abs().max()) for v in ref.values()), default=0.0)
-    worst, worst_name, rel_max = 0.0, None, 0.0
-    for k, r in ref.items():
+def feeds_batchnorm(name, n_layers):
+    """A bias that is added right in front of a BatchNorm (conv biases of the hidden layers, the Linear bias of a projection
+    head): BatchNorm subtracts the column mean, so its gradient is mathematically zero and what either implementation holds
+    is rounding noise -- not a measurement."""
+    if name in ("student_proj.0.bias", "teacher_proj.0.bias"):
+        return True
+    return any(name in (f"model.convs.{i}.bias", f"model.convs.{i}.lin_l.bias") for i in range(n_layers - 1))
+
+
+def grad_errors(got, ref32, ref64, n_layers=MODEL["layers"]):
+    """Per-parameter gradient comparison after ONE step (the gradients are still in .grad: zero_grad() runs before backward).
+
+    Reference = a FLOAT64 run of the CPU oracle.  At full size two correct fp32 implementations cannot agree to 1e-4 on the
+    gradients upstream of a ReLU: of the 43 M pre-activations of a hidden layer a handful lie within fp32 rounding of zero, the
+    two runs put them on different sides, and each such flip moves a weight gradient (a sum over 169 343 rows) by ~1 / sqrt(N) =
+    2e-3 of its size (tools/checks/fullsize_ops_probe.py and tests/test_gpu_full_size.py::test_relu_mask_flips_... show the
+    mechanism: with the SAME mask the layer's gradients agree to 1e-6).  The fp32 CPU oracle itself is 1e-4 .. 5e-3 away from
+    its float64 run on those tensors.  The bar is therefore: per parameter tensor, |got - ref64| <= 1e-4 |ref64| + 2e-5
+    max|ref64| OR max|got - ref64| <= 1.5 x max|oracle_fp32 - ref64| -- not farther from the truth than the
+    reference's own fp32 CPU path.  Biases in front of a BatchNorm (true gradient zero, see feeds_batchnorm) are skipped.
+    Returns (worst violation ratio, worst tensor, max error of `got` and of the fp32 oracle over max|ref64|)."""
+    worst, worst_name, rel_got, rel_32 = 0.0, None, 0.0, 0.0
+    for k, r in ref64.items():
         scale = float(r.abs().max())
-        if scale <= 1e-6 * top or k not in got:
+        if feeds_batchnorm(k, n_layers) or scale == 0.0 or k not in got:
             continue
-        g = got[k]
+        e_got, e_32 = (got[k] - r).abs(), (ref32[k] - r).abs()
         bound = PARITY_BARS["grad_rtol"] * r.abs() + PARITY_BARS["grad_atol_over_max"] * scale
-        ratio = float(((g - r).abs() / bound).max())
-        rel_max = max(rel_max, float((g - r).abs().max()) / scale)
+        ratio = min(float((e_got / bound).max()), float(e_got.max()) / max(1.5 * float(e_32.max()), 1e-300))
+        rel_got, rel_32 = max(rel_got, float(e_got.max()) / scale), max(rel_32, float(e_32.max()) / scale)
         if ratio > worst:
             worst, worst_name = ratio, k
-    return worst, worst_name, rel_max
+    return worst, worst_name, rel_got, rel_32
+
+
+def _named_grads(model, sp, tp):
+    named = [(f"model.{k}", v) for k, v in model.named_parameters()]
+    for tag, m in (("student_proj", sp), ("teacher_proj", tp)):
+        if m is not None:
+            named += [(f"{tag}.{k}", v) for k, v in m.named_parameters()]
+    return {k: v.grad.detach().double().cpu() for k, v in named if v.grad is not None}
 
 
 def parity_check(args, data, d, device, hp, PM):
     """Full-size parity inside the driver-observed run: ONE optimisation step of the timed configuration (same graph,
     N = 169 343, S = max_samples, same np.random draw, same initial weights) on the GPU path and on the CPU oracle, with
     dropout = 0 (the dropout masks of the two implementations are only equal in distribution), plus the eval logits of
-    the initial state.  Bars: PARITY_BARS (gnn.py:102-195, criterion.py:57-149)."""
+    the initial state.  Bars: PARITY_BARS (gnn.py:102-195, criterion.py:57-149); gradients against a float64 run of the
+    oracle (see grad_errors)."""
+    import copy
     import oracle.models as OM
     import oracle.sparse as OS
     import types
@@ -263,6 +286,8 @@ def parity_check(args, data, d, device, hp, PM):
     for a, b in ((psp, osp), (ptp, otp)):
         if a is not None:
             a.load_state_dict(b.state_dict())
+    # the float64 twin of the oracle (same initial weights; built before any forward so that no fp32 A^ is cached in it)
+    om64, osp64, otp64 = (copy.deepcopy(m).double() if m is not None else None for m in (om, osp, otp))
     edge_o = edge_p = None
     if args.training == "lpw":
         import oracle.utils as OU
@@ -278,20 +303,36 @@ def parity_check(args, data, d, device, hp, PM):
     np.random.seed(args.seed + 17)
     got = PM.train_step(pm, d.x, d.adj_t, d.y, d.split_idx["train"], popt, args.training, hp, d.teacher_out_feat,
                         d.teacher_logits, psp, ptp, edge_p)
+    groups64 = [{"params": m.parameters(), "lr": MODEL["lr"]} for m in (om64, osp64, otp64) if m is not None]
+    fill32 = OS.SparseTensor.fill_value
+    OS.SparseTensor.fill_value = lambda self, fill, dtype=torch.float64: fill32(self, fill, dtype)   # A^ values in double as well
+    try:
+        np.random.seed(args.seed + 17)
+        ref64 = OM.train_step(om64, dc.x.double(), dc.adj_t, dc.y, dc.split_idx["train"], torch.optim.Adam(groups64), args.training, hp,
+                              None if dc.teacher_out_feat is None else dc.teacher_out_feat.double(), dc.teacher_logits.double(), osp64, otp64, edge_o)
+    finally:
+        OS.SparseTensor.fill_value = fill32
     rtol = PARITY_BARS["loss_rtol_pairwise"] if args.training in ("nce", "gpw") else PARITY_BARS["loss_rtol"]
     # relative error of each of the three terms (a term that is exactly zero on the oracle -- `supervised` has no auxiliary
     # loss -- must be exactly zero here)
     rel = max((abs(a - b) / abs(b)) if b != 0 else (0.0 if a == 0 else float("inf")) for a, b in zip(got, ref))
-    named = lambda m, tag: [(f"{tag}.{k}", v) for k, v in m.named_parameters()] if m is not None else []   # noqa: E731
-    gworst, gname, grel = grad_errors(named(pm, "model") + named(psp, "student_proj") + named(ptp, "teacher_proj"),
-                                      named(om, "model") + named(osp, "student_proj") + named(otp, "teacher_proj"))
-    ok = bool(rel <= rtol and logit_err <= PARITY_BARS["logits"] and gworst <= 1.0
+    rel64 = max((abs(a - b) / abs(b)) if b != 0 else (0.0 if a == 0 else float("inf")) for a, b in zip(got, ref64))
+    gworst, gname, grel, grel32 = grad_errors(_named_grads(pm, psp, ptp), _named_grads(om, osp, otp), _named_grads(om64, osp64, otp64))
+    # a loss term passes at rtol against the fp32 oracle, or -- a term that is a small difference of large sums, e.g. the KL of two
+    # nearly uniform edge distributions (LSP with the rbf kernel: 2e-5 out of O(1) terms over 680 k edges) -- when it is not
+    # farther from the float64 value than 1.5 x the fp32 oracle is
+    loss_ok = all(abs(g - c) <= rtol * abs(c) or abs(g - t) <= max(rtol * abs(t), 1.5 * abs(c - t)) for g, c, t in zip(got, ref, ref64))
+    ok = bool(loss_ok and logit_err <= PARITY_BARS["logits"] and gworst <= 1.0
               and all(abs(a - b) <= 1e-4 for a, b in zip(accs_p, accs_o)))
     return dict(ok=ok, what="first train step (dropout 0) + initial eval, GPU path vs CPU oracle, full size, same seeds/draw/weights",
-                loss=dict(gpu=got[0], cpu=ref[0]), loss_cls=dict(gpu=got[1], cpu=ref[1]), loss_aux=dict(gpu=got[2], cpu=ref[2]),
-                max_rel_err=rel, rtol=rtol, eval_logits_max_abs_err_over_max_abs=logit_err, logits_tol=PARITY_BARS["logits"],
-                grads=dict(max_abs_err_over_max_abs=grel, worst_violation_of_bar=round(gworst, 4), worst_tensor=gname,
-                           bar=f"|got - ref| <= {PARITY_BARS['grad_rtol']} |ref| + {PARITY_BARS['grad_atol_over_max']} max|ref| per parameter tensor"),
+                loss=dict(gpu=got[0], cpu=ref[0], cpu_f64=ref64[0]), loss_cls=dict(gpu=got[1], cpu=ref[1], cpu_f64=ref64[1]),
+                loss_aux=dict(gpu=got[2], cpu=ref[2], cpu_f64=ref64[2]),
+                max_rel_err=rel, max_rel_err_vs_f64=rel64, rtol=rtol, losses_ok=loss_ok,
+                loss_bar="each term: |gpu - cpu| <= rtol |cpu|, or |gpu - f64| <= max(rtol |f64|, 1.5 |cpu - f64|)", eval_logits_max_abs_err_over_max_abs=logit_err, logits_tol=PARITY_BARS["logits"],
+                grads=dict(reference="float64 run of the CPU oracle", gpu_max_abs_err_over_max_abs=grel, cpu_oracle_f32_max_abs_err_over_max_abs=grel32,
+                           worst_violation_of_bar=round(gworst, 4), worst_tensor=gname,
+                           bar=f"per parameter tensor: |gpu - f64| <= {PARITY_BARS['grad_rtol']} |f64| + {PARITY_BARS['grad_atol_over_max']} max|f64|, or "
+                               "max|gpu - f64| <= 1.5 max|cpu_f32 - f64| (ReLU-mask flips at full size: bench.grad_errors)"),
                 accs=dict(gpu=[round(a, 6) for a in accs_p], cpu=[round(a, 6) for a in accs_o]))
 
 
@@ -350,10 +391,10 @@ def gather_ceiling(adj_gcn, K, device):
     sink = torch.zeros(1, device=device)
     nnz = adj_gcn.nnz()
     best = None
-    for bps in (128, 256, 512, 1024):
+    for bps, inflight in ((128, 8), (256, 8), (512, 8), (1024, 8), (256, 16), (512, 16), (1024, 4), (2048, 4)):
         def run():
-            _lib.check(lib.egnn_probe_gather_lines_f32(_lib.ptr(x), x.stride(0), x.shape[0], K, _lib.ptr(col), nnz, bps, _lib.ptr(sink),
-                                                       _lib.stream()), "egnn_probe_gather_lines_f32")
+            _lib.check(lib.egnn_probe_gather_lines_f32(_lib.ptr(x), x.stride(0), x.shape[0], K, _lib.ptr(col), nnz, bps, inflight,
+                                                       _lib.ptr(sink), _lib.stream()), "egnn_probe_gather_lines_f32")
         for _ in range(2):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -364,8 +405,8 @@ def gather_ceiling(adj_gcn, K, device):
         e1.synchronize()
         secs = e0.elapsed_time(e1) * 1e-3 / 10
         if best is None or secs < best[0]:
-            best = (secs, bps)
-    return dict(gathered_bytes=nnz * K * 4, secs=best[0], blocks_per_slice=best[1])
+            best = (secs, bps, inflight)
+    return dict(gathered_bytes=nnz * K * 4, secs=best[0], blocks_per_slice=best[1], loads_in_flight=best[2])
 
 
 def lib_sha16() -> str:
@@ -532,7 +573,7 @@ def main():
                         launches_timed=roof["launches"], traffic=traffic, traffic_source=traffic_note)
         try:   # the same call's gather stream alone (no reduction, no output): what the request path delivers on this graph
             import efficient_gnns_amd as _E
-            gc = gather_ceiling(_E.gcn_norm(d.adj_t), K, device)
+            gc = gather_ceiling(_E.gcn_norm(d.adj_t) if args.gnn == "gcn" else d.adj_t, K, device)   # the matrix the K-wide calls aggregate over
         except Exception as e:  # noqa: BLE001  (a diagnostic must not take the headline line down)
             gc = None
             roofline["gather_ceiling_error"] = f"{type(e).__name__}: {str(e)[:200]}"
@@ -541,9 +582,10 @@ def main():
             ceil_gbs = gc["gathered_bytes"] / gc["secs"] / 1e9
             roofline.update(gathered_line_bytes_per_launch=gc["gathered_bytes"], gather_GBs=round(lines_gbs, 1),
                             gather_ceiling_GBs=round(ceil_gbs, 1), gather_ceiling_us=round(gc["secs"] * 1e6, 2),
+                            gather_ceiling_grid=dict(blocks_per_slice=gc["blocks_per_slice"], loads_in_flight=gc["loads_in_flight"]),
                             frac_of_gather_ceiling=round(lines_gbs / ceil_gbs, 4),
                             gather_ceiling_what="egnn_probe_gather_lines_f32 in this run: the call's nnz x K x 4 bytes of 128-byte lines, same "
-                                                "slice <-> XCD binding, no reduction / values / output (HIP events, 10 launches, best grid)")
+                                                "slice <-> XCD binding, no reduction / values / output (HIP events, 10 launches, best of 8 launch shapes)")
     roofline_mfma = None
     nsum = nce_probe.summary()
     if nsum:

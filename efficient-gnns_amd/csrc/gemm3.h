@@ -143,7 +143,9 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[TM][TN], const u32x4 (&
 //           the shadow of the matrix pipe inside ONE wave (an in-order wave cannot overlap them otherwise: ds_read -> cut ->
 //           MFMA is a dependency chain).  The stage read ahead is one beyond the stage computed, so the DMA ring is NB
 //           stages deep on top of the register stage.
-template <int AMODE, int BMODE, int TM, int TN, int BKT, int NB, int PIPE = 0>
+// ABL (lab only, tools/lab/gemm3_lab.hip; results are then wrong on purpose): 1 = no DMA, 2 = no barriers, 4 = fragments read
+// once and reused, 8 = no vmcnt waits, 16 = s_setprio(1) around every MFMA block.
+template <int AMODE, int BMODE, int TM, int TN, int BKT, int NB, int PIPE = 0, int ABL = 0>
 __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM][TN], const void* __restrict__ pa, int64_t la, int64_t m0, const void* __restrict__ pb,
                                          int64_t lb, int64_t n0, int64_t kbeg, int64_t kend, char* smem) {
   using T = Tile<AMODE, BMODE, TM, TN, BKT, NB>;
@@ -152,11 +154,27 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM][TN], const void* __re
   const int wm = wave >> 1, wn = wave & 1;
   const int nk = (int)((kend - kbeg) / BKT);
   auto issue = [&](int stage) {
+    if constexpr (ABL & 1) return;
     char* s = smem + (stage % NB) * T::STAGE_BYTES;
     issue_stage<AMODE, T::BM, BKT>(pa, la, m0, kbeg + (int64_t)stage * BKT, s, wave, lane);
     issue_stage<BMODE, T::BN, BKT>(pb, lb, n0, kbeg + (int64_t)stage * BKT, s + T::SA::BYTES, wave, lane);
   };
+  bool frags_done = false;
   auto frags = [&](int stage, int kb, u32x4 (&a)[TM][3], u32x4 (&b)[TN][3]) {
+    if constexpr (ABL & 4) {
+      if (frags_done) {   // keep the registers live and opaque, read nothing
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(a[tm][p]));
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) asm volatile("" : "+v"(b[tn][p]));
+        return;
+      }
+      frags_done = stage > 0 || PIPE == 0 || kb > 0;   // PIPE: both register sets get one real read
+    }
     const char* sa = smem + (stage % NB) * T::STAGE_BYTES;
     const char* sb = sa + T::SA::BYTES;
 #pragma unroll
@@ -205,13 +223,17 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM][TN], const void* __re
     auto block = [&](auto steady_c, int s, int kb, u32x4 (&ac)[TM][3], u32x4 (&bc)[TN][3], u32x4 (&an)[TM][3], u32x4 (&bn)[TN][3]) {
       constexpr bool STEADY = decltype(steady_c)::value;
       if (kb == KB - 1) {                                        // the next fragments come from stage s + 1
-        if constexpr (STEADY) {
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * G) : "memory");
-        } else {
-          if (s + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!(ABL & 8)) {
+          if constexpr (STEADY) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NB - 2) * G) : "memory");
+          } else {
+            if (s + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my LDS reads of stage s are complete before its buffer is re-filled
-        __builtin_amdgcn_s_barrier();                            // stage s + 1 landed for everybody; everybody has read stage s
+        if constexpr (!(ABL & 2)) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my LDS reads of stage s are complete before its buffer is re-filled
+          __builtin_amdgcn_s_barrier();                          // stage s + 1 landed for everybody; everybody has read stage s
+        }
         asm volatile("" ::: "memory");
         if constexpr (STEADY) {
           issue(s + NB);                                         // into the buffer of stage s
@@ -223,7 +245,9 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM][TN], const void* __re
       } else {
         frags(s, kb + 1, an, bn);
       }
+      if constexpr (ABL & 16) __builtin_amdgcn_s_setprio(1);
       mfma_block<TM, TN>(acc, ac, bc);
+      if constexpr (ABL & 16) __builtin_amdgcn_s_setprio(0);
     };
     // k-blocks alternate between the two register sets; a group of GS stages is an even number of k-blocks, so that both
     // sets are compile-time names inside the (unrolled) group and every group starts on set 0

@@ -39,12 +39,14 @@ __global__ __launch_bounds__(256) void probe_gather_kernel(const float* __restri
 }  // namespace
 
 extern "C" int egnn_probe_gather_lines_f32(const float* X, int64_t ldx, int64_t n_src, int64_t K, const int32_t* col, int64_t nnz,
-                                           int blocks_per_slice, float* sink, void* stream) {
+                                           int blocks_per_slice, int loads_in_flight, float* sink, void* stream) {
   EGNN_CHECK_ARG(X && col && sink && K > 0 && K % 32 == 0 && ldx >= K && ldx % 4 == 0 && n_src > 0 && nnz >= 0 && blocks_per_slice > 0);
   if (!egnn_aligned16(X)) return EGNN_EALIGN;
   if (nnz == 0) return EGNN_OK;
   const int n_slices = (int)(K / 32);
   const dim3 grid((unsigned)(n_slices * blocks_per_slice));
-  hipLaunchKernelGGL(probe_gather_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, col, nnz, n_slices, sink);
+  if (loads_in_flight >= 16) hipLaunchKernelGGL(probe_gather_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, col, nnz, n_slices, sink);
+  else if (loads_in_flight >= 8) hipLaunchKernelGGL(probe_gather_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, col, nnz, n_slices, sink);
+  else hipLaunchKernelGGL(probe_gather_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, X, ldx, col, nnz, n_slices, sink);
   return egnn_launch_status();
 }

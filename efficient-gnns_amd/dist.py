@@ -32,6 +32,104 @@ from . import _lib, ops
 from .sparse import SparseTensor
 
 
+class CommTrace:
+    """Records every torch.distributed collective this rank issues inside the ``with`` block: (op, payload bytes in, payload
+    bytes out, per-peer element counts of an all_to_all).  Two uses: (1) the CPU (gloo) test asserts that all ranks issue the
+    SAME sequence with matching sizes, step after step, including shards without train rows -- a mismatch is a hang on real
+    hardware; (2) ``bench_main`` reports the per-rank communication volume of one epoch in its JSON line.  Also collects the
+    overlap probes of ``_OverlapAggregate`` (HIP events: compute window the exchange is hidden under / time the stream then
+    still waits for it) when ``probe_overlap`` is set."""
+
+    _OPS = ("all_reduce", "all_to_all_single", "all_gather_into_tensor", "all_gather", "broadcast", "reduce_scatter_tensor", "barrier")
+    active = None
+
+    def __init__(self, probe_overlap: bool = False):
+        self.records, self.overlap, self.probe_overlap = [], [], probe_overlap
+
+    @staticmethod
+    def _bytes(t):
+        return 0 if t is None else t.numel() * t.element_size()
+
+    def __enter__(self):
+        self._orig = {n: getattr(dist, n) for n in self._OPS}
+        rec = self.records
+
+        def wrap(name, orig):
+            def f(*a, **kw):
+                if name == "all_to_all_single":
+                    out, inp = a[0], a[1]
+                    osz = a[2] if len(a) > 2 else kw.get("output_split_sizes")
+                    isz = a[3] if len(a) > 3 else kw.get("input_split_sizes")
+                    width = 1
+                    for v in inp.shape[1:]:
+                        width *= int(v)
+                    rec.append((name, self._bytes(inp), self._bytes(out), width,
+                                None if isz is None else tuple(int(v) for v in isz), None if osz is None else tuple(int(v) for v in osz)))
+                elif name == "all_gather_into_tensor":
+                    rec.append((name, self._bytes(a[1]), self._bytes(a[0]), a[1].numel()))
+                elif name == "barrier":
+                    rec.append((name, 0, 0, 0))
+                else:
+                    t = a[0] if torch.is_tensor(a[0]) else a[1]
+                    rec.append((name, self._bytes(t), self._bytes(t), t.numel()))
+                return orig(*a, **kw)
+            return f
+        for n, o in self._orig.items():
+            setattr(dist, n, wrap(n, o))
+        CommTrace.active = self
+        return self
+
+    def __exit__(self, *exc):
+        for n, o in self._orig.items():
+            setattr(dist, n, o)
+        CommTrace.active = None
+
+    def summary(self) -> dict:
+        """Bytes this rank put on / took off the wire, by kind (an all_reduce counted as 2 (w-1)/w of its payload each way is the
+        RING volume; here the plain payload is reported and the ring factor left to the reader)."""
+        a2a_out = sum(r[1] for r in self.records if r[0] == "all_to_all_single")
+        a2a_in = sum(r[2] for r in self.records if r[0] == "all_to_all_single")
+        red = sum(r[1] for r in self.records if r[0] == "all_reduce")
+        gat = sum(r[2] for r in self.records if r[0].startswith("all_gather"))
+        out = dict(collectives=len(self.records), halo_all_to_all_bytes_sent=a2a_out, halo_all_to_all_bytes_received=a2a_in,
+                   all_reduce_payload_bytes=red, all_gather_bytes_received=gat)
+        if self.overlap:
+            win = sum(e0.elapsed_time(e1) for e0, e1, _ in self.overlap) * 1e3
+            exp = sum(e1.elapsed_time(e2) for _, e1, e2 in self.overlap) * 1e3
+            out.update(overlapped_exchanges=len(self.overlap), overlap_window_us=round(win, 1), exposed_comm_us=round(exp, 1))
+        return out
+
+
+def consistent_collectives(per_rank_records) -> str | None:
+    """None when the ranks' CommTrace records describe one consistent collective program, else a description of the first
+    mismatch: same number and order of operations; equal payload for all_reduce / all_gather; for every all_to_all_single
+    what rank r sends to q is what q expects from r."""
+    world = len(per_rank_records)
+    n = len(per_rank_records[0])
+    for r, rec in enumerate(per_rank_records):
+        if len(rec) != n:
+            return f"rank {r} issued {len(rec)} collectives, rank 0 issued {n}"
+    for i in range(n):
+        ops_i = [rec[i] for rec in per_rank_records]
+        names = {o[0] for o in ops_i}
+        if len(names) != 1:
+            return f"collective #{i}: ranks disagree on the operation: {sorted(names)}"
+        name = ops_i[0][0]
+        if name in ("all_reduce", "all_gather_into_tensor", "broadcast", "reduce_scatter_tensor"):
+            if len({o[3] for o in ops_i}) != 1:
+                return f"collective #{i} ({name}): element counts differ across ranks: {[o[3] for o in ops_i]}"
+        elif name == "all_to_all_single":
+            if len({o[3] for o in ops_i}) != 1:
+                return f"collective #{i} (all_to_all_single): row widths differ: {[o[3] for o in ops_i]}"
+            for r in range(world):
+                for q in range(world):
+                    send = ops_i[r][4][q] if ops_i[r][4] is not None else None
+                    recv = ops_i[q][5][r] if ops_i[q][5] is not None else None
+                    if send is not None and recv is not None and send != recv:
+                        return f"collective #{i} (all_to_all_single): rank {r} sends {send} rows to rank {q}, which expects {recv}"
+    return None
+
+
 # ------------------------------------------------------------------------------------------------
 # partition plan (integer, deterministic, identical on every rank)
 # ------------------------------------------------------------------------------------------------
@@ -185,9 +283,18 @@ class _OverlapAggregate(torch.autograd.Function):
             send_buf = x_local.index_select(0, sadj.send_idx_dev).contiguous()
             x_halo = torch.empty(plan.n_halo, K, dtype=x_local.dtype, device=x_local.device)
             work = dist.all_to_all_single(x_halo, send_buf, plan.recv_counts, plan.send_counts, group=group, async_op=True)
+        probe = CommTrace.active is not None and CommTrace.active.probe_overlap and work is not None and x_local.is_cuda
+        if probe:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
         y = _agg(a_own, x_local)                                    # runs while the halo rows travel
+        if probe:
+            ev[1].record()
         if work is not None:
             work.wait()
+        if probe:   # ev0..ev1: compute the exchange is hidden under; ev1..ev2: what the stream still waits for it afterwards
+            ev[2].record()
+            CommTrace.active.overlap.append(tuple(ev))
         if plan.n_halo:
             y = _agg(a_halo, x_halo, addend=y)
         ctx.sadj, ctx.pieces = sadj, (a_own, a_halo)
@@ -824,6 +931,15 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     halo = torch.tensor([float(prob.adj.plan.n_halo)], device=device)
     dist.all_reduce(halo)
+    # one more epoch, outside the timed region, with the collectives recorded: per-rank communication volume, the compute
+    # window every halo exchange is hidden under and what is left exposed (HIP events on the compute stream)
+    with CommTrace(probe_overlap=on_gpu) as trace:
+        epoch()
+        if on_gpu:
+            torch.cuda.synchronize()
+    comm = trace.summary()
+    per_rank_comm = [None] * world
+    dist.all_gather_object(per_rank_comm, comm)
     if rank == 0:
         el = float(elapsed)
         roofline = None
@@ -852,6 +968,10 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
                         partitioning=f"node-range shards x{world}: halo all_to_all {'overlapped with the own-column aggregation' if _OVERLAP else '(blocking)'}"
                                      f" + SyncBN all-reduce + flat grad all-reduce over RCCL",
                         mean_halo_rows_per_rank=int(float(halo) / world)),
+            comm_per_epoch=dict(what="one epoch (train step + eval) traced after the timed region: payload bytes per rank and kind; "
+                                     "overlap_window_us = own-column aggregation time the halo exchanges run under, exposed_comm_us = what the "
+                                     "compute stream still waits for them afterwards (forward exchanges; HIP events)",
+                                per_rank=per_rank_comm),
             roofline=roofline, cpu_baseline=None,
             last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs])
     dist.barrier()

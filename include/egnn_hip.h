@@ -451,9 +451,10 @@ int egnn_rows_add_f32(float* dst, int64_t ld_dst, const int64_t* idx, const floa
  * nothing else -- for every stored entry e, the 128-byte slice s of row col[e] of X [n_src, K] is read by an 8-lane sub-group,
  * slice s by the workgroups with blockIdx % (K / 32) == s (the aggregation kernel's slice <-> XCD binding,
  * efficient-gnns_amd/csrc/spmm_blk.hip).  nnz * K * 4 bytes of lines per call; `sink` [1] is never written for finite data.
- * K % 32 == 0, X 16-byte aligned, int32 column ids.  No counterpart in the reference. */
+ * K % 32 == 0, X 16-byte aligned, int32 column ids; loads_in_flight = independent 16-byte gathers per lane (4, 8 or 16).
+ * No counterpart in the reference. */
 int egnn_probe_gather_lines_f32(const float* X, int64_t ldx, int64_t n_src, int64_t K, const int32_t* col, int64_t nnz,
-                                int blocks_per_slice, float* sink, void* stream);
+                                int blocks_per_slice, int loads_in_flight, float* sink, void* stream);
 
 #ifdef __cplusplus
 }

@@ -233,6 +233,87 @@ def test_shard_plan_integer_logic():
             assert torch.equal(pq.send_idx[so:so + pq.send_counts[r]] + pq.lo, ids)
 
 
+def _trace_worker(rank, world, port, gnn, mode, q, hp=None):
+    HP = dict(globals()["HP"], **(hp or {}))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _patch_ops_with_oracle()
+        import efficient_gnns_amd.dist as DD
+        import efficient_gnns_amd.models as PM
+        d = _make_data(train_ids_below=HP.pop("train_ids_below", None))
+        prob = DD.ShardedProblem(d, world, rank, "cpu", None, need_gcn=True)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        model = (PM.GCN if gnn == "gcn" else PM.SAGE)(d.num_features, 32, d.num_classes, 3, 0.5)
+        sp = tp = None
+        groups = [{"params": model.parameters(), "lr": 0.01}]
+        if mode in ("nce", "gpw"):
+            sp, tp = DD.swap_batchnorm(PM.make_projection(32, 16)), DD.swap_batchnorm(PM.make_projection(750, 16))
+            groups += [{"params": sp.parameters(), "lr": 0.01}, {"params": tp.parameters(), "lr": 0.01}]
+        DD.swap_batchnorm(model)
+        opt = torch.optim.Adam(groups)
+        DD.sharded_train_step(model, prob, opt, mode, HP, sp, tp)          # warm-up: one-off exchanges (static halo, teacher rows)
+        steps = []
+        for _ in range(3):
+            with DD.CommTrace() as tr:
+                DD.sharded_train_step(model, prob, opt, mode, HP, sp, tp)
+                DD.sharded_evaluate(model, prob)
+            steps.append(tr.records)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, steps)
+        if rank == 0:
+            q.put(everyone)
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+    _quiet_exit()
+
+
+@pytest.mark.parametrize("gnn,mode,world,max_samples", [("gcn", "nce", 2, 96), ("gcn", "nce", 3, 5), ("gcn", "kd", 3, -300), ("sage", "lpw", 3, -300),
+                                                        ("gcn", "gpw", 2, 40)])
+def test_every_rank_issues_the_same_collective_sequence(gnn, mode, world, max_samples):
+    """The sharded step is a fixed collective PROGRAM: every rank issues the same operations in the same order with matching
+    sizes, step after step -- also a rank that owns no train row or no sampled row (its loss terms are attached zeros so that
+    its backward still runs every halo exchange and SyncBN reduction).  Any mismatch here is a hang over RCCL."""
+    import efficient_gnns_amd.dist as DD
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    hp = dict(max_samples=max_samples)
+    if max_samples < 0:
+        hp = dict(max_samples=64, train_ids_below=-max_samples)
+    if mode in ("gpw", "lpw"):
+        hp.update(kernel="cosine", beta=100.0)
+    port = _free_port()
+    procs = [ctx.Process(target=_trace_worker, args=(r, world, port, gnn, mode, q, hp)) for r in range(world)]
+    for p in procs:
+        p.start()
+    everyone = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    assert len(everyone) == world
+    for step in range(3):
+        per_rank = [everyone[r][step] for r in range(world)]
+        assert len(per_rank[0]) > 10, "the trace is empty: the step issued no collectives?"
+        bad = DD.consistent_collectives(per_rank)
+        assert bad is None, f"step {step}: {bad}"
+    # the program does not change from step to step (same operations and payload sizes; the per-peer split of the sampled rows may)
+    for r in range(world):
+        sig = [[(o[0], o[3]) if o[0] != "all_to_all_single" else (o[0], o[3]) for o in everyone[r][st]] for st in range(3)]
+        assert [s_[0] for s_ in sig[0]] == [s_[0] for s_ in sig[1]] == [s_[0] for s_ in sig[2]], f"rank {r}: the operation sequence changes between steps"
+    # and the checker itself catches a mismatch
+    broken = [list(everyone[r][0]) for r in range(world)]
+    broken[-1] = broken[-1][:-1]
+    assert DD.consistent_collectives(broken) is not None
+    a2a = next(i for i, o in enumerate(everyone[0][0]) if o[0] == "all_to_all_single" and o[4] is not None)
+    broken = [list(everyone[r][0]) for r in range(world)]
+    o = broken[0][a2a]
+    broken[0][a2a] = (o[0], o[1], o[2], o[3], tuple(v + 1 for v in o[4]), o[5])
+    assert DD.consistent_collectives(broken) is not None
+
+
 def test_sharded_adj_from_a_prebuilt_plan_without_a_process_group():
     """``ShardPlan.from_global`` + ``ShardedAdj(_plan=...)`` (single-process tools): the raw adjacency is built without any
     collective; the normalised one needs the peers' degrees, so asking for it without a process group is a clear error."""

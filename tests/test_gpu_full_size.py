@@ -3,7 +3,10 @@
 One optimisation step (dropout 0) + the initial eval of every configuration at the size ``bench.py`` times it
 (N = 169 343, the synthetic arxiv-shaped graph), GPU path through the C ABI against the CPU oracle on the same seeds,
 NumPy draw and weights -- the very function ``bench.py`` prints as its ``parity`` object -- at the SURVEY 8(c) bars:
-losses rtol 1e-5 (G-CRD / GSP 2e-5), eval logits 1e-5 of max|ref|, parameter gradients rtol 1e-4 (+ 2e-5 max|ref|).
+losses rtol 1e-5 (G-CRD / GSP 2e-5), eval logits 1e-5 of max|ref|, parameter gradients rtol 1e-4 (+ 2e-5 max|ref|) against
+a FLOAT64 run of the oracle -- or not farther from it than 1.5 x the fp32 oracle itself: at 43 M pre-activations per layer a
+handful of ReLU inputs lie within rounding of zero and land on different sides in any two fp32 runs
+(``test_relu_mask_flips_explain_full_size_gradient_differences``).
 Then the LSP / GSP criteria alone at full size on features scaled so that the rbf similarities are O(1) (the student's
 hidden features at initialisation are ~20 apart: exp(-200) = 0 in fp32, in the reference as well, so inside a train step
 the rbf kernel exercises no student-side arithmetic), and the MAG-shaped SAGE-mean layer at N = 1 939 743.
@@ -57,13 +60,56 @@ def test_one_full_size_train_step_and_eval_vs_oracle(arxiv, name):
     gnn, mode, hp = CONFIGS[name]
     p = bench.parity_check(_args(gnn, mode), data, d, DEV, hp, PM)
     assert p["ok"], p
-    assert p["max_rel_err"] <= p["rtol"] and p["eval_logits_max_abs_err_over_max_abs"] <= 1e-5 and p["grads"]["worst_violation_of_bar"] <= 1.0
+    assert p["losses_ok"] and p["eval_logits_max_abs_err_over_max_abs"] <= 1e-5 and p["grads"]["worst_violation_of_bar"] <= 1.0
+    if not (mode == "lpw" and hp["kernel"] == "rbf"):   # (the KL of two nearly uniform distributions: judged against float64, see bench.parity_check)
+        assert p["max_rel_err"] <= p["rtol"], p
     if mode != "kd":
         assert p["loss_aux"]["cpu"] != 0.0, "a distillation term that is numerically zero compares nothing"
         if not (mode == "gpw" and hp["kernel"] == "rbf"):
             # (GSP-rbf between two BatchNorm-ed 128-d projections: ||a-b||^2 ~ 90, similarities ~1e-20, their squared
             # differences are fp32 denormals -- the value of record of run_gcn.sh:52-57, beta = 1e5 for that reason)
             assert abs(p["loss_aux"]["cpu"]) > 1e-6, p["loss_aux"]
+
+
+def test_relu_mask_flips_explain_full_size_gradient_differences(arxiv):
+    """Why full-size gradients are judged against float64 (bench.grad_errors): one GCN layer + BatchNorm + ReLU at N = 169 343,
+    K = 256.  Forward, BatchNorm gradients and everything with the SAME ReLU mask agree with a float64 torch evaluation to
+    ~1e-6; the few pre-activations within fp32 rounding of zero get the other sign in float64, and each flip moves dX at that
+    element by O(1) of its size and dW (a sum over N rows) by ~1 / sqrt(N).  Re-evaluating the float64 reference with the
+    GPU's own mask removes the difference: the kernels are right, the function has kinks."""
+    import efficient_gnns_amd.ops as ops
+    import torch.nn.functional as F
+    data, d = arxiv
+    N, C = data.num_nodes, 256
+    g = torch.Generator(device=DEV).manual_seed(5)
+    h = torch.randn(N, C, device=DEV, generator=g) + 0.5 * torch.randn(C, device=DEV, generator=g)
+    gy = torch.randn(N, C, device=DEV, generator=g) * (torch.rand(N, 1, device=DEV, generator=g) < 0.54)
+    conv = E.GCNConv(C, C, cached=True).to(DEV)
+    bn = torch.nn.BatchNorm1d(C).to(DEV)
+    hp = h.clone().requires_grad_(True)
+    z = conv(hp, d.adj_t, bn_stats_shift=bn.running_mean, want_bn_stats=True)
+    out = ops.bn_act(z, bn, relu=True, p=0.0, training=True)
+    out.backward(gy)
+    rowptr, col, val = E.gcn_norm(d.adj_t).csr()
+    A = torch.sparse_csr_tensor(rowptr, col, val.double(), size=(N, N))
+
+    def reference(mask):
+        hd = h.double().requires_grad_(True)
+        Wd, bd = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+        gam, bet = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+        y = F.batch_norm(torch.sparse.mm(A, hd @ Wd) + bd, None, None, gam, bet, True, 0.0, bn.eps)
+        o = torch.relu(y) if mask is None else y * mask
+        o.backward(gy.double())
+        return o, y, hd.grad, Wd.grad, gam.grad, bet.grad
+    o64, y64, dx64, dW64, dg64, db64 = reference(None)
+    flips = int(((out > 0) != (y64 > 0)).sum())
+    close(out, o64, rtol=1e-5, atol_scale=1e-5, msg="forward")
+    o_m, _, dx_m, dW_m, dg_m, db_m = reference((out > 0).double())          # the float64 reference with the GPU's ReLU mask
+    for name, a, b in (("dX", hp.grad, dx_m), ("dW", conv.weight.grad, dW_m), ("dgamma", bn.weight.grad, dg_m), ("dbeta", bn.bias.grad, db_m)):
+        close(a, b, rtol=1e-4, atol_scale=2e-5, msg=f"{name} with the same ReLU mask ({flips} of {N * C} mask entries differ from float64)")
+    # and the size of the effect when the masks differ: bounded by the number of flips, ~1/sqrt(N) each on dW
+    err_dw = float((conv.weight.grad.double() - dW64).abs().max() / dW64.abs().max())
+    assert err_dw <= max(2e-5, 4.0 * flips / np.sqrt(N)), (flips, err_dw)
 
 
 def _train_subgraph(data):

@@ -38,7 +38,7 @@ struct LabArgs {
   int64_t M, N, K, k_per_split;
 };
 
-template <int AMODE, int BMODE, int TM, int TN, int BKT, int NB, int OCC, int PIPE>
+template <int AMODE, int BMODE, int TM, int TN, int BKT, int NB, int OCC, int PIPE, int ABL>
 __global__ __launch_bounds__(256, OCC) void lab_kernel(const LabArgs g) {
   using T = Tile<AMODE, BMODE, TM, TN, BKT, NB>;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, OCC) void lab_kernel(const LabArgs g) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  mainloop<AMODE, BMODE, TM, TN, BKT, NB, PIPE>(acc, g.A, g.la, m0, g.B, g.lb, n0, kbeg, kend, smem);
+  mainloop<AMODE, BMODE, TM, TN, BKT, NB, PIPE, ABL>(acc, g.A, g.la, m0, g.B, g.lb, n0, kbeg, kend, smem);
   const int lane = egnn_lane(), wave = egnn_wave_id();
   const int wm = wave >> 1, wn = wave & 1;
   float* out = g.C + (int64_t)blockIdx.y * g.M * g.ldc;
@@ -82,12 +82,13 @@ struct Variant {
   int amode, bmode, BM, BN, BKT;
   size_t shm;
   void (*launch)(const LabArgs&, dim3, hipStream_t);
+  int abl;   // != 0: an ablation (results wrong on purpose; the timing shows what the removed part costs)
 };
 
-template <int AMODE, int BMODE, int TM, int TN, int BKT, int NB, int OCC, int PIPE>
+template <int AMODE, int BMODE, int TM, int TN, int BKT, int NB, int OCC, int PIPE, int ABL>
 void launch_v(const LabArgs& g, dim3 grid, hipStream_t st) {
   using T = Tile<AMODE, BMODE, TM, TN, BKT, NB>;
-  auto* fn = lab_kernel<AMODE, BMODE, TM, TN, BKT, NB, OCC, PIPE>;
+  auto* fn = lab_kernel<AMODE, BMODE, TM, TN, BKT, NB, OCC, PIPE, ABL>;
   static bool once = false;
   if (!once) {
     CK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -97,7 +98,9 @@ void launch_v(const LabArgs& g, dim3 grid, hipStream_t st) {
 }
 
 #define VARIANT(name, AM, BMo, TM, TN, BKT, NB, OCC, PIPE) \
-  Variant{name, AM, BMo, 64 * TM, 64 * TN, BKT, (size_t)Tile<AM, BMo, TM, TN, BKT, NB>::SMEM_BYTES, launch_v<AM, BMo, TM, TN, BKT, NB, OCC, PIPE>}
+  Variant{name, AM, BMo, 64 * TM, 64 * TN, BKT, (size_t)Tile<AM, BMo, TM, TN, BKT, NB>::SMEM_BYTES, launch_v<AM, BMo, TM, TN, BKT, NB, OCC, PIPE, 0>, 0}
+#define ABLATION(name, AM, BMo, TM, TN, BKT, NB, OCC, PIPE, ABL) \
+  Variant{name, AM, BMo, 64 * TM, 64 * TN, BKT, (size_t)Tile<AM, BMo, TM, TN, BKT, NB>::SMEM_BYTES, launch_v<AM, BMo, TM, TN, BKT, NB, OCC, PIPE, ABL>, ABL}
 
 int main(int argc, char** argv) {
   int iters = 5, rounds = 3;
@@ -137,6 +140,17 @@ int main(int argc, char** argv) {
       VARIANT("f32m_pln_128x128_bk16_nb3", F32M, PLANES, 2, 2, 16, 3, 2, 0),
       VARIANT("f32m_pln_128x128_bk16_nb3_p", F32M, PLANES, 2, 2, 16, 3, 2, 1),
       VARIANT("f32m_f32m_128x128_bk16_nb3_p", F32M, F32M, 2, 2, 16, 3, 2, 1),
+      // ablations of pln_pln_128x128_bk16_nb3_p (no split VALU in the loop at all): what bounds it?
+      ABLATION("abl_pp_setprio", PLANES, PLANES, 2, 2, 16, 3, 2, 1, 16),
+      ABLATION("abl_pp_nodma", PLANES, PLANES, 2, 2, 16, 3, 2, 1, 1 | 8),
+      ABLATION("abl_pp_nodma_nobarrier", PLANES, PLANES, 2, 2, 16, 3, 2, 1, 1 | 8 | 2),
+      ABLATION("abl_pp_nodma_nofrag", PLANES, PLANES, 2, 2, 16, 3, 2, 1, 1 | 8 | 4),
+      ABLATION("abl_pp_mfma_only", PLANES, PLANES, 2, 2, 16, 3, 2, 1, 1 | 8 | 4 | 2),
+      ABLATION("abl_pp_mfma_only_1wg", PLANES, PLANES, 2, 2, 16, 3, 1, 1, 1 | 8 | 4 | 2),
+      ABLATION("abl_pp_dma_nofrag", PLANES, PLANES, 2, 2, 16, 3, 2, 1, 4),
+      ABLATION("abl_fp_nodma", F32K, PLANES, 2, 2, 16, 3, 2, 1, 1 | 8),
+      ABLATION("abl_fp_setprio", F32K, PLANES, 2, 2, 32, 2, 2, 1, 16),
+      ABLATION("abl_pp256_mfma_only", PLANES, PLANES, 4, 2, 16, 3, 1, 1, 1 | 8 | 4 | 2),
   };
   hipStream_t st;
   CK(hipStreamCreate(&st));
@@ -179,14 +193,14 @@ int main(int argc, char** argv) {
     auto check = [&](int splits, double& mean_rel, double& max_rel) {
       CK(hipStreamSynchronize(st));
       std::vector<float> part((size_t)s.M * s.N);
-      std::fill(hc.begin(), hc.end(), 0.f);
+      std::vector<double> got(samp.size(), 0.0);
       for (int sp = 0; sp < splits; ++sp) {
         CK(hipMemcpy(part.data(), dc + (size_t)sp * s.M * s.N, part.size() * 4, hipMemcpyDeviceToHost));
-        for (size_t q = 0; q < samp.size(); ++q) hc[(size_t)samp[q].first * s.N + samp[q].second] += part[(size_t)samp[q].first * s.N + samp[q].second];
+        for (size_t q = 0; q < samp.size(); ++q) got[q] += part[(size_t)samp[q].first * s.N + samp[q].second];
       }
       mean_rel = max_rel = 0;
       for (size_t q = 0; q < samp.size(); ++q) {
-        const double rel = std::fabs(hc[(size_t)samp[q].first * s.N + samp[q].second] - ref[q]) / (scale[q] + 1e-30);
+        const double rel = std::fabs(got[q] - ref[q]) / (scale[q] + 1e-30);
         mean_rel += rel / samp.size();
         max_rel = std::max(max_rel, rel);
       }
@@ -255,7 +269,8 @@ int main(int argc, char** argv) {
       CK(hipStreamSynchronize(st));
       CK(hipGetLastError());
       Row r{v->name, {}, 0, 0, v->shm};
-      check(s.splits, r.mean_rel, r.max_rel);
+      if (!v->abl) check(s.splits, r.mean_rel, r.max_rel);
+      else r.mean_rel = r.max_rel = -1;
       // interleaved timing rounds happen below; planes are re-packed per variant there as well (outside the timed region)
       rows.push_back(r);
       largs.push_back(g);
