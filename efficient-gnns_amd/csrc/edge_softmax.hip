@@ -101,8 +101,9 @@ __global__ __launch_bounds__(256) void seg_softmax_fwd_kernel(const int64_t* __r
     float z = 0.f;
     for (int64_t i = b + lane; i < e; i += 64) z += expf(x[i] - m);
     z = egnn_wave_sum(z);
-    const float inv = 1.f / (z + 1e-16f);  // PyG: out / (sum + 1e-16)
-    for (int64_t i = b + lane; i < e; i += 64) p[i] = expf(x[i] - m) * inv;
+    const float den = z + 1e-16f;  // PyG: out / (sum + 1e-16) -- a DIVISION per entry as in the reference (one rounding; e * (1 / den) has two,
+                                   // which shows in the KL of two nearly uniform distributions, a difference of O(1) sums)
+    for (int64_t i = b + lane; i < e; i += 64) p[i] = expf(x[i] - m) / den;
   }
 }
 

@@ -277,16 +277,19 @@ __host__ __device__ inline size_t planes_bytes(int64_t rows, int64_t K, int RB, 
 }
 
 // X(r, k): k_major = 1 -> X[r * ld + k], else X[k * ld + r].  One thread per 16-byte output chunk (8 k-values of one row);
-// rows / k past the end are zero planes.  scale (nullable): per-row factor applied before the cut (w_i of the G-CRD backward).
+// rows / k past the end are zero planes.  Optional factors applied before the cut: scale[row] (per operand row) and
+// exp(kshift - klse[k]) (per k: the row weights w_i of the G-CRD backward, criterion.py:139-145 via nce.hip).  ridx: row gather.
 template <int RB, int BKT>
 __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restrict__ X, int64_t ld, int k_major, int64_t rows, int64_t K,
-                                                          const float* __restrict__ scale, const int64_t* __restrict__ ridx, char* __restrict__ out) {
+                                                          const float* __restrict__ scale, const int64_t* __restrict__ ridx,
+                                                          const float* __restrict__ klse, float kshift, char* __restrict__ out) {
   using S = Stage<PLANES, RB, BKT>;
   const int64_t nks = (K + BKT - 1) / BKT, nrb = (rows + RB - 1) / RB;
   const int64_t total = nrb * nks * RB * S::CHP;
   for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    const int c = (int)(t % S::CHP);
-    const int r = (int)((t / S::CHP) % RB);
+    // consecutive threads walk the contiguous direction of X: chunks of one row (k-major) or rows of one chunk
+    const int c = k_major ? (int)(t % S::CHP) : (int)((t / RB) % S::CHP);
+    const int r = k_major ? (int)((t / S::CHP) % RB) : (int)(t % RB);
     const int64_t unit = t / (S::CHP * RB), ks = unit % nks, rb = unit / nks;
     const int64_t row = rb * RB + r, k0 = ks * BKT + c * 8;
     float v[8];
@@ -295,7 +298,12 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int64_t k = k0 + j;
-      v[j] = (row < rows && k < K) ? sc * (k_major ? X[rs * ld + k] : X[k * ld + rs]) : 0.f;
+      float x = 0.f;
+      if (row < rows && k < K) {
+        x = sc * (k_major ? X[rs * ld + k] : X[k * ld + rs]);
+        if (klse) x *= expf(kshift - klse[k]);
+      }
+      v[j] = x;
     }
     u32x4 p0, p1, p2;
     split8(v, p0, p1, p2);
@@ -304,6 +312,15 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restric
     *reinterpret_cast<u32x4*>(o + RB * BKT * 2) = p1;
     *reinterpret_cast<u32x4*>(o + 2 * RB * BKT * 2) = p2;
   }
+}
+
+template <int RB, int BKT>
+static inline void pack_planes(const float* X, int64_t ld, int k_major, int64_t rows, int64_t K, const float* scale, const int64_t* ridx,
+                               const float* klse, float kshift, char* out, hipStream_t st) {
+  const int64_t total = ((rows + RB - 1) / RB) * ((K + BKT - 1) / BKT) * RB * (BKT / 8);
+  const int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL((pack_planes_kernel<RB, BKT>), dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, X, ld, k_major, rows, K,
+                     scale, ridx, klse, kshift, out);
 }
 
 }  // namespace egnn_gemm3

@@ -17,7 +17,7 @@
 //                  i.e. two plain GEMMs on E with a row scale on one side (one exp per 4 staged elements of fhat).
 #include <stdlib.h>
 
-#include "gemm_split.h"
+#include "gemm3.h"
 
 using namespace egnn_gemm;
 
@@ -476,10 +476,108 @@ inline int nce_bwd_split(int64_t M, int64_t P, int64_t Kd) {
   return n < 1 ? 1 : (int)n;
 }
 
+// ---- unit-rows backward on the DMA pipeline (gemm3.h) ----------------------------------------------------------------------
+// Both backward products have E (fp32, [Sr, Sc], written by the forward) as their big operand and a [S, P] matrix of unit rows
+// as the small one.  The small operand is cut ONCE per call into tile-packed bf16 planes (T^ as it is for the student side,
+// the rows of F^ weighted by w_i for the teacher side) and streamed by lane-linear DMA; E goes global -> LDS by DMA as fp32 and
+// is cut on the fragment side, as rows (student side: A = E, k contiguous) or down columns (teacher side: A = E^T, the [k][m]
+// image read with ds_read_b32).  No staging registers, no ds_write pass, no split VALU for the small operand.  Partials of the
+// split reduction go to the workspace; nce_bwd_reduce_kernel adds them in a fixed order and applies the epilogue.
+//   student side: 128 x 128 tiles, k-steps of 32, two LDS stages (lab: 705 vs 795 us at S = 16384, P = 256)
+//   teacher side: 256 x 256 tiles, four waves of 128 x 128, k-steps of 16, three LDS stages (667 vs 810 us)
+template <int AMODE, int TM, int TN, int BKT, int NB, int OCC>
+__global__ __launch_bounds__(256, OCC) void nce3_bwd_kernel(const float* __restrict__ E, int64_t lde, const char* __restrict__ planes, int64_t nks,
+                                                            int64_t M, int64_t P, int64_t k_per_split, float* __restrict__ ws) {
+  using T = egnn_gemm3::Tile<AMODE, egnn_gemm3::PLANES, TM, TN, BKT, NB>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int64_t tiles_n = P / T::BN;
+  int64_t tile = blockIdx.x;
+  if (tiles_n > 1 && tiles_n <= 8) {   // the column tiles of a row tile follow each other on ONE XCD (they share the E tile)
+    const int64_t tiles = gridDim.x, q = tiles >> 3, rem = tiles & 7, xcd = tile & 7, j = tile >> 3;
+    tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + j;
+  }
+  const int64_t m0 = (tile / tiles_n) * T::BM, n0 = (tile % tiles_n) * T::BN;
+  const int64_t kbeg = (int64_t)blockIdx.y * k_per_split, kend = kbeg + k_per_split;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  egnn_gemm3::mainloop<AMODE, egnn_gemm3::PLANES, TM, TN, BKT, NB, 1>(acc, E, lde, m0, planes, nks, n0, kbeg, kend, reinterpret_cast<char*>(smem));
+  const int lane = egnn_lane(), wave = egnn_wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  float* out = ws + (int64_t)blockIdx.y * M * P;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int64_t c = n0 + wn * 32 * TN + tn * 32 + (lane & 31);
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        out[row * P + c] = acc[tm][tn][r];
+      }
+  }
+}
+
+constexpr int kNce3Split = 8;   // k ranges of the reduction (fixed-order reduce afterwards)
+
+// floats of workspace the DMA backward needs for one side: partials + the packed planes of the small operand (+ slack for alignment)
+inline size_t nce3_ws_floats(int64_t M, int64_t P, int64_t Kd) {
+  return (size_t)kNce3Split * M * P + (egnn_gemm3::planes_bytes(P, Kd, 256, 32) + 1024) / 4;
+}
+
+// true when this side of the backward can take the DMA pipeline (whole tiles, aligned E, unit-rows form with a workspace)
+template <int AMAJ>
+inline bool nce3_takes(int64_t M, int64_t Kd, int64_t P, int64_t ldz, const float* Z, bool expz, bool vec4, const float* ws) {
+  static const bool off = getenv("EGNN_NCE_DMA") && getenv("EGNN_NCE_DMA")[0] == '0';   // A/B switch: EGNN_NCE_DMA=0 keeps the staged pipeline
+  constexpr int BM = AMAJ == KMAJOR ? 128 : 256, BN = AMAJ == KMAJOR ? 128 : 256, BKT = AMAJ == KMAJOR ? 32 : 16;
+  return !off && egnn_split_pipe() && expz && vec4 && ws && M % BM == 0 && P % BN == 0 && Kd % (kNce3Split * BKT) == 0 && ldz % 4 == 0 &&
+         egnn_aligned16(Z) && Kd / kNce3Split >= 4 * BKT;
+}
+
+template <int AMAJ>
+int launch_bwd3(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag_off, const float* lse, float shift, const float* Bm, int64_t P,
+                int64_t ldb, const float* Im, int64_t ldi, float coef, const float* g, float* C, int64_t ldc, float* ws, hipStream_t st) {
+  using namespace egnn_gemm3;
+  float* partial = ws;
+  char* planes = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws + (size_t)kNce3Split * M * P) + 1023) & ~(uintptr_t)1023);
+  const int64_t k_per_split = Kd / kNce3Split;
+  int rc;
+  if constexpr (AMAJ == KMAJOR) {
+    // student side: C = E T^ ; B(k = j, n = p) = T^[j, p]  ->  planes of T^ transposed (rows p, k = j)
+    constexpr int TM = 2, TN = 2, BKT = 32, NB = 2;
+    pack_planes<64 * TN, BKT>(Bm, ldb, 0, P, Kd, nullptr, nullptr, nullptr, 0.f, planes, st);
+    using T = Tile<F32K, PLANES, TM, TN, BKT, NB>;
+    const dim3 grid((unsigned)((M / T::BM) * (P / T::BN)), (unsigned)kNce3Split);
+    rc = launch_dyn_lds<nce3_bwd_kernel<F32K, TM, TN, BKT, NB, 2>>(grid, dim3(256), (size_t)T::SMEM_BYTES, st, Z, ldz, (const char*)planes, Kd / BKT, M, P,
+                                                                   k_per_split, partial);
+  } else {
+    // teacher side: C = E^T (w o F^) ; A(m = j, k = i) = E[i, j] ; B(k = i, n = p) = w_i F^[i, p]  ->  planes of (w o F^) transposed
+    constexpr int TM = 4, TN = 4, BKT = 16, NB = 3;
+    pack_planes<64 * TN, BKT>(Bm, ldb, 0, P, Kd, nullptr, nullptr, lse, shift, planes, st);
+    using T = Tile<F32M, PLANES, TM, TN, BKT, NB>;
+    const dim3 grid((unsigned)((M / T::BM) * (P / T::BN)), (unsigned)kNce3Split);
+    rc = launch_dyn_lds<nce3_bwd_kernel<F32M, TM, TN, BKT, NB, 1>>(grid, dim3(256), (size_t)T::SMEM_BYTES, st, Z, ldz, (const char*)planes, Kd / BKT, M, P,
+                                                                   k_per_split, partial);
+  }
+  if (rc != EGNN_OK) return rc;
+  const int64_t rb = (M * P + 255) / 256;
+  hipLaunchKernelGGL((nce_bwd_reduce_kernel<AMAJ, true>), dim3((unsigned)(rb < 4096 ? rb : 4096)), dim3(256), 0, st, partial, kNce3Split, M, P, Kd,
+                     diag_off, lse, shift, Im, ldi, coef, g, C, ldc);
+  return EGNN_OK;
+}
+
 template <int AMAJ>
 void launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag_off, const float* lse, float shift, bool expz,
                 const float* Bm, int64_t P, int64_t ldb, const float* Im, int64_t ldi, float coef, const float* g, float* C,
                 int64_t ldc, bool vec4, float* ws, hipStream_t st) {
+  if (nce3_takes<AMAJ>(M, Kd, P, ldz, Z, expz, vec4, ws)) {
+    launch_bwd3<AMAJ>(Z, ldz, M, Kd, diag_off, lse, shift, Bm, P, ldb, Im, ldi, coef, g, C, ldc, ws, st);
+    return;
+  }
   const int64_t tiles_n = (P + 127) / 128;
   const int64_t t128 = ((M + 127) / 128) * tiles_n;
   // With a workspace the reduction is split so that every CU gets ~3 workgroups of 128 x 128 (fixed-order reduce
@@ -537,7 +635,10 @@ extern "C" size_t egnn_nce_ws_floats(int64_t S) { return (size_t)S * (1 + 2 * kM
 extern "C" size_t egnn_nce_bwd_ws_floats(int64_t Sr, int64_t Sc, int64_t P) {
   if (Sr <= 0 || Sc <= 0 || P <= 0) return 0;
   const size_t a = (size_t)nce_bwd_split(Sr, P, Sc) * Sr * P, b = (size_t)nce_bwd_split(Sc, P, Sr) * Sc * P;
-  return (a > b ? a : b) + (size_t)Sr * P;   // split-K partials + the weighted student rows of the teacher-side GEMM
+  const size_t staged = (a > b ? a : b) + (size_t)Sr * P;   // split-K partials + the weighted student rows of the teacher-side GEMM
+  const size_t a3 = nce3_ws_floats(Sr, P, Sc), b3 = nce3_ws_floats(Sc, P, Sr);   // the DMA pipeline's partials + packed planes
+  const size_t dma = a3 > b3 ? a3 : b3;
+  return staged > dma ? staged : dma;
 }
 
 extern "C" int egnn_nce_saves_exp(float tau, int unit_rows) { return tau > 0.f && nce_unit_form(tau, unit_rows) ? 1 : 0; }

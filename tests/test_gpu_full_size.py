@@ -13,6 +13,7 @@ the rbf kernel exercises no student-side arithmetic), and the MAG-shaped SAGE-me
 
 Reference: arxiv_pyg/criterion.py:57-126, scripts/run_gcn.sh:52-94,140-145, run_sage.sh:96-138, mag_pyg/gnn.py:151,162.
 """
+import json
 import types
 
 import numpy as np
@@ -59,7 +60,7 @@ def test_one_full_size_train_step_and_eval_vs_oracle(arxiv, name):
     data, d = arxiv
     gnn, mode, hp = CONFIGS[name]
     p = bench.parity_check(_args(gnn, mode), data, d, DEV, hp, PM)
-    assert p["ok"], p
+    assert p["ok"], json.dumps(p)
     assert p["losses_ok"] and p["eval_logits_max_abs_err_over_max_abs"] <= 1e-5 and p["grads"]["worst_violation_of_bar"] <= 1.0
     if not (mode == "lpw" and hp["kernel"] == "rbf"):   # (the KL of two nearly uniform distributions: judged against float64, see bench.parity_check)
         assert p["max_rel_err"] <= p["rtol"], p

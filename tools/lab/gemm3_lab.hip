@@ -77,6 +77,21 @@ __global__ __launch_bounds__(256, OCC) void lab_kernel(const LabArgs g) {
 
 struct Shape { const char* name; int64_t M, N, K; int splits; };
 
+// `only` = comma-separated substrings; true when `name` contains one of them (or no filter is given)
+static bool selected(const char* name, const char* only) {
+  if (!only) return true;
+  std::string o(only);
+  size_t pos = 0;
+  while (pos <= o.size()) {
+    const size_t c = o.find(',', pos);
+    const std::string tok = o.substr(pos, c == std::string::npos ? std::string::npos : c - pos);
+    if (!tok.empty() && strstr(name, tok.c_str())) return true;
+    if (c == std::string::npos) break;
+    pos = c + 1;
+  }
+  return false;
+}
+
 struct Variant {
   const char* name;
   int amode, bmode, BM, BN, BKT;
@@ -140,6 +155,17 @@ int main(int argc, char** argv) {
       VARIANT("f32m_pln_128x128_bk16_nb3", F32M, PLANES, 2, 2, 16, 3, 2, 0),
       VARIANT("f32m_pln_128x128_bk16_nb3_p", F32M, PLANES, 2, 2, 16, 3, 2, 1),
       VARIANT("f32m_f32m_128x128_bk16_nb3_p", F32M, F32M, 2, 2, 16, 3, 2, 1),
+      // 256 x 256 block tiles, four waves of 128 x 128 (256 accumulator registers, one wave per SIMD): half the L2 -> LDS bytes per FLOP
+      VARIANT("pln_pln_256x256_bk16_nb3", PLANES, PLANES, 4, 4, 16, 3, 1, 0),
+      VARIANT("pln_pln_256x256_bk16_nb3_p", PLANES, PLANES, 4, 4, 16, 3, 1, 1),
+      VARIANT("f32k_pln_256x256_bk16_nb3", F32K, PLANES, 4, 4, 16, 3, 1, 0),
+      VARIANT("f32k_pln_256x256_bk16_nb3_p", F32K, PLANES, 4, 4, 16, 3, 1, 1),
+      VARIANT("f32k_f32k_256x256_bk16_nb3", F32K, F32K, 4, 4, 16, 3, 1, 0),
+      VARIANT("f32k_f32k_256x256_bk16_nb4_p", F32K, F32K, 4, 4, 16, 4, 1, 1),
+      VARIANT("f32k_f32k_256x256_bk32_nb2_p", F32K, F32K, 4, 4, 32, 2, 1, 1),
+      VARIANT("f32m_pln_256x256_bk16_nb3_p", F32M, PLANES, 4, 4, 16, 3, 1, 1),
+      VARIANT("f32m_f32m_256x256_bk16_nb3_p", F32M, F32M, 4, 4, 16, 3, 1, 1),
+      VARIANT("f32k_f32k_256x128_bk16_nb3", F32K, F32K, 4, 2, 16, 3, 2, 0),
       // ablations of pln_pln_128x128_bk16_nb3_p (no split VALU in the loop at all): what bounds it?
       ABLATION("abl_pp_setprio", PLANES, PLANES, 2, 2, 16, 3, 2, 1, 16),
       ABLATION("abl_pp_nodma", PLANES, PLANES, 2, 2, 16, 3, 2, 1, 1 | 8),
@@ -156,7 +182,7 @@ int main(int argc, char** argv) {
   CK(hipStreamCreate(&st));
   std::mt19937 rng(11);
   for (const Shape& s : shapes) {
-    if (only_shape && !strstr(s.name, only_shape)) continue;
+    if (!selected(s.name, only_shape)) continue;
     std::vector<float> ha((size_t)s.M * s.K), hb((size_t)s.N * s.K);
     std::normal_distribution<float> nd(0.f, 1.f);
     for (auto& v : ha) v = nd(rng) * std::exp2f((float)(rng() % 12) - 6.f);   // twelve binades inside every dot product
@@ -175,7 +201,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dat, hat.data(), ha.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dbt, hbt.data(), hb.size() * 4, hipMemcpyHostToDevice));
     CK(hipMalloc(&dc, (size_t)s.splits * s.M * s.N * 4));
-    const size_t pa_cap = planes_bytes(s.M, s.K, 128, 16) + (1 << 20), pb_cap = planes_bytes(s.N, s.K, 128, 16) + (1 << 20);
+    const size_t pa_cap = planes_bytes(s.M, s.K, 256, 32) + (1 << 20), pb_cap = planes_bytes(s.N, s.K, 256, 32) + (1 << 20);
     CK(hipMalloc(&pa, pa_cap)); CK(hipMalloc(&pb, pb_cap));
     std::vector<float> hc((size_t)s.M * s.N);
     std::vector<std::pair<int64_t, int64_t>> samp;
@@ -226,7 +252,7 @@ int main(int argc, char** argv) {
       int rc = egnn_gemm_f32(0, 1, s.M, s.N, s.K, 1.f, da, s.K, db, s.K, nullptr, dc, s.N, s.splits, dws, wsf * 4, st);
       if (rc) { fprintf(stderr, "egnn_gemm_f32 rc=%d\n", rc); exit(3); }
     };
-    if (!only || strstr("shipped", only)) {
+    if (selected("shipped", only)) {
       CK(hipMemsetAsync(dc, 0, (size_t)s.M * s.N * 4, st));
       run_ref();
       Row r{"shipped_egnn_gemm_f32", {}, 0, 0, 0};
@@ -238,7 +264,7 @@ int main(int argc, char** argv) {
     std::vector<LabArgs> largs;
     std::vector<dim3> grids;
     for (const Variant& v : variants) {
-      if (only && !strstr(v.name, only)) continue;
+      if (!selected(v.name, only)) continue;
       if (s.M % v.BM || s.N % v.BN || (s.K / s.splits) % v.BKT) continue;
       act.push_back(&v);
     }
@@ -251,10 +277,10 @@ int main(int argc, char** argv) {
       auto pack = [&](const float* X, int64_t rows_, int RB, char* dst) {
         const int64_t total = ((rows_ + RB - 1) / RB) * nks * RB * (v->BKT / 8);
         const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535);
-        if (RB == 128 && v->BKT == 16) hipLaunchKernelGGL((pack_planes_kernel<128, 16>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, dst);
-        else if (RB == 128 && v->BKT == 32) hipLaunchKernelGGL((pack_planes_kernel<128, 32>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, dst);
-        else if (RB == 256 && v->BKT == 16) hipLaunchKernelGGL((pack_planes_kernel<256, 16>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, dst);
-        else if (RB == 256 && v->BKT == 32) hipLaunchKernelGGL((pack_planes_kernel<256, 32>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, dst);
+        if (RB == 128 && v->BKT == 16) hipLaunchKernelGGL((pack_planes_kernel<128, 16>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, nullptr, 0.f, dst);
+        else if (RB == 128 && v->BKT == 32) hipLaunchKernelGGL((pack_planes_kernel<128, 32>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, nullptr, 0.f, dst);
+        else if (RB == 256 && v->BKT == 16) hipLaunchKernelGGL((pack_planes_kernel<256, 16>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, nullptr, 0.f, dst);
+        else if (RB == 256 && v->BKT == 32) hipLaunchKernelGGL((pack_planes_kernel<256, 32>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, nullptr, 0.f, dst);
         else { fprintf(stderr, "no packer for RB=%d BK=%d\n", RB, v->BKT); exit(4); }
       };
       if (v->amode == PLANES) { pack(da, s.M, v->BM, pa); g.A = pa; g.la = nks; }
@@ -278,7 +304,7 @@ int main(int argc, char** argv) {
     }
     for (int rd = 0; rd < rounds; ++rd) {
       size_t ri = 0;
-      if (!only || strstr("shipped", only)) rows[ri++].us.push_back(time_it(run_ref));
+      if (selected("shipped", only)) rows[ri++].us.push_back(time_it(run_ref));
       for (size_t vi = 0; vi < act.size(); ++vi, ++ri) {
         const Variant* v = act[vi];
         // re-pack: variants with the same mode but another (RB, BK) share the plane buffers
@@ -287,10 +313,10 @@ int main(int argc, char** argv) {
         auto pack = [&](const float* X, int64_t rows_, int RB, char* dst) {
           const int64_t total = ((rows_ + RB - 1) / RB) * nks * RB * (v->BKT / 8);
           const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 65535);
-          if (RB == 128 && v->BKT == 16) hipLaunchKernelGGL((pack_planes_kernel<128, 16>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, dst);
-          else if (RB == 128 && v->BKT == 32) hipLaunchKernelGGL((pack_planes_kernel<128, 32>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, dst);
-          else if (RB == 256 && v->BKT == 16) hipLaunchKernelGGL((pack_planes_kernel<256, 16>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, dst);
-          else hipLaunchKernelGGL((pack_planes_kernel<256, 32>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, dst);
+          if (RB == 128 && v->BKT == 16) hipLaunchKernelGGL((pack_planes_kernel<128, 16>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, nullptr, 0.f, dst);
+          else if (RB == 128 && v->BKT == 32) hipLaunchKernelGGL((pack_planes_kernel<128, 32>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, nullptr, 0.f, dst);
+          else if (RB == 256 && v->BKT == 16) hipLaunchKernelGGL((pack_planes_kernel<256, 16>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, nullptr, 0.f, dst);
+          else hipLaunchKernelGGL((pack_planes_kernel<256, 32>), dim3(blocks), dim3(256), 0, st, X, s.K, 1, rows_, s.K, nullptr, nullptr, nullptr, 0.f, dst);
         };
         if (v->amode == PLANES) pack(da, s.M, v->BM, pa);
         if (v->bmode == PLANES) pack(db, s.N, v->BN, pb);
