@@ -35,9 +35,20 @@ def _sample_rows(n: int, max_samples: int, device):
     return None
 
 
+# The public criteria keep the reference's signatures exactly.  Each has a ``rows_*`` twin (an extension; the reference has no
+# such thing) that takes the FULL [N, .] ``logits`` / ``labels`` (/ ``teacher_logits``) plus the row ids: the classification / KD
+# terms are evaluated on those rows inside the kernels -- the ``[train_idx]`` gathers of gnn.py:109-110,121 and the zero-fill +
+# scatter of their backward never exist.  ``models.train_step`` uses the twins.
+
+
 def kd_criterion(logits, labels, teacher_logits, alpha=0.9, T=4):
     """Logit KD (criterion.py:8-21): CE + KL(softmax(teacher/T) || softmax(logits/T)) with reduction='mean'."""
-    loss_cls, loss_kd = ops.ce_and_kd(logits, labels, teacher_logits, T)
+    return rows_kd_criterion(logits, labels, teacher_logits, alpha, T, rows=None)
+
+
+def rows_kd_criterion(logits, labels, teacher_logits, alpha=0.9, T=4, rows=None):
+    """``kd_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
+    loss_cls, loss_kd = ops.ce_and_kd(logits, labels, teacher_logits, T, rows)
     loss = loss_kd * (alpha * T * T) + loss_cls * (1 - alpha)
     return loss, loss_cls, loss_kd
 
@@ -49,7 +60,12 @@ def loss_kd_only(logits, labels, teacher_logits, alpha=0.9, T=4):
 
 def fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000):
     """FitNet (criterion.py:24-36): MSE between L2-normalised rows."""
-    loss_cls = ops.cross_entropy(logits, labels)
+    return rows_fitnet_criterion(logits, labels, feat, teacher_feat, beta, rows=None)
+
+
+def rows_fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=None):
+    """``fitnet_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
+    loss_cls = ops.cross_entropy(logits, labels, rows)
     diff = ops.gather_normalize(feat) - ops.gather_normalize(teacher_feat)
     loss_aux = (diff * diff).mean()
     return loss_cls + beta * loss_aux, loss_cls, loss_aux
@@ -57,7 +73,12 @@ def fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000):
 
 def at_criterion(logits, labels, feat, teacher_feat, beta=1000):
     """Attention transfer (criterion.py:39-54): per-node energies, L2-normalised ACROSS nodes."""
-    loss_cls = ops.cross_entropy(logits, labels)
+    return rows_at_criterion(logits, labels, feat, teacher_feat, beta, rows=None)
+
+
+def rows_at_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=None):
+    """``at_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
+    loss_cls = ops.cross_entropy(logits, labels, rows)
     e_s = (feat * feat).sum(-1)
     e_t = (teacher_feat * teacher_feat).sum(-1)
     d = e_s / e_s.norm().clamp_min(1e-12) - e_t / e_t.norm().clamp_min(1e-12)
@@ -67,10 +88,15 @@ def at_criterion(logits, labels, feat, teacher_feat, beta=1000):
 
 def gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, max_samples=8192):
     """GSP (criterion.py:57-92): MSE between all-pairs similarity matrices of student and teacher rows."""
+    return rows_gpw_criterion(logits, labels, feat, teacher_feat, kernel, beta, max_samples, rows=None)
+
+
+def rows_gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, max_samples=8192, rows=None):
+    """``gpw_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
     from .ops_pairwise import gsp_loss
     if kernel not in ("cosine", "poly", "l2", "rbf"):
         raise NotImplementedError
-    loss_cls = ops.cross_entropy(logits, labels)
+    loss_cls = ops.cross_entropy(logits, labels, rows)
     idx = _sample_rows(feat.shape[0], max_samples, feat.device)
     loss_aux = gsp_loss(feat, teacher_feat, idx, kernel)
     return loss_cls + beta * loss_aux, loss_cls, loss_aux
@@ -78,17 +104,27 @@ def gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, m
 
 def lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="cosine", beta=100, criterion="kld"):
     """LSP (criterion.py:95-126): per-edge similarity, softmax over the edges sharing ``dst``, KL or MSE."""
+    return rows_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel, beta, criterion, rows=None)
+
+
+def rows_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="cosine", beta=100, criterion="kld", rows=None):
+    """``lpw_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
     from .ops_edge import lsp_loss
     if kernel not in ("cosine", "poly", "l2", "rbf") or criterion not in ("kld", "mse"):
         raise NotImplementedError
-    loss_cls = ops.cross_entropy(logits, labels)
+    loss_cls = ops.cross_entropy(logits, labels, rows)
     loss_aux = lsp_loss(feat, teacher_feat, edge_index, kernel, criterion)
     return loss_cls + beta * loss_aux, loss_cls, loss_aux
 
 
 def nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max_samples=8192):
     """G-CRD (criterion.py:129-149): InfoNCE between unit student rows and unit teacher rows."""
-    loss_cls = ops.cross_entropy(logits, labels)
+    return rows_nce_criterion(logits, labels, feat, teacher_feat, beta, nce_T, max_samples, rows=None)
+
+
+def rows_nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max_samples=8192, rows=None):
+    """``nce_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
+    loss_cls = ops.cross_entropy(logits, labels, rows)
     idx = _sample_rows(feat.shape[0], max_samples, feat.device)
     fhat = ops.gather_normalize(feat, idx)
     that = ops.gather_normalize(teacher_feat, idx)

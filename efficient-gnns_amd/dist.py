@@ -641,6 +641,7 @@ class ShardedProblem:
         self.adj = ShardedAdj((rowptr[lo:hi + 1] - e0), col[e0:e1], n, world, rank, device, group, with_gcn=need_gcn)
         self._rows_cpu = ((rowptr[lo:hi + 1] - e0).clone(), col[e0:e1].clone(), data.split_idx["train"].clone())   # for the LSP subgraph plan
         self._train_sub = None
+        self.sample_hook = None          # ShardedGraphedEpoch: static device buffer instead of the per-step host draw + upload
         self.x = data.x[lo:hi].to(device)
         self.adj.register_static(self.x)          # input features never change: halo copy fetched once
         self.y = data.y[lo:hi].to(device)
@@ -719,8 +720,43 @@ def _flat_grads_of(optimizer) -> FlatGrads:
     return fg
 
 
+def _sampled_rows(prob: ShardedProblem, S: int, dev):
+    """criterion.py:62-65,134-137 on shards: ONE np.random.choice over the GLOBAL train list (the same draw on every rank), then
+    (local positions of the rows this rank owns, as a device tensor; rows per rank).  ``prob.sample_hook`` (ShardedGraphedEpoch)
+    replaces the host draw + upload by a static device buffer refilled before every replay."""
+    if prob.sample_hook is not None:
+        return prob.sample_hook(S)
+    ntr = prob.n_train_global
+    pick = np.random.choice(ntr, S, replace=False) if S < ntr else np.arange(ntr)
+    pick_t = torch.from_numpy(pick)
+    owner = prob.train_owner[pick_t]
+    counts = torch.bincount(owner, minlength=prob.world).tolist()
+    return prob.train_localpos[pick_t[owner == prob.rank]].to(dev), counts
+
+
+def finish_losses(vals, mode: str, hp: dict):
+    """(loss, loss_cls, loss_aux) of the GLOBAL problem from the three reduced numbers of ``sharded_train_step_tensors``."""
+    aux_is_global = mode in ("nce", "gpw")
+    loss_cls_g = vals[0]
+    loss_aux_g = vals[2] if aux_is_global else vals[1]
+    if mode == "kd":
+        loss_g = loss_aux_g * (hp["alpha"] * hp["kd_T"] ** 2) + loss_cls_g * (1 - hp["alpha"])
+    elif mode in ("nce", "gpw", "lpw"):
+        loss_g = loss_cls_g + hp["beta"] * loss_aux_g
+    else:
+        loss_g = loss_cls_g
+    return loss_g, loss_cls_g, loss_aux_g
+
+
 def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: dict, student_proj=None, teacher_proj=None):
     """The reference's ``train()`` (gnn.py:102-195) on one shard; returns the GLOBAL (loss, loss_cls, loss_aux)."""
+    rep = sharded_train_step_tensors(model, prob, optimizer, mode, hp, student_proj, teacher_proj)
+    return finish_losses(rep.tolist(), mode, hp)                 # one device->host read per step
+
+
+def sharded_train_step_tensors(model, prob: ShardedProblem, optimizer, mode: str, hp: dict, student_proj=None, teacher_proj=None):
+    """The step without its host read: forward, loss, backward, gradient all-reduce, Adam, and the all-reduce of the loss terms;
+    returns the device tensor [loss_cls, loss_aux (sum over ranks), loss_aux (already global for nce / gpw)]."""
     from . import criterion as C
     model.train()
     for p in (student_proj, teacher_proj):
@@ -755,14 +791,7 @@ def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: di
         else:
             f = student_proj(take(model.out_feat, prob.train_local))
             t = teacher_proj(take(prob.teacher_out_feat, prob.train_local))
-        S = hp["max_samples"]
-        ntr = prob.n_train_global
-        pick = np.random.choice(ntr, S, replace=False) if S < ntr else np.arange(ntr)   # same draw on every rank
-        pick_t = torch.from_numpy(pick)
-        owner = prob.train_owner[pick_t]
-        counts = torch.bincount(owner, minlength=prob.world).tolist()
-        mine = pick_t[owner == prob.rank]
-        idx = prob.train_localpos[mine].to(dev)
+        idx, counts = _sampled_rows(prob, hp["max_samples"], dev)
         fhat = ops.gather_normalize(f, idx)
         that = ops.gather_normalize(t, idx)
         loss_aux = _DistNCE.apply(fhat, that, hp["nce_T"], counts, prob.rank, group)
@@ -780,13 +809,7 @@ def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: di
         else:
             f = student_proj(take(model.out_feat, prob.train_local))
             t = teacher_proj(take(prob.teacher_out_feat, prob.train_local))
-        S = hp["max_samples"]
-        ntr = prob.n_train_global
-        pick = np.random.choice(ntr, S, replace=False) if S < ntr else np.arange(ntr)   # same draw on every rank
-        pick_t = torch.from_numpy(pick)
-        owner = prob.train_owner[pick_t]
-        counts = torch.bincount(owner, minlength=prob.world).tolist()
-        idx = prob.train_localpos[pick_t[owner == prob.rank]].to(dev)
+        idx, counts = _sampled_rows(prob, hp["max_samples"], dev)
         fs = _GatherSampledRows.apply(f[idx], counts, prob.rank, group)
         ts = _GatherSampledRows.apply(t[idx], counts, prob.rank, group)
         loss_aux = ops_pairwise.gsp_loss(fs, ts, None, hp["kernel"])      # the GLOBAL value on every rank
@@ -816,28 +839,106 @@ def sharded_train_step(model, prob: ShardedProblem, optimizer, mode: str, hp: di
     aux_is_global = mode in ("nce", "gpw")
     rep = torch.stack([loss_cls.detach(), loss_aux.detach() if not aux_is_global else zero, loss_aux.detach()])
     dist.all_reduce(rep[:2], group=group)                     # loss_aux of nce / gpw is already global: not reduced
-    vals = rep.tolist()                                       # one device->host read per step
-    loss_cls_g = vals[0]
-    loss_aux_g = vals[2] if aux_is_global else vals[1]
-    if mode == "kd":
-        loss_g = loss_aux_g * (hp["alpha"] * hp["kd_T"] ** 2) + loss_cls_g * (1 - hp["alpha"])
-    elif mode in ("nce", "gpw", "lpw"):
-        loss_g = loss_cls_g + hp["beta"] * loss_aux_g
-    else:
-        loss_g = loss_cls_g
-    return loss_g, loss_cls_g, loss_aux_g
+    return rep
 
 
 @torch.no_grad()
-def sharded_evaluate(model, prob: ShardedProblem):
+def sharded_evaluate_tensors(model, prob: ShardedProblem):
+    """``test()`` on shards without the host read: (local logits, device tensor of the three GLOBAL hit counts)."""
     model.eval()
     out = model(prob.x, prob.adj)
     y_pred = out.argmax(dim=-1, keepdim=True)
     correct = torch.stack([(prob.y[prob.split_local[k]] == y_pred[prob.split_local[k]]).sum() for k in ("train", "valid", "test")]).float()
     dist.all_reduce(correct, group=prob.group)
+    return out, correct
+
+
+def sharded_evaluate(model, prob: ShardedProblem):
+    out, correct = sharded_evaluate_tensors(model, prob)
     hits = correct.tolist()                                   # one device->host read for the three counts
     accs = tuple(hits[i] / max(1, prob.split_sizes[k]) for i, k in enumerate(("train", "valid", "test")))
     return out, accs
+
+
+class ShardedGraphedEpoch:
+    """One epoch of the sharded run (train step + eval on this rank's shard, collectives included) captured ONCE as a hipGraph
+    and replayed -- the sharded counterpart of ``models.GraphedEpoch``: the ~250 launches and ~25 collectives of an epoch are
+    enqueued by one call.  RCCL collectives are stream operations and are captured like kernels (all ranks capture and replay
+    the same program, see tests/test_dist_gloo.py::test_every_rank_issues_the_same_collective_sequence).
+    Static shapes are required: every mode with ONE rank, and ``kd`` / ``supervised`` / ``lpw`` with any number of ranks.  With
+    several ranks the G-CRD / GSP row sample splits unevenly over the ranks from step to step (a binomial count per rank), so
+    those steps stay eager (``capturable()`` says which).  Host randomness as in the eager step: one np.random.choice per step
+    into a static device buffer, a fresh dropout seed per replay; one device->host read per epoch."""
+
+    @staticmethod
+    def capturable(world: int, mode: str) -> bool:
+        return world == 1 or mode in ("kd", "supervised", "lpw")
+
+    def __init__(self, model, prob: ShardedProblem, optimizer, mode: str, hp: dict, student_proj=None, teacher_proj=None, warmup: int = 3):
+        if not prob.x.is_cuda:
+            raise ValueError("ShardedGraphedEpoch needs GPU tensors")
+        if not self.capturable(prob.world, mode):
+            raise ValueError(f"the sharded '{mode}' step has step-dependent shapes on {prob.world} ranks: not capturable")
+        self.mode, self.hp, self.prob = mode, hp, prob
+        dev = prob.x.device
+        S = hp.get("max_samples", 0) if mode in ("nce", "gpw") else 0
+        self.n_pick = min(S, prob.n_train_global) if S else 0
+        self._pick_dev = torch.zeros(max(self.n_pick, 1), dtype=torch.int64, device=dev)
+        self._pick_host = torch.zeros(max(self.n_pick, 1), dtype=torch.int64).pin_memory()
+        self._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._seed_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+
+        def body():
+            rep = sharded_train_step_tensors(model, prob, optimizer, mode, hp, student_proj, teacher_proj)
+            _, correct = sharded_evaluate_tensors(model, prob)
+            return rep, correct
+        prev = (prob.sample_hook, ops._DROPOUT_SEED_DEV)
+        prob.sample_hook = lambda S_: (self._pick_dev[:self.n_pick], [self.n_pick])     # one rank owns the whole sample
+        ops._DROPOUT_SEED_DEV = self._seed_dev
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._refresh()
+                    body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            self._refresh()
+            torch.cuda.synchronize(dev)
+            with torch.cuda.graph(self.graph):
+                self.rep, self.correct = body()
+            torch.cuda.synchronize(dev)
+        finally:
+            prob.sample_hook, ops._DROPOUT_SEED_DEV = prev
+        self._refresh()
+
+    def _draw(self):
+        if self.n_pick:
+            ntr = self.prob.n_train_global
+            pick = np.random.choice(ntr, self.n_pick, replace=False) if self.n_pick < ntr else np.arange(ntr)
+            self._pick_host.copy_(self.prob.train_localpos[torch.from_numpy(pick)])       # one rank: every picked row is local
+        self._seed_host.random_()
+        self._seed_host.bitwise_and_(0x3FFFFFFFFFFFFFFF)
+
+    def _upload(self):
+        if self.n_pick:
+            self._pick_dev.copy_(self._pick_host, non_blocking=True)
+        self._seed_dev.copy_(self._seed_host, non_blocking=True)
+
+    def _refresh(self):
+        self._draw()
+        self._upload()
+
+    def step(self):
+        """Replay one epoch; returns ((loss, loss_cls, loss_aux), (train, valid, test accuracies))."""
+        self.graph.replay()
+        self._draw()                                              # the next step's host draw overlaps the replay
+        vals = torch.cat([self.rep, self.correct]).tolist()       # one device->host read per epoch
+        self._upload()
+        accs = tuple(vals[3 + i] / max(1, self.prob.split_sizes[k]) for i, k in enumerate(("train", "valid", "test")))
+        return finish_losses(vals[:3], self.mode, self.hp), accs
 
 
 # ------------------------------------------------------------------------------------------------
@@ -893,16 +994,33 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
         sp = swap_batchnorm(PM.make_projection(model_cfg["hidden"], hp["proj_dim"]).to(device))
         tp = swap_batchnorm(PM.make_projection(data.teacher_out_feat.shape[1], hp["proj_dim"]).to(device))
         groups += [{"params": sp.parameters(), "lr": model_cfg["lr"]}, {"params": tp.parameters(), "lr": model_cfg["lr"]}]
-    opt = torch.optim.Adam(groups, fused=(on_gpu and os.environ.get("EGNN_ADAM", "fused") == "fused"))
+    if on_gpu and os.environ.get("EGNN_ADAM_GROUPS", "one") == "one":   # same hyper-parameters in every group (gnn.py:308-312): one launch
+        groups = [{"params": [p for g in groups for p in g["params"]], "lr": model_cfg["lr"]}]
+    opt = torch.optim.Adam(groups, fused=(on_gpu and os.environ.get("EGNN_ADAM", "fused") == "fused"), capturable=on_gpu)
     torch.manual_seed(args.seed + 1000 + rank)               # dropout masks differ per shard
 
-    def epoch():
+    def eager_epoch():
         l = sharded_train_step(model, prob, opt, args.training, hp, sp, tp)
         _, a = sharded_evaluate(model, prob)
         return l, a
 
-    for _ in range(args.warmup):
-        epoch()
+    # hipGraph replay of the epoch where the step has static shapes (ShardedGraphedEpoch.capturable): --graph on / auto
+    graphed, graph_note = None, "eager launches"
+    want_graph = getattr(args, "graph", "off") in ("on", "auto") and on_gpu
+    if want_graph and ShardedGraphedEpoch.capturable(world, args.training):
+        try:
+            graphed = ShardedGraphedEpoch(model, prob, opt, args.training, hp, sp, tp, warmup=max(args.warmup, 3))
+            graph_note = "hipGraph replay of the sharded train step + eval, collectives captured (dist.ShardedGraphedEpoch)"
+        except Exception as e:  # noqa: BLE001
+            graph_note = f"capture of the sharded epoch failed, eager launches: {type(e).__name__}: {str(e)[:200]}"
+            graphed = None
+    elif want_graph:
+        graph_note = (f"eager launches: the sharded '{args.training}' step has step-dependent shapes on {world} ranks (the row sample splits "
+                      f"unevenly over the ranks), not capturable")
+    epoch = graphed.step if graphed is not None else eager_epoch
+    if graphed is None:
+        for _ in range(args.warmup):
+            eager_epoch()
     # The interpreter holds ~170k long-lived objects after the torch / RCCL imports; a full (generation-2) collection
     # walks all of them (~40 ms) and the per-step autograd / collective bookkeeping triggers one every few steps.
     # Freezing the survivors of set-up keeps later collections proportional to the per-step garbage.
@@ -926,7 +1044,6 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
     for _ in range(args.steps):
         losses, accs = epoch()
     sync()
-    ops.spmm_raw = orig_raw
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     halo = torch.tensor([float(prob.adj.plan.n_halo)], device=device)
@@ -934,9 +1051,10 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
     # one more epoch, outside the timed region, with the collectives recorded: per-rank communication volume, the compute
     # window every halo exchange is hidden under and what is left exposed (HIP events on the compute stream)
     with CommTrace(probe_overlap=on_gpu) as trace:
-        epoch()
+        eager_epoch()
         if on_gpu:
             torch.cuda.synchronize()
+    ops.spmm_raw = orig_raw          # (the aggregation brackets cover the timed region when it ran eagerly, and this epoch)
     comm = trace.summary()
     per_rank_comm = [None] * world
     dist.all_gather_object(per_rank_comm, comm)
@@ -968,6 +1086,7 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
                         partitioning=f"node-range shards x{world}: halo all_to_all {'overlapped with the own-column aggregation' if _OVERLAP else '(blocking)'}"
                                      f" + SyncBN all-reduce + flat grad all-reduce over RCCL",
                         mean_halo_rows_per_rank=int(float(halo) / world)),
+            launch=graph_note,
             comm_per_epoch=dict(what="one epoch (train step + eval) traced after the timed region: payload bytes per rank and kind; "
                                      "overlap_window_us = own-column aggregation time the halo exchanges run under, exposed_comm_us = what the "
                                      "compute stream still waits for them afterwards (forward exchanges; HIP events)",

@@ -139,12 +139,15 @@ def _const_rows(t, idx):
 
 
 def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_logits, hp,
-                 student_proj=None, teacher_proj=None, edge_index=None, adj_t=None, kd_and_aux=False):
+                 student_proj=None, teacher_proj=None, edge_index=None, adj_t=None, kd_and_aux=False, rows=None):
+    """``rows`` = None: ``out`` / ``labels`` are the compact train rows (gnn.py:109-110).  ``rows`` = train_idx: they are the FULL
+    logits / labels and the criteria pick the rows inside their kernels (criterion.py's ``rows`` keyword)."""
+    kd_teacher = (lambda: teacher_logits) if rows is not None else (lambda: _const_rows(teacher_logits, train_idx))
     if mode == "supervised":
-        loss = ops.cross_entropy(out, labels)
+        loss = ops.cross_entropy(out, labels, rows)
         return loss, loss, loss * 0
     if mode == "kd":
-        return C.kd_criterion(out, labels, _const_rows(teacher_logits, train_idx), hp["alpha"], hp["kd_T"])
+        return C.rows_kd_criterion(out, labels, kd_teacher(), hp["alpha"], hp["kd_T"], rows=rows)
     if mode in ("fitnet", "gpw", "nce"):
         if hasattr(student_proj, "forward_rows") and hasattr(teacher_proj, "forward_rows") and not _CACHE_CONST_ROWS:
             f = student_proj.forward_rows(model.out_feat, train_idx)       # proj(feat[train_idx]) without the copies
@@ -160,19 +163,19 @@ def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_
     else:
         raise NotImplementedError(mode)
     if mode == "fitnet":
-        res = C.fitnet_criterion(out, labels, f, t, hp["beta"])
+        res = C.rows_fitnet_criterion(out, labels, f, t, hp["beta"], rows=rows)
     elif mode == "at":
-        res = C.at_criterion(out, labels, f, t, hp["beta"])
+        res = C.rows_at_criterion(out, labels, f, t, hp["beta"], rows=rows)
     elif mode == "gpw":
-        res = C.gpw_criterion(out, labels, f, t, hp["kernel"], hp["beta"], hp["max_samples"])
+        res = C.rows_gpw_criterion(out, labels, f, t, hp["kernel"], hp["beta"], hp["max_samples"], rows=rows)
     elif mode == "lpw":
-        res = C.lpw_criterion(out, labels, f, t, edge_index, hp["kernel"], hp["beta"])
+        res = C.rows_lpw_criterion(out, labels, f, t, edge_index, hp["kernel"], hp["beta"], rows=rows)
     else:
-        res = C.nce_criterion(out, labels, f, t, hp["beta"], hp["nce_T"], hp["max_samples"])
+        res = C.rows_nce_criterion(out, labels, f, t, hp["beta"], hp["nce_T"], hp["max_samples"], rows=rows)
     if not kd_and_aux:
         return res
     loss_aux = res[2]
-    loss, loss_cls, _ = C.kd_criterion(out, labels, _const_rows(teacher_logits, train_idx), hp["alpha"], hp["kd_T"])
+    loss, loss_cls, _ = C.rows_kd_criterion(out, labels, kd_teacher(), hp["alpha"], hp["kd_T"], rows=rows)
     return loss + hp["beta"] * loss_aux, loss_cls, loss_aux
 
 
@@ -184,10 +187,17 @@ def train_step_tensors(model, x, adj_t, y, train_idx, optimizer, mode, hp, teach
     for p in (student_proj, teacher_proj):
         if p is not None:
             p.train()
-    out = ops.take_rows(model(x, adj_t), train_idx)   # == model(...)[train_idx] (split ids are unique)
-    labels = y.squeeze(1)[train_idx]
-    loss, loss_cls, loss_aux = distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_logits, hp,
-                                            student_proj, teacher_proj, edge_index, adj_t, kd_and_aux)
+    logits = model(x, adj_t)
+    if logits.is_cuda and y.dim() == 2 and y.shape[1] == 1 and y.dtype == torch.int64:
+        # gnn.py:109-110 `out = model(...)[train_idx]`, `y.squeeze(1)[train_idx]` (and `teacher_logits[train_idx]`): the row picks
+        # happen inside the CE / KD kernels (the criteria's `rows` keyword), their backward writes the dense logits gradient
+        loss, loss_cls, loss_aux = distill_loss(mode, model, logits, y.view(-1), train_idx, teacher_out_feat, teacher_logits, hp,
+                                                student_proj, teacher_proj, edge_index, adj_t, kd_and_aux, rows=train_idx)
+    else:
+        out = ops.take_rows(logits, train_idx)   # == model(...)[train_idx] (split ids are unique)
+        labels = y.squeeze(1)[train_idx]
+        loss, loss_cls, loss_aux = distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_logits, hp,
+                                                student_proj, teacher_proj, edge_index, adj_t, kd_and_aux)
     optimizer.zero_grad()
     loss.backward()
     optimizer.step()

@@ -36,9 +36,11 @@ def _patch_ops_with_oracle():
     ops.take_rows = lambda x, idx: x[idx]
     ops.matmul = lambda x, w, bias=None: x @ w if bias is None else x @ w + bias
     ops.linear = lambda x, w, b=None: F.linear(x, w, b)
-    ops.cross_entropy = lambda logits, labels: F.cross_entropy(logits, labels)
+    ops.cross_entropy = lambda logits, labels, rows=None: F.cross_entropy(logits if rows is None else logits[rows], labels if rows is None else labels[rows])
 
-    def ce_and_kd(logits, labels, teacher, T):
+    def ce_and_kd(logits, labels, teacher, T, rows=None):
+        if rows is not None:
+            logits, labels, teacher = logits[rows], labels[rows], teacher[rows]
         return (F.cross_entropy(logits, labels),
                 F.kl_div(F.log_softmax(logits / T, dim=1), F.softmax(teacher / T, dim=1), log_target=False))
     ops.ce_and_kd = ce_and_kd

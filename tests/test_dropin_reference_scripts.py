@@ -158,10 +158,10 @@ def _host_layer_worker(q, gnn, mode):
     ops.matmul = lambda x, w, bias=None: x @ w if bias is None else x @ w + bias
     ops.linear = lambda x, w, b=None: F.linear(x, w, b)
     ops.take_rows = lambda x, idx: x[idx]
-    ops.cross_entropy = lambda logits, labels: F.cross_entropy(logits, labels)
+    ops.cross_entropy = lambda logits, labels, rows=None: F.cross_entropy(logits, labels)
     ops.gather_normalize = lambda x, idx=None, eps=1e-12: F.normalize(x if idx is None else x[idx], p=2, dim=-1)
     ops.nce_unit = lambda f, t, tau: F.cross_entropy(f @ t.t() / tau, torch.arange(f.shape[0]))
-    ops.ce_and_kd = lambda logits, labels, teacher, T: (
+    ops.ce_and_kd = lambda logits, labels, teacher, T, rows=None: (
         F.cross_entropy(logits, labels), F.kl_div(F.log_softmax(logits / T, dim=1), F.softmax(teacher / T, dim=1), log_target=False))
 
     ref = _load_reference_gnn()

@@ -759,6 +759,32 @@ def test_ce_kd_kernel_vs_oracle(n, C, T):
     close(lg.grad, logits.grad, rtol=1e-4)
 
 
+def test_criteria_rows_twins_equal_the_compact_call():
+    """The ``rows_*`` twins of the criteria (full logits / labels / teacher logits + the row ids, picked inside the CE / KD
+    kernels) gives the losses of the reference-style call on ``logits[rows]`` bit for bit and the same logits gradient, scattered."""
+    g = torch.Generator().manual_seed(4)
+    N, C = 3000, 40
+    logits = torch.randn(N, C, generator=g).to(DEV)
+    labels = torch.randint(0, C, (N,), generator=g).to(DEV)
+    teacher = (torch.randn(N, C, generator=g) * 3).to(DEV)
+    rows = torch.randperm(N, generator=g)[:1700].to(DEV)
+    f = torch.relu(torch.randn(1700, 64, generator=g)).to(DEV)
+    t = torch.relu(torch.randn(1700, 64, generator=g)).to(DEV)
+    for name, full, compact in (
+            ("kd", lambda L: PC.rows_kd_criterion(L, labels, teacher, 0.9, 4, rows=rows), lambda L: E.kd_criterion(L[rows], labels[rows], teacher[rows], 0.9, 4)),
+            ("nce", lambda L: PC.rows_nce_criterion(L, labels, f, t, 0.1, 0.075, 4096, rows=rows), lambda L: E.nce_criterion(L[rows], labels[rows], f, t, 0.1, 0.075, 4096)),
+            ("gpw", lambda L: PC.rows_gpw_criterion(L, labels, f, t, "cosine", 1.0, 4096, rows=rows), lambda L: E.gpw_criterion(L[rows], labels[rows], f, t, "cosine", 1.0, 4096))):
+        a = logits.clone().requires_grad_(True)
+        b = logits.clone().requires_grad_(True)
+        la, lb = full(a), compact(b)
+        for x, y in zip(la, lb):
+            assert float(x) == float(y), name
+        la[0].backward()
+        lb[0].backward()
+        assert torch.equal(a.grad, b.grad), name
+        assert float(a.grad[rows].abs().sum()) > 0 and float(a.grad.abs().sum()) == float(a.grad[rows].abs().sum()), "rows outside the list get exact zeros"
+
+
 @pytest.mark.parametrize("S,P,n,tau", [(64, 16, 64, 0.075), (300, 72, 500, 0.075), (1000, 256, 1000, 0.05), (2048, 256, 3000, 0.075)])
 def test_nce_vs_oracle(S, P, n, tau):
     g = torch.Generator().manual_seed(S)
@@ -1149,6 +1175,63 @@ def test_sharded_path_with_one_rank_over_rccl_matches_single_gpu_path(gnn, mode)
         close(out, ref_logits, rtol=1e-4, atol_scale=1e-5)
         np.testing.assert_allclose(accs, ref_accs, atol=1e-9)
         np.testing.assert_allclose(np.array(got), np.array(ref), rtol=2e-4, atol=1e-6)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gnn,mode", [("gcn", "nce"), ("sage", "kd"), ("sage", "lpw")])
+def test_sharded_epoch_captured_as_a_graph_replays_the_eager_steps(gnn, mode):
+    """dist.ShardedGraphedEpoch (one rank over RCCL): the captured epoch -- collectives included -- reproduces the eager sharded
+    steps (same host draw, dropout 0): losses and accuracies of three replays equal three eager steps to fp32 rounding."""
+    import torch.distributed as dist
+    import efficient_gnns_amd.dist as DD
+    import copy
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29578", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        d = D.arxiv_like(scale=0.02, seed=5)
+        hp = dict(alpha=0.9, kd_T=4.0, beta=0.1 if mode == "nce" else 100.0, nce_T=0.075, max_samples=512, kernel="cosine")
+        prob = DD.ShardedProblem(d, 1, 0, torch.device(DEV, 0), None, need_gcn=(gnn == "gcn"))
+
+        def build():
+            torch.manual_seed(0)
+            m = DD.swap_batchnorm((PM.GCN if gnn == "gcn" else PM.SAGE)(d.num_features, 64, d.num_classes, 3, 0.0).to(DEV))
+            sp = tp = None
+            params = list(m.parameters())
+            if mode == "nce":
+                sp = DD.swap_batchnorm(PM.make_projection(64, 32).to(DEV))
+                tp = DD.swap_batchnorm(PM.make_projection(750, 32).to(DEV))
+                params += list(sp.parameters()) + list(tp.parameters())
+            return m, sp, tp, torch.optim.Adam(params, lr=0.01, fused=True, capturable=True)
+        m1, sp1, tp1, o1 = build()
+        m2, sp2, tp2, o2 = build()
+        np.random.seed(3)
+        eager = []
+        for _ in range(3):
+            l = DD.sharded_train_step(m1, prob, o1, mode, hp, sp1, tp1)
+            _, a = DD.sharded_evaluate(m1, prob)
+            eager.append((l, a))
+        # the graph's constructor runs `warmup` untimed steps on the model: give it a throw-away twin state, then restore
+        state = [copy.deepcopy(x.state_dict()) if x is not None else None for x in (m2, sp2, tp2)]
+        ge = DD.ShardedGraphedEpoch(m2, prob, o2, mode, hp, sp2, tp2, warmup=2)
+        for x, st in zip((m2, sp2, tp2), state):
+            if x is not None:
+                x.load_state_dict(st)
+        for grp in o2.param_groups:          # Adam state back to step 0
+            for p_ in grp["params"]:
+                stt = o2.state[p_]
+                if stt:
+                    stt["exp_avg"].zero_(); stt["exp_avg_sq"].zero_(); stt["step"].zero_()
+        np.random.seed(3)
+        ge._refresh()
+        got = [ge.step() for _ in range(3)]
+        for (le, ae), (lg, ag) in zip(eager, got):
+            np.testing.assert_allclose(np.array(lg), np.array(le), rtol=2e-4, atol=1e-7)
+            np.testing.assert_allclose(np.array(ag), np.array(ae), atol=2e-3)
     finally:
         if created:
             dist.destroy_process_group()

@@ -15,6 +15,7 @@ import efficient_gnns_amd.data as D  # noqa: E402
 import efficient_gnns_amd.ops as ops  # noqa: E402
 
 K = int(os.environ.get("EGNN_PMC_K", "256"))
+REDUCE = os.environ.get("EGNN_PMC_REDUCE", "sum")
 REPS = int(os.environ.get("EGNN_PMC_REPS", "3"))
 which = os.environ.get("EGNN_PMC_GRAPHS", "chunglu,window4096").split(",")
 
@@ -50,6 +51,18 @@ def graph(name):
             return rp, col, d.num_nodes
         rp, col, n = cached(name, build)
         return E.gcn_norm(E.SparseTensor(rowptr=rp.cuda(), col=col.cuda(), sparse_sizes=(n, n)))
+    if name in ("mag", "mag_reordered"):
+        # BASELINE.json configs[4]: the MAG-shaped graph (N = 1 939 743, 42.2 M entries), value-less adjacency, mean aggregation
+        def build():
+            d = D.mag_like(1.0, seed=0)
+            rp, col, _ = d.adj_t.csr()
+            return rp, col, d.num_nodes
+        rp, col, n = cached("mag", build)
+        adj = E.SparseTensor(rowptr=rp.cuda(), col=col.cuda(), sparse_sizes=(n, n))
+        if name == "mag_reordered":
+            from efficient_gnns_amd.sparse import community_order
+            adj = adj.permute(community_order(adj))
+        return adj
     raise SystemExit(f"unknown graph {name}")
 
 
@@ -61,10 +74,14 @@ torch.cuda.synchronize()
 for name in which:
     adj = graph(name)
     x = torch.randn(adj.sparse_size(1), K, device="cuda")
-    ops.spmm_raw(adj, x, "sum")   # warm-up (plan construction)
+    ops.spmm_raw(adj, x, REDUCE)   # warm-up (plan construction)
     torch.cuda.synchronize()
     torch.zeros(7777, device="cuda")   # marker dispatch between graphs (grid of 7777 elements)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(REPS):
-        ops.spmm_raw(adj, x, "sum")
+        ops.spmm_raw(adj, x, REDUCE)
+    e1.record()
     torch.cuda.synchronize()
+    print("us_per_call", round(e0.elapsed_time(e1) * 1e3 / REPS, 1), end=" ")
     print("graph", name, "nnz", adj.nnz(), "alg_bytes", adj.spmm_algorithmic_bytes(K), flush=True)
