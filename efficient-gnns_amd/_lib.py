@@ -81,6 +81,11 @@ SIGNATURES = {
     "egnn_split_accuracy_ws_ints": (_sz, []),
     "egnn_split_accuracy_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     "egnn_rows_add_f32": (_i32, [_p, _i64, _p, _p, _i64, _i64, _i64, _p]),
+    "egnn_feature_loss_ws_floats": (_sz, [_i64]),
+    "egnn_fitnet_fwd_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _f32, _p, _p, _sz, _p]),
+    "egnn_fitnet_bwd_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _f32, _p, _p, _i64, _p, _i64, _p]),
+    "egnn_at_fwd_f32": (_i32, [_p, _i64, _i64, _p, _i64, _i64, _i64, _f32, _p, _p, _sz, _p]),
+    "egnn_at_bwd_f32": (_i32, [_p, _i64, _i64, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _i64, _p, _i64, _p]),
     "egnn_probe_gather_lines_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i64, _i32, _i32, _p, _p]),
     "egnn_bn_act_bwd_reduce_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _p, _p, _sz, _p]),
     "egnn_bn_act_bwd_apply_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _p, _f32, _p, _i64, _p]),

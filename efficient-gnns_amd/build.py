@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libegnn_hip.so")
 SOURCES = ["api.hip", "spmm.hip", "spmm_blk.hip", "graph.hip", "losses.hip", "gemm.hip", "gemm_skinny.hip", "nce.hip", "pairwise.hip", "edge_softmax.hip",
-           "fused_bn.hip", "graph_build.hip", "probe.hip"]
+           "fused_bn.hip", "graph_build.hip", "probe.hip", "feature_losses.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"] + os.environ.get("EGNN_EXTRA_FLAGS", "").split()
 
 

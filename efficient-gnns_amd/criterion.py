@@ -14,7 +14,8 @@ import torch
 from . import ops
 
 __all__ = ["kd_criterion", "fitnet_criterion", "at_criterion", "gpw_criterion", "lpw_criterion", "nce_criterion",
-           "loss_kd_only", "ppi_kd_criterion"]
+           "loss_kd_only", "ppi_kd_criterion", "ppi_fitnet_criterion", "ppi_at_criterion", "ppi_gpw_criterion", "ppi_lpw_criterion",
+           "ppi_nce_criterion"]
 
 
 # Optional override of the sampled-row source: ``callable(n, max_samples, device) -> int64 device tensor | None``.
@@ -33,6 +34,23 @@ def _sample_rows(n: int, max_samples: int, device):
         pick = np.random.choice(n, max_samples, replace=False)
         return torch.from_numpy(pick).to(device=device, dtype=torch.int64, non_blocking=True)
     return None
+
+
+def _ce_term(logits, labels, rows=None):
+    return ops.cross_entropy(logits, labels, rows)
+
+
+def _bce_term(logits, labels, rows=None):
+    """Multi-label classification term of the PPI scripts (ppi_pyg/criterion.py:11,24,42,57,98,132): mean BCE-with-logits."""
+    from .ops_pairwise import bce_with_logits_pair
+    if rows is not None:
+        logits, labels = logits[rows], labels[rows]
+    return bce_with_logits_pair(logits, labels, logits.detach())[0]
+
+
+# The classification term the criteria below use: class-index cross entropy (arxiv / MAG scripts); ``ppi_criteria()`` evaluates them
+# with the multi-label BCE term instead.  A module-level switch rather than a parameter: the public signatures stay the reference's.
+_CLS = _ce_term
 
 
 # The public criteria keep the reference's signatures exactly.  Each has a ``rows_*`` twin (an extension; the reference has no
@@ -65,9 +83,8 @@ def fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000):
 
 def rows_fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=None):
     """``fitnet_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
-    loss_cls = ops.cross_entropy(logits, labels, rows)
-    diff = ops.gather_normalize(feat) - ops.gather_normalize(teacher_feat)
-    loss_aux = (diff * diff).mean()
+    loss_cls = _CLS(logits, labels, rows)
+    loss_aux = ops.fitnet_loss(feat, teacher_feat)
     return loss_cls + beta * loss_aux, loss_cls, loss_aux
 
 
@@ -78,11 +95,8 @@ def at_criterion(logits, labels, feat, teacher_feat, beta=1000):
 
 def rows_at_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=None):
     """``at_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
-    loss_cls = ops.cross_entropy(logits, labels, rows)
-    e_s = (feat * feat).sum(-1)
-    e_t = (teacher_feat * teacher_feat).sum(-1)
-    d = e_s / e_s.norm().clamp_min(1e-12) - e_t / e_t.norm().clamp_min(1e-12)
-    loss_aux = (d * d).mean()
+    loss_cls = _CLS(logits, labels, rows)
+    loss_aux = ops.at_loss(feat, teacher_feat)
     return loss_cls + beta * loss_aux, loss_cls, loss_aux
 
 
@@ -96,7 +110,7 @@ def rows_gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta
     from .ops_pairwise import gsp_loss
     if kernel not in ("cosine", "poly", "l2", "rbf"):
         raise NotImplementedError
-    loss_cls = ops.cross_entropy(logits, labels, rows)
+    loss_cls = _CLS(logits, labels, rows)
     idx = _sample_rows(feat.shape[0], max_samples, feat.device)
     loss_aux = gsp_loss(feat, teacher_feat, idx, kernel)
     return loss_cls + beta * loss_aux, loss_cls, loss_aux
@@ -112,7 +126,7 @@ def rows_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="c
     from .ops_edge import lsp_loss
     if kernel not in ("cosine", "poly", "l2", "rbf") or criterion not in ("kld", "mse"):
         raise NotImplementedError
-    loss_cls = ops.cross_entropy(logits, labels, rows)
+    loss_cls = _CLS(logits, labels, rows)
     loss_aux = lsp_loss(feat, teacher_feat, edge_index, kernel, criterion)
     return loss_cls + beta * loss_aux, loss_cls, loss_aux
 
@@ -124,12 +138,54 @@ def nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max
 
 def rows_nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max_samples=8192, rows=None):
     """``nce_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
-    loss_cls = ops.cross_entropy(logits, labels, rows)
+    loss_cls = _CLS(logits, labels, rows)
     idx = _sample_rows(feat.shape[0], max_samples, feat.device)
     fhat = ops.gather_normalize(feat, idx)
     that = ops.gather_normalize(teacher_feat, idx)
     loss_aux = ops.nce_unit(fhat, that, nce_T)
     return loss_cls + beta * loss_aux, loss_cls, loss_aux
+
+
+class _PpiCriteria:
+    """The auxiliary criteria of /root/reference/ppi_pyg/criterion.py:21-146 -- the same feature losses as the arxiv scripts with
+    the multi-label BCE-with-logits classification term (the file differs from arxiv_pyg/criterion.py in that line only)."""
+
+    @staticmethod
+    def _with_bce(fn):
+        def wrapped(*a, **kw):
+            global _CLS
+            prev, _CLS = _CLS, _bce_term
+            try:
+                return fn(*a, **kw)
+            finally:
+                _CLS = prev
+        wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+        return wrapped
+
+
+def ppi_fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000):
+    """ppi_pyg/criterion.py:21-36."""
+    return _PpiCriteria._with_bce(fitnet_criterion)(logits, labels, feat, teacher_feat, beta)
+
+
+def ppi_at_criterion(logits, labels, feat, teacher_feat, beta=1000):
+    """ppi_pyg/criterion.py:39-54."""
+    return _PpiCriteria._with_bce(at_criterion)(logits, labels, feat, teacher_feat, beta)
+
+
+def ppi_gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, max_samples=8192):
+    """ppi_pyg/criterion.py:57-92."""
+    return _PpiCriteria._with_bce(gpw_criterion)(logits, labels, feat, teacher_feat, kernel, beta, max_samples)
+
+
+def ppi_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="cosine", beta=100, criterion="kld"):
+    """ppi_pyg/criterion.py:95-126."""
+    return _PpiCriteria._with_bce(lpw_criterion)(logits, labels, feat, teacher_feat, edge_index, kernel, beta, criterion)
+
+
+def ppi_nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max_samples=8192):
+    """ppi_pyg/criterion.py:129-149."""
+    return _PpiCriteria._with_bce(nce_criterion)(logits, labels, feat, teacher_feat, beta, nce_T, max_samples)
 
 
 def ppi_kd_criterion(logits, labels, teacher_logits, alpha=0.5, T=1):

@@ -3,7 +3,7 @@
 // backward GEMMs (/root/reference/arxiv_pyg/gnn.py:47,79,296-306,192).
 #include <cstdlib>
 
-#include "gemm_split.h"
+#include "gemm3.h"
 
 using namespace egnn_gemm;
 
@@ -238,6 +238,39 @@ bool planes_form(int64_t M, int64_t N, int64_t K, bool b_gather) {
   return on && gemm_split_pipe() && !b_gather && N >= 96 && K >= 16 && M >= 3 * N && planes_bytes(N, K) <= (256u << 20);
 }
 
+// ---- DMA form (gemm3.h): a node-count-tall A [M, K] (k contiguous) against a SMALL B (layer weights) -------------------------
+// x W of GCNConv / nn.Linear and dX = dY W^T (arxiv_pyg/gnn.py:47,52,79,84,192): B is cut once per call into tile-packed bf16
+// planes (a few hundred KB), A goes global -> LDS by LDS-DMA as fp32 and is cut on the fragment side.  128 x 128 tiles, k-steps of
+// 32, two LDS stages, fragments one k-block ahead in registers (lab: 137-143 vs 155-158 us on 169 216 x 256 x 256).
+constexpr int DMA_BKT = 32;
+using DmaTile = egnn_gemm3::Tile<egnn_gemm3::F32K, egnn_gemm3::PLANES, 2, 2, DMA_BKT, 2>;
+
+__global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int64_t tiles_n = g.N / 128;
+  int64_t tile = blockIdx.x;
+  if (tiles_n > 1 && tiles_n <= 8) {   // the column tiles of a row tile next to each other on one XCD (see gemm_kernel)
+    const int64_t tiles = gridDim.x, q = tiles >> 3, rem = tiles & 7, xcd = tile & 7, j = tile >> 3;
+    tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + j;
+  }
+  const int64_t m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  egnn_gemm3::mainloop<egnn_gemm3::F32K, egnn_gemm3::PLANES, 2, 2, DMA_BKT, 2, 1>(acc, g.A, g.lda, m0, g.planes, g.K / DMA_BKT, n0, 0, g.K,
+                                                                                 reinterpret_cast<char*>(smem), g.M);
+  const int wave = egnn_wave_id();
+  if (g.wide_store) store_tile_wide<128, 128, 2>(acc, g, m0, n0, 0, egnn_lane(), wave >> 1, wave & 1, smem);
+  else store_tile<128, 128, 2>(acc, g, m0, n0, 0, egnn_lane(), wave >> 1, wave & 1);
+}
+
+// shapes the DMA form takes: tall A with k contiguous, whole 128-column tiles of a small B, whole k-steps of 32
+bool dma_form(int trans_a, int64_t M, int64_t N, int64_t K, int split_k, bool gathers) {
+  static const bool off = getenv("EGNN_GEMM_DMA") && getenv("EGNN_GEMM_DMA")[0] == '0';   // A/B switch
+  return !off && gemm_split_pipe() && !trans_a && !gathers && split_k <= 1 && M >= 4096 && N % 128 == 0 && N >= 128 && N <= 1024 &&
+         K % DMA_BKT == 0 && K >= 2 * DMA_BKT && K <= 4096;
+}
+inline size_t dma_ws_bytes(int64_t N, int64_t K) { return egnn_gemm3::planes_bytes(N, K, 128, DMA_BKT) + 1024; }
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
   const int64_t total = g.M * g.N;
   const float alpha = g.alpha * (g.alpha_dev ? g.alpha_dev[0] : 1.f);
@@ -332,6 +365,17 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   const int bmaj = trans_b ? KMAJOR : MNMAJOR;   // B stored [N,K] when transposed, else [K,N]
   int rc;
   const size_t split_ws = split_k > 1 ? (size_t)split_k * M * N * sizeof(float) : 0;
+  if (dma_form(trans_a, M, N, K, split_k, a_rows || b_rows) && ws && ws_bytes >= dma_ws_bytes(N, K) && lda % 4 == 0 && egnn_aligned16(A)) {
+    char* planes = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws) + 1023) & ~(uintptr_t)1023);
+    // B(k, n): stored [N, K] when trans_b (k contiguous), else [K, N]
+    egnn_gemm3::pack_planes<128, DMA_BKT>(B, ldb, trans_b ? 1 : 0, N, K, nullptr, nullptr, nullptr, 0.f, planes, st);
+    g.planes = reinterpret_cast<const u32x4*>(planes);
+    const int64_t tiles = ((M + 127) / 128) * (N / 128);
+    if (tiles > 0x7fffffffLL) return EGNN_EINVAL;
+    rc = launch_dyn_lds<gemm_dma_kernel>(dim3((unsigned)tiles), dim3(256), (size_t)DmaTile::SMEM_BYTES, st, g);
+    if (rc != EGNN_OK) return rc;
+    return egnn_launch_status();
+  }
   if (planes_form(M, N, K, b_rows != nullptr) && ws && ws_bytes >= split_ws + planes_bytes(N, K) + 16) {
     u32x4* planes = reinterpret_cast<u32x4*>((reinterpret_cast<uintptr_t>(ws) + split_ws + 15) & ~(uintptr_t)15);
     g.planes = planes;
@@ -362,6 +406,10 @@ extern "C" size_t egnn_gemm_ws_floats(int trans_a, int trans_b, int64_t M, int64
   size_t need = split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N : 0;
   const int kind = skinny_kind(trans_a, trans_b, M, N, K, false);
   if (kind == 0 && planes_form(M, N, K, false)) need += planes_bytes(N, K) / sizeof(float) + 8;   // B cut into bf16 planes (gemm_split.h)
+  if (kind == 0 && dma_form(trans_a, M, N, K, split_k, false)) {   // tile-packed planes of B for the DMA form (gemm3.h)
+    const size_t dma = dma_ws_bytes(N, K) / sizeof(float) + 1;
+    if (dma > need) need = dma;
+  }
   size_t sk = 0;
   if (kind == 3) sk = egnn_skinny_dw_ws_floats(K, M, N);
   else if (kind == 4) sk = egnn_skinny_dw_ws_floats(K, N, M);

@@ -59,8 +59,10 @@ __device__ __forceinline__ void dma16(const void* g, void* lds_wave_base) {
 // Issues this wave's share of the DMA of one operand stage.
 //   F32K / F32M: p = fp32 matrix, ld = leading dimension, r0 = first row of the block tile, k0 = first k of the stage
 //   PLANES:      p = packed planes, nks = k-steps of the whole operand, r0 / k0 as above (multiples of R / BKT)
+// rmax (F32K): rows at or past it re-read row rmax - 1 (the last row tile of a ragged operand; such rows are never stored)
 template <int MODE, int R, int BKT>
-__device__ __forceinline__ void issue_stage(const void* __restrict__ p, int64_t ld_or_nks, int64_t r0, int64_t k0, char* lds, int wave, int lane) {
+__device__ __forceinline__ void issue_stage(const void* __restrict__ p, int64_t ld_or_nks, int64_t r0, int64_t k0, char* lds, int wave, int lane,
+                                            int64_t rmax = INT64_MAX) {
   using S = Stage<MODE, R, BKT>;
 #pragma unroll
   for (int i = 0; i < S::PIECES / 4; ++i) {
@@ -73,7 +75,9 @@ __device__ __forceinline__ void issue_stage(const void* __restrict__ p, int64_t 
       constexpr int RPP = 64 / S::CH;                        // rows per piece
       const int row = q * RPP + lane / S::CH, s = lane % S::CH;
       const int c = s ^ S::swz(row);
-      dma16((const float*)p + (r0 + row) * ld_or_nks + k0 + 4 * c, dst);
+      int64_t rr = r0 + row;
+      if (rr >= rmax) rr = rmax - 1;
+      dma16((const float*)p + rr * ld_or_nks + k0 + 4 * c, dst);
     } else {                                                 // F32M: image [BKT][R] floats, as in memory
       constexpr int CPR = R / 4;                             // 16-byte chunks per k-row
       const int cidx = q * 64 + lane;
@@ -147,7 +151,7 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[TM][TN], const u32x4 (&
 // once and reused, 8 = no vmcnt waits, 16 = s_setprio(1) around every MFMA block.
 template <int AMODE, int BMODE, int TM, int TN, int BKT, int NB, int PIPE = 0, int ABL = 0>
 __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM][TN], const void* __restrict__ pa, int64_t la, int64_t m0, const void* __restrict__ pb,
-                                         int64_t lb, int64_t n0, int64_t kbeg, int64_t kend, char* smem) {
+                                         int64_t lb, int64_t n0, int64_t kbeg, int64_t kend, char* smem, int64_t a_rows = INT64_MAX) {
   using T = Tile<AMODE, BMODE, TM, TN, BKT, NB>;
   constexpr int G = T::DMA_PER_WAVE, KB = BKT / 16;
   const int lane = egnn_lane(), wave = egnn_wave_id();
@@ -156,7 +160,7 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM][TN], const void* __re
   auto issue = [&](int stage) {
     if constexpr (ABL & 1) return;
     char* s = smem + (stage % NB) * T::STAGE_BYTES;
-    issue_stage<AMODE, T::BM, BKT>(pa, la, m0, kbeg + (int64_t)stage * BKT, s, wave, lane);
+    issue_stage<AMODE, T::BM, BKT>(pa, la, m0, kbeg + (int64_t)stage * BKT, s, wave, lane, a_rows);
     issue_stage<BMODE, T::BN, BKT>(pb, lb, n0, kbeg + (int64_t)stage * BKT, s + T::SA::BYTES, wave, lane);
   };
   bool frags_done = false;

@@ -210,6 +210,13 @@ extern "C" int egnn_ce_kd_fwd_f32(const float* logits, int64_t ld_logits, const 
   return egnn_launch_status();
 }
 
+namespace {
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ p, int64_t ld, int64_t n, int64_t C) {
+  const int64_t total = n * C;
+  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) p[(t / C) * ld + (t % C)] = 0.f;
+}
+}  // namespace
+
 extern "C" int egnn_ce_kd_bwd_f32(const float* logits, int64_t ld_logits, const float* teacher, int64_t ld_teacher,
                                   const int64_t* labels, const int64_t* rows, int64_t n_total_rows, int64_t n, int64_t C, float T,
                                   const float* out3, const float* g_cls, const float* g_kd, float* dlogits, int64_t ld_dlogits,
@@ -217,12 +224,11 @@ extern "C" int egnn_ce_kd_bwd_f32(const float* logits, int64_t ld_logits, const 
   EGNN_CHECK_ARG(n > 0 && C > 0 && logits && labels && dlogits && out3 && ld_logits >= C && ld_dlogits >= C && T > 0.f);
   EGNN_CHECK_ARG(rows == nullptr || n_total_rows >= n);
   hipStream_t st = (hipStream_t)stream;
-  if (rows) {   // rows outside the list receive no gradient: clear the whole [n_total_rows, C] block first
-    if (ld_dlogits == C) {
-      if (hipMemsetAsync(dlogits, 0, (size_t)n_total_rows * (size_t)C * sizeof(float), st) != hipSuccess) return EGNN_ELAUNCH;
-    } else if (hipMemset2DAsync(dlogits, (size_t)ld_dlogits * sizeof(float), 0, (size_t)C * sizeof(float), (size_t)n_total_rows, st) != hipSuccess) {
-      return EGNN_ELAUNCH;
-    }
+  if (rows) {   // rows outside the list receive no gradient: clear the whole [n_total_rows, C] block first (a kernel, not a memset
+                // node: the step is captured into hipGraphs, and a plain launch keeps one kind of node in them)
+    const int64_t total = n_total_rows * C;
+    const int64_t zb = (total + 1023) / 1024;
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)(zb < 8192 ? zb : 8192)), dim3(256), 0, st, dlogits, ld_dlogits, n_total_rows, C);
   }
   const int rpb = kRowsPerBlock * (C <= 64 ? 4 : 1);
   const int64_t want = (n + rpb - 1) / rpb;

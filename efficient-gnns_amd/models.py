@@ -21,6 +21,7 @@ from .sparse import SparseTensor
 
 
 _EVAL_BN_FOLD = os.environ.get("EGNN_EVAL_BN_FOLD", "1") == "1"   # A/B switch of the eval-mode BatchNorm fold
+_TRAIN_ROWS = os.environ.get("EGNN_TRAIN_ROWS", "1") == "1"       # A/B switch: [train_idx] row picks inside the CE / KD kernels
 
 
 class _Student(nn.Module):
@@ -188,7 +189,7 @@ def train_step_tensors(model, x, adj_t, y, train_idx, optimizer, mode, hp, teach
         if p is not None:
             p.train()
     logits = model(x, adj_t)
-    if logits.is_cuda and y.dim() == 2 and y.shape[1] == 1 and y.dtype == torch.int64:
+    if _TRAIN_ROWS and logits.is_cuda and y.dim() == 2 and y.shape[1] == 1 and y.dtype == torch.int64:
         # gnn.py:109-110 `out = model(...)[train_idx]`, `y.squeeze(1)[train_idx]` (and `teacher_logits[train_idx]`): the row picks
         # happen inside the CE / KD kernels (the criteria's `rows` keyword), their backward writes the dense logits gradient
         loss, loss_cls, loss_aux = distill_loss(mode, model, logits, y.view(-1), train_idx, teacher_out_feat, teacher_logits, hp,

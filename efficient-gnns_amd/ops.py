@@ -664,6 +664,64 @@ def gather_normalize(x: Tensor, idx: Tensor | None = None, eps: float = 1e-12) -
 
 
 # ------------------------------------------------------------------------------------------------
+# FitNet / attention-transfer losses (criterion.py:24-54) as row kernels
+# ------------------------------------------------------------------------------------------------
+class _FeatureLoss(torch.autograd.Function):
+    """kind 'fitnet': mse(F.normalize(f), F.normalize(t));  kind 'at': mse of the per-node energies normalised ACROSS nodes."""
+
+    @staticmethod
+    def forward(ctx, f, t, kind, eps):
+        _lib.require_gpu(f, t)
+        f, t = _rowmajor(f), _rowmajor(t)
+        if f.dim() != 2 or t.dim() != 2 or f.shape[0] != t.shape[0] or (kind == "fitnet" and f.shape[1] != t.shape[1]):
+            raise ValueError(f"{kind}: student features {tuple(f.shape)} and teacher features {tuple(t.shape)} do not match")
+        n = f.shape[0]
+        lib, dev = _lib.load(), f.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        nws = lib.egnn_feature_loss_ws_floats(n)
+        ws = torch.empty(nws, dtype=torch.float32, device=dev)
+        if kind == "fitnet":
+            rc = lib.egnn_fitnet_fwd_f32(_lib.ptr(f), f.stride(0), _lib.ptr(t), t.stride(0), n, f.shape[1], float(eps), _lib.ptr(loss),
+                                         _lib.ptr(ws), nws, _lib.stream())
+        else:
+            rc = lib.egnn_at_fwd_f32(_lib.ptr(f), f.stride(0), f.shape[1], _lib.ptr(t), t.stride(0), t.shape[1], n, float(eps), _lib.ptr(loss),
+                                     _lib.ptr(ws), nws, _lib.stream())
+        _lib.check(rc, f"egnn_{kind}_fwd_f32")
+        ctx.save_for_backward(f, t, ws)
+        ctx.kind, ctx.eps = kind, float(eps)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        f, t, ws = ctx.saved_tensors
+        n = f.shape[0]
+        g = g.contiguous().to(torch.float32).reshape(1)
+        df = torch.empty_like(f) if ctx.needs_input_grad[0] else None
+        dt = torch.empty_like(t) if ctx.needs_input_grad[1] else None
+        lib = _lib.load()
+        if ctx.kind == "fitnet":
+            rc = lib.egnn_fitnet_bwd_f32(_lib.ptr(f), f.stride(0), _lib.ptr(t), t.stride(0), n, f.shape[1], ctx.eps, _lib.ptr(g),
+                                         _lib.ptr(df), 0 if df is None else df.stride(0), _lib.ptr(dt), 0 if dt is None else dt.stride(0),
+                                         _lib.stream())
+        else:
+            rc = lib.egnn_at_bwd_f32(_lib.ptr(f), f.stride(0), f.shape[1], _lib.ptr(t), t.stride(0), t.shape[1], n, ctx.eps, _lib.ptr(ws),
+                                     _lib.ptr(g), _lib.ptr(df), 0 if df is None else df.stride(0), _lib.ptr(dt),
+                                     0 if dt is None else dt.stride(0), _lib.stream())
+        _lib.check(rc, f"egnn_{ctx.kind}_bwd_f32")
+        return df, dt, None, None
+
+
+def fitnet_loss(feat: Tensor, teacher_feat: Tensor, eps: float = 1e-12) -> Tensor:
+    """F.mse_loss(F.normalize(feat), F.normalize(teacher_feat)) in one pass per direction (egnn_fitnet_*_f32)."""
+    return _FeatureLoss.apply(feat, teacher_feat, "fitnet", eps)
+
+
+def at_loss(feat: Tensor, teacher_feat: Tensor, eps: float = 1e-12) -> Tensor:
+    """criterion.py:44-50: per-node energies sum_d x^2, each length-n vector L2-normalised across the nodes, then mse."""
+    return _FeatureLoss.apply(feat, teacher_feat, "at", eps)
+
+
+# ------------------------------------------------------------------------------------------------
 # G-CRD / InfoNCE on unit rows
 # ------------------------------------------------------------------------------------------------
 class _NCE(torch.autograd.Function):

@@ -447,6 +447,23 @@ int egnn_split_accuracy_f32(const float* logits, int64_t ld, int64_t n, int64_t 
 int egnn_rows_add_f32(float* dst, int64_t ld_dst, const int64_t* idx, const float* src, int64_t ld_src, int64_t n, int64_t C,
                       void* stream);
 
+/* FitNet (/root/reference/arxiv_pyg/criterion.py:24-36, ppi_pyg/criterion.py:21-33): loss[0] = mean over n * D of
+ * (F.normalize(f) - F.normalize(t))^2, F.normalize(x) = x / max(||x||_2, eps); one wave per row, fixed-order sums.
+ * bwd: df / dt (nullable) = g[0] * dloss/df, dloss/dt.  ws: egnn_feature_loss_ws_floats(n) floats. */
+size_t egnn_feature_loss_ws_floats(int64_t n);
+int egnn_fitnet_fwd_f32(const float* f, int64_t ldf, const float* t, int64_t ldt, int64_t n, int64_t D, float eps, float* loss,
+                        float* ws, size_t ws_floats, void* stream);
+int egnn_fitnet_bwd_f32(const float* f, int64_t ldf, const float* t, int64_t ldt, int64_t n, int64_t D, float eps, const float* g,
+                        float* df, int64_t lddf, float* dt, int64_t lddt, void* stream);
+
+/* Attention transfer (criterion.py:39-54): e_s[i] = sum_d f[i,d]^2 over Df columns, e_t likewise over Dt; both length-n vectors are
+ * L2-normalised ACROSS the n nodes (the reference's F.normalize on a 1-D tensor) and loss[0] = mean_i (e_s[i]/|e_s| - e_t[i]/|e_t|)^2.
+ * The forward leaves e_s, e_t and its scalars in ws (same size as above); the backward reads them: keep ws until then. */
+int egnn_at_fwd_f32(const float* f, int64_t ldf, int64_t Df, const float* t, int64_t ldt, int64_t Dt, int64_t n, float eps, float* loss,
+                    float* ws, size_t ws_floats, void* stream);
+int egnn_at_bwd_f32(const float* f, int64_t ldf, int64_t Df, const float* t, int64_t ldt, int64_t Dt, int64_t n, float eps, const float* ws,
+                    const float* g, float* df, int64_t lddf, float* dt, int64_t lddt, void* stream);
+
 /* DIAGNOSTIC (measurement only; bench.py's roofline.gather_ceiling_GBs): replays the gather stream of one aggregation call and
  * nothing else -- for every stored entry e, the 128-byte slice s of row col[e] of X [n_src, K] is read by an 8-lane sub-group,
  * slice s by the workgroups with blockIdx % (K / 32) == s (the aggregation kernel's slice <-> XCD binding,

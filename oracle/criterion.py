@@ -2,7 +2,8 @@
 
 Each function follows /root/reference/arxiv_pyg/criterion.py (line ranges in the docstrings) and
 returns the reference's 3-tuple ``(loss, loss_cls, loss_aux)``.  Paper names: LSP = ``lpw``,
-GSP = ``gpw``, G-CRD = ``nce``.  ``ppi_kd_criterion`` follows /root/reference/ppi_pyg/criterion.py:8-18.
+GSP = ``gpw``, G-CRD = ``nce``.  ``ppi_*_criterion`` follow /root/reference/ppi_pyg/criterion.py:8-146 (the same
+feature losses with the multi-label BCE-with-logits classification term).
 
 Pinned against the reference's own file by ``tests/golden/make_golden.py`` (see oracle/__init__.py).
 Host-RNG coupling is preserved: exactly one ``np.random.choice(n, S, replace=False)`` per ``gpw`` /
@@ -130,3 +131,42 @@ def ppi_kd_criterion(logits, labels, teacher_logits, alpha=0.5, T=1):
     loss_cls = F.binary_cross_entropy_with_logits(logits, labels)
     loss_kd = F.binary_cross_entropy_with_logits(logits, torch.sigmoid(teacher_logits))
     return loss_kd * (alpha * T * T) + loss_cls * (1 - alpha), loss_cls, loss_kd
+
+
+def _with_bce(fn):
+    """The PPI flavour of an arxiv criterion: /root/reference/ppi_pyg/criterion.py differs from arxiv_pyg/criterion.py in the
+    classification term only (F.binary_cross_entropy_with_logits, lines 24,42,57,98,132)."""
+    def wrapped(*a, **kw):
+        global _ce
+        prev = _ce
+        _ce = lambda logits, labels: F.binary_cross_entropy_with_logits(logits, labels)   # noqa: E731
+        try:
+            return fn(*a, **kw)
+        finally:
+            _ce = prev
+    return wrapped
+
+
+def ppi_fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000):
+    """ppi_pyg/criterion.py:21-36."""
+    return _with_bce(fitnet_criterion)(logits, labels, feat, teacher_feat, beta)
+
+
+def ppi_at_criterion(logits, labels, feat, teacher_feat, beta=1000):
+    """ppi_pyg/criterion.py:39-54."""
+    return _with_bce(at_criterion)(logits, labels, feat, teacher_feat, beta)
+
+
+def ppi_gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, max_samples=8192):
+    """ppi_pyg/criterion.py:57-92."""
+    return _with_bce(gpw_criterion)(logits, labels, feat, teacher_feat, kernel, beta, max_samples)
+
+
+def ppi_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="cosine", beta=100, criterion="kld"):
+    """ppi_pyg/criterion.py:95-126."""
+    return _with_bce(lpw_criterion)(logits, labels, feat, teacher_feat, edge_index, kernel, beta, criterion)
+
+
+def ppi_nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max_samples=8192):
+    """ppi_pyg/criterion.py:129-149."""
+    return _with_bce(nce_criterion)(logits, labels, feat, teacher_feat, beta, nce_T, max_samples)

@@ -33,6 +33,11 @@ def golden_criterion():
 
 
 @pytest.fixture(scope="session")
+def golden_criterion_ppi():
+    return np.load(os.path.join(GOLDEN, "criterion_ppi.npz"))
+
+
+@pytest.fixture(scope="session")
 def golden_ppi_teacher():
     return np.load(os.path.join(GOLDEN, "ppi_teacher.npz"), allow_pickle=False)
 

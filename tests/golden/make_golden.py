@@ -7,7 +7,8 @@ Run only in the build container (needs /root/reference; the GPU box has no copy)
 
 What is executed for real (imported from /root/reference, unmodified):
   * arxiv_pyg/criterion.py   -> kd / fitnet / at / gpw / lpw / nce criteria
-  * ppi_pyg/criterion.py     -> multi-label kd_criterion
+  * ppi_pyg/criterion.py     -> multi-label kd_criterion (criterion.npz) and the BCE-flavoured fitnet / at / gpw / lpw / nce
+                                criteria (criterion_ppi.npz)
   * arxiv_pyg/gnn.py         -> GCN, SAGE, ProjectionGCD, train(), test()
   * arxiv_pyg/gnn_kd_and_aux.py -> train() (KD + aux combination rule)
   * ppi_pyg/gnn.py           -> GAT and TeacherNet (the frozen teacher the PPI student step runs, :208-209), GCN,
@@ -185,6 +186,42 @@ def make_criterion_goldens():
             out[f"{name}__{k}"] = v
     np.savez_compressed(os.path.join(HERE, "criterion.npz"), **out)
     print("criterion.npz:", len(cases), "cases")
+
+
+def ppi_criterion_cases(ref_module, d, py):
+    """(name -> callable(leaves)) of the PPI auxiliary criteria on the shared toy inputs; ``ref_module`` = the reference's
+    ppi_pyg/criterion.py (generator) or a module with the same six names (tests)."""
+    cases = {
+        "ppi_fitnet": (lambda L: ref_module.fitnet_criterion(L["logits"], py, L["feat"], L["tfeat"], 1000), "p", None),
+        "ppi_at": (lambda L: ref_module.at_criterion(L["logits"], py, L["feat"], L["tfeat"], 1000), "raw", None),
+        "ppi_nce_full": (lambda L: ref_module.nce_criterion(L["logits"], py, L["feat"], L["tfeat"], 0.1, 0.075, 8192), "p", None),
+        "ppi_nce_sub": (lambda L: ref_module.nce_criterion(L["logits"], py, L["feat"], L["tfeat"], 0.1, 0.075, 32), "p", 7),
+    }
+    for kern in ("cosine", "rbf"):
+        cases[f"ppi_gpw_{kern}_sub"] = (lambda L, kern=kern: ref_module.gpw_criterion(L["logits"], py, L["feat"], L["tfeat"], kern, 2.0, 32), "p", 123)
+        cases[f"ppi_lpw_{kern}_kld"] = (lambda L, kern=kern: ref_module.lpw_criterion(L["logits"], py, L["feat"], L["tfeat"], d["edge_index"],
+                                                                                       kern, 100, "kld"), "raw", None)
+    return cases
+
+
+def make_ppi_criterion_goldens():
+    """The auxiliary criteria of the reference's ppi_pyg/criterion.py:21-146 (multi-label BCE classification term) -- a file of
+    its own, so that criterion.npz keeps regenerating bit for bit."""
+    refp = load_ref("ppi_pyg/criterion.py", "ref_ppi_criterion_aux")
+    d = criterion_inputs()
+    g = torch.Generator().manual_seed(6)
+    n, C = d["logits"].shape
+    py = (torch.rand(n, C, generator=g) < 0.3).float()
+    out = {"in_ppi_labels": t2n(py)}
+    n_cases = 0
+    for name, (fn, which, seed) in ppi_criterion_cases(refp, d, py).items():
+        leaves = {"logits": d["logits"], "feat": d["feat_p"] if which == "p" else d["feat"], "tfeat": d["tfeat_p"] if which == "p" else d["tfeat"]}
+        rec = run_criterion_case(fn, leaves, np_seed=seed)
+        for k, v in rec.items():
+            out[f"{name}__{k}"] = v
+        n_cases += 1
+    np.savez_compressed(os.path.join(HERE, "criterion_ppi.npz"), **out)
+    print("criterion_ppi.npz:", n_cases, "cases")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -565,3 +602,4 @@ if __name__ == "__main__":
     make_mag_rgcn_goldens()
     make_ppi_train_goldens()
     make_arxiv_gat_goldens()
+    make_ppi_criterion_goldens()

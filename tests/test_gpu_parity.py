@@ -354,6 +354,35 @@ def test_gemm_all_layouts(M, N, K, ta, tb):
     close(out, ref, rtol=1e-5, atol_scale=2e-6, msg=f"{M}x{N}x{K} ta={ta} tb={tb}")
 
 
+@pytest.mark.parametrize("M,N,K", [(5000, 256, 256), (4097, 128, 64), (169343, 256, 128), (8192, 384, 96)])
+@pytest.mark.parametrize("tb", [False, True])
+def test_gemm_dma_form_tall_a_small_b(M, N, K, tb):
+    """The DMA form of egnn_gemm_f32 (csrc/gemm3.h: A by LDS-DMA as fp32 and cut on the fragment side, B cut once into
+    tile-packed bf16 planes): tall A with a ragged last row tile, both weight layouts, bias and the fused ReLU, against a float64
+    product; and bit-equal to itself across launches."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-6, 6, (M, K), generator=g).float())).to(DEV)
+    w = (torch.randn(N, K, generator=g) if tb else torch.randn(K, N, generator=g)).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    ref = a.double() @ (w.double().t() if tb else w.double()) + bias.double()
+    scale = (a.double().abs() @ (w.double().abs().t() if tb else w.double().abs())) + bias.double().abs()
+    for relu in (False, True):
+        y = ops.gemm_raw(a, w, False, tb, bias=bias, relu=relu)
+        r = torch.relu(ref) if relu else ref
+        assert float(((y.double() - r).abs() / scale).max()) < 1e-6
+        assert torch.equal(y, ops.gemm_raw(a, w, False, tb, bias=bias, relu=relu))
+    # autograd through linear / matmul at a DMA-form size
+    x = a[:6000].clone().requires_grad_(True)
+    wp = w.clone().requires_grad_(True)
+    out = ops.linear(x, wp, bias) if tb else ops.matmul(x, wp, bias)
+    gy = torch.randn(6000, N, generator=g).to(DEV)
+    out.backward(gy)
+    xd, wd = a[:6000].double().requires_grad_(True), w.double().requires_grad_(True)
+    (xd @ (wd.t() if tb else wd) + bias.double()).backward(gy.double())
+    close(x.grad, xd.grad, rtol=1e-4, atol_scale=2e-5)
+    close(wp.grad, wd.grad, rtol=1e-4, atol_scale=2e-5)
+
+
 @pytest.mark.parametrize("M,N,K", [(5000, 40, 256), (4099, 64, 128), (9001, 7, 64), (6000, 48, 16)])
 @pytest.mark.parametrize("tb", [False, True])
 def test_gemm_skinny_output_layer_forms(M, N, K, tb):
@@ -733,6 +762,63 @@ def test_criteria_match_reference_goldens(golden_criterion):
         except AssertionError as ex:
             failures.append(f"{name}: {str(ex)[:300]}")
     assert not failures, "\n".join(failures)
+
+
+def test_ppi_auxiliary_criteria_match_reference_goldens(golden_criterion, golden_criterion_ppi):
+    """The PPI drop-in's fitnet / at / gpw / lpw / nce (multi-label BCE classification term) on the kernels against the goldens
+    produced by the reference's own ppi_pyg/criterion.py:21-146 -- through the module ``dropin/launch.py`` puts in front of the
+    ppi_pyg scripts, i.e. under the reference's names."""
+    import importlib.util
+    import types
+    from test_oracle_golden import ppi_aux_cases
+    path = os.path.join(os.path.dirname(os.path.abspath(PC.__file__)), "dropin", "ppi_pyg", "criterion.py")
+    spec = importlib.util.spec_from_file_location("_ppi_dropin_criterion", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    shim = types.SimpleNamespace(ppi_fitnet_criterion=mod.fitnet_criterion, ppi_at_criterion=mod.at_criterion, ppi_gpw_criterion=mod.gpw_criterion,
+                                 ppi_lpw_criterion=mod.lpw_criterion, ppi_nce_criterion=mod.nce_criterion)
+    Gp = golden_criterion_ppi
+    failures = []
+    for name, fn, leaves, seed in ppi_aux_cases(golden_criterion, Gp, shim, DEV):
+        try:
+            rec = _run_case(fn, leaves, seed)
+            for k, v in rec.items():
+                ref = Gp[f"{name}__{k}"]
+                if v is None:
+                    assert ref.size == 0 or np.abs(ref).max() == 0, f"{name}:{k} missing grad"
+                    continue
+                close(v, ref, rtol=2e-5 if k.startswith("loss") else 1e-4, atol_scale=1e-5 if not k.startswith("loss") else 0, msg=f"{name}:{k}")
+        except AssertionError as ex:
+            failures.append(f"{name}: {str(ex)[:300]}")
+    assert not failures, "\n".join(failures)
+
+
+@pytest.mark.parametrize("n,Ds,Dt", [(1, 8, 8), (777, 256, 256), (5000, 128, 128), (3001, 64, 750)])
+def test_fitnet_and_at_kernels_vs_oracle(n, Ds, Dt):
+    """egnn_fitnet_* / egnn_at_* (criterion.py:24-54) against the oracle at sizes beyond the goldens, with all-zero rows (the
+    eps clamp of F.normalize: constant denominator, no projection term in the gradient)."""
+    g = torch.Generator().manual_seed(n)
+    logits, labels = torch.randn(n, 5, generator=g), torch.randint(0, 5, (n,), generator=g)
+    f = torch.relu(torch.randn(n, Ds, generator=g))
+    t = torch.relu(torch.randn(n, Dt, generator=g)) * 0.7
+    if n > 10:
+        f[3] = 0.0
+        t[5] = 0.0
+    for name in ("fitnet", "at"):
+        if name == "fitnet" and Ds != Dt:
+            with pytest.raises(ValueError):
+                E.fitnet_criterion(logits.to(DEV), labels.to(DEV), f.to(DEV), t.to(DEV))
+            continue
+        fo, to_ = f.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        fp, tp = f.to(DEV).requires_grad_(True), t.to(DEV).requires_grad_(True)
+        ref = getattr(OC, f"{name}_criterion")(logits, labels, fo, to_, 1000)
+        out = getattr(E, f"{name}_criterion")(logits.to(DEV), labels.to(DEV), fp, tp, 1000)
+        close(out[2], ref[2], rtol=2e-5, atol_scale=0, msg=f"{name} loss_aux")
+        close(out[0], ref[0], rtol=2e-5, atol_scale=0, msg=f"{name} loss")
+        ref[0].backward()
+        out[0].backward()
+        close(fp.grad, fo.grad, rtol=1e-4, atol_scale=2e-5, msg=f"{name} d feat")
+        close(tp.grad, to_.grad, rtol=1e-4, atol_scale=2e-5, msg=f"{name} d teacher_feat")
 
 
 def test_ppi_kd_matches_reference_golden(golden_criterion):

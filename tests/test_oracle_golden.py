@@ -1,4 +1,7 @@
 """Oracle vs the golden vectors produced by the reference's own files (tests/golden/make_golden.py)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -65,6 +68,34 @@ def test_criteria_match_reference(golden_criterion):
     assert len(cases) == 22
     for name, fn, leaves, seed in cases:
         _check(_run(fn, leaves, seed), G, name)
+
+
+def ppi_aux_cases(G, Gp, mod, dev="cpu"):
+    """(name, fn(leaves) -> triple, leaves, np_seed) of tests/golden/criterion_ppi.npz for a module with ppi_*_criterion functions."""
+    import types
+    d = {k[3:]: as_t(G[k], dev) for k in G.files if k.startswith("in_") and not k.startswith("in_ppi")}
+    py = as_t(Gp["in_ppi_labels"], dev)
+    names = types.SimpleNamespace(fitnet_criterion=mod.ppi_fitnet_criterion, at_criterion=mod.ppi_at_criterion,
+                                  gpw_criterion=mod.ppi_gpw_criterion, lpw_criterion=mod.ppi_lpw_criterion, nce_criterion=mod.ppi_nce_criterion)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_mk_golden_cases", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)          # only its case table is used (nothing under /root/reference is touched at import)
+    out = []
+    for name, (fn, which, seed) in mg.ppi_criterion_cases(names, d, py).items():
+        leaves = {"logits": d["logits"], "feat": d["feat_p"] if which == "p" else d["feat"], "tfeat": d["tfeat_p"] if which == "p" else d["tfeat"]}
+        out.append((name, fn, leaves, seed))
+    return out
+
+
+def test_ppi_auxiliary_criteria_match_reference(golden_criterion, golden_criterion_ppi):
+    """The BCE-flavoured fitnet / at / gpw / lpw / nce of /root/reference/ppi_pyg/criterion.py:21-146 (goldens produced by that
+    file itself) against the oracle's restatement: losses and gradients."""
+    cases = ppi_aux_cases(golden_criterion, golden_criterion_ppi, OC)
+    assert len(cases) == 8
+    for name, fn, leaves, seed in cases:
+        _check(_run(fn, leaves, seed), golden_criterion_ppi, name)
 
 
 def test_ppi_kd_matches_reference(golden_criterion):
