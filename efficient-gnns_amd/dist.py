@@ -907,7 +907,9 @@ class ShardedGraphedEpoch:
             self.graph = torch.cuda.CUDAGraph()
             self._refresh()
             torch.cuda.synchronize(dev)
-            with torch.cuda.graph(self.graph):
+            # thread-local capture mode: the process group's watchdog thread polls the events of the warm-up collectives; in the
+            # default (global) mode a call from ANY thread invalidates the capture (seen: abort in capture_end)
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.rep, self.correct = body()
             torch.cuda.synchronize(dev)
         finally:

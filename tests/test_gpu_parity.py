@@ -372,12 +372,13 @@ def test_gemm_dma_form_tall_a_small_b(M, N, K, tb):
         assert float(((y.double() - r).abs() / scale).max()) < 1e-6
         assert torch.equal(y, ops.gemm_raw(a, w, False, tb, bias=bias, relu=relu))
     # autograd through linear / matmul at a DMA-form size
-    x = a[:6000].clone().requires_grad_(True)
+    m2 = min(M, 6000)
+    x = a[:m2].clone().requires_grad_(True)
     wp = w.clone().requires_grad_(True)
     out = ops.linear(x, wp, bias) if tb else ops.matmul(x, wp, bias)
-    gy = torch.randn(6000, N, generator=g).to(DEV)
+    gy = torch.randn(m2, N, generator=g).to(DEV)
     out.backward(gy)
-    xd, wd = a[:6000].double().requires_grad_(True), w.double().requires_grad_(True)
+    xd, wd = a[:m2].double().requires_grad_(True), w.double().requires_grad_(True)
     (xd @ (wd.t() if tb else wd) + bias.double()).backward(gy.double())
     close(x.grad, xd.grad, rtol=1e-4, atol_scale=2e-5)
     close(wp.grad, wd.grad, rtol=1e-4, atol_scale=2e-5)
@@ -1270,57 +1271,16 @@ def test_sharded_path_with_one_rank_over_rccl_matches_single_gpu_path(gnn, mode)
 @pytest.mark.parametrize("gnn,mode", [("gcn", "nce"), ("sage", "kd"), ("sage", "lpw")])
 def test_sharded_epoch_captured_as_a_graph_replays_the_eager_steps(gnn, mode):
     """dist.ShardedGraphedEpoch (one rank over RCCL): the captured epoch -- collectives included -- reproduces the eager sharded
-    steps (same host draw, dropout 0): losses and accuracies of three replays equal three eager steps to fp32 rounding."""
-    import torch.distributed as dist
-    import efficient_gnns_amd.dist as DD
-    import copy
-    created = False
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29578", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-        created = True
-    try:
-        d = D.arxiv_like(scale=0.02, seed=5)
-        hp = dict(alpha=0.9, kd_T=4.0, beta=0.1 if mode == "nce" else 100.0, nce_T=0.075, max_samples=512, kernel="cosine")
-        prob = DD.ShardedProblem(d, 1, 0, torch.device(DEV, 0), None, need_gcn=(gnn == "gcn"))
-
-        def build():
-            torch.manual_seed(0)
-            m = DD.swap_batchnorm((PM.GCN if gnn == "gcn" else PM.SAGE)(d.num_features, 64, d.num_classes, 3, 0.0).to(DEV))
-            sp = tp = None
-            params = list(m.parameters())
-            if mode == "nce":
-                sp = DD.swap_batchnorm(PM.make_projection(64, 32).to(DEV))
-                tp = DD.swap_batchnorm(PM.make_projection(750, 32).to(DEV))
-                params += list(sp.parameters()) + list(tp.parameters())
-            return m, sp, tp, torch.optim.Adam(params, lr=0.01, fused=True, capturable=True)
-        m1, sp1, tp1, o1 = build()
-        m2, sp2, tp2, o2 = build()
-        np.random.seed(3)
-        eager = []
-        for _ in range(3):
-            l = DD.sharded_train_step(m1, prob, o1, mode, hp, sp1, tp1)
-            _, a = DD.sharded_evaluate(m1, prob)
-            eager.append((l, a))
-        # the graph's constructor runs `warmup` untimed steps on the model: give it a throw-away twin state, then restore
-        state = [copy.deepcopy(x.state_dict()) if x is not None else None for x in (m2, sp2, tp2)]
-        ge = DD.ShardedGraphedEpoch(m2, prob, o2, mode, hp, sp2, tp2, warmup=2)
-        for x, st in zip((m2, sp2, tp2), state):
-            if x is not None:
-                x.load_state_dict(st)
-        for grp in o2.param_groups:          # Adam state back to step 0
-            for p_ in grp["params"]:
-                stt = o2.state[p_]
-                if stt:
-                    stt["exp_avg"].zero_(); stt["exp_avg_sq"].zero_(); stt["step"].zero_()
-        np.random.seed(3)
-        ge._refresh()
-        got = [ge.step() for _ in range(3)]
-        for (le, ae), (lg, ag) in zip(eager, got):
-            np.testing.assert_allclose(np.array(lg), np.array(le), rtol=2e-4, atol=1e-7)
-            np.testing.assert_allclose(np.array(ag), np.array(ae), atol=2e-3)
-    finally:
-        if created:
-            dist.destroy_process_group()
+    steps (same host draw, dropout 0).  Runs in its own interpreter (tools/checks/sharded_graph_check.py), as bench.py does: a
+    process that has captured RCCL work into a graph keeps communicator threads alive that must not sit next to later,
+    unrelated captures of the same test process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "checks", "sharded_graph_check.py"), "--gnn", gnn, "--mode", mode],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    assert "SHARDED-GRAPH-OK" in p.stdout
 
 
 @pytest.mark.gpu
