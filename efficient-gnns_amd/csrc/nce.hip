@@ -522,11 +522,17 @@ __global__ __launch_bounds__(256, OCC) void nce3_bwd_kernel(const float* __restr
   }
 }
 
-constexpr int kNce3Split = 8;   // k ranges of the reduction (fixed-order reduce afterwards)
+constexpr int kNce3SplitMax = 8;   // k ranges of the reduction (fixed-order reduce afterwards); the workspace is sized for the maximum
+static inline int nce3_split() {
+  // 4 k-ranges: 2 378 vs 2 433 us (8) vs 2 718 us (2) for forward + backward at S = 16 384, P = 256 (fewer partials to reduce, still one
+  // workgroup per CU on the 256 x 256 side); EGNN_NCE_KSPLIT = 2 | 4 | 8 is the lab knob
+  static const int n = getenv("EGNN_NCE_KSPLIT") ? atoi(getenv("EGNN_NCE_KSPLIT")) : 4;
+  return n == 2 || n == 8 ? n : 4;
+}
 
 // floats of workspace the DMA backward needs for one side: partials + the packed planes of the small operand (+ slack for alignment)
 inline size_t nce3_ws_floats(int64_t M, int64_t P, int64_t Kd) {
-  return (size_t)kNce3Split * M * P + (egnn_gemm3::planes_bytes(P, Kd, 256, 32) + 1024) / 4;
+  return (size_t)kNce3SplitMax * M * P + (egnn_gemm3::planes_bytes(P, Kd, 256, 32) + 1024) / 4;
 }
 
 // true when this side of the backward can take the DMA pipeline (whole tiles, aligned E, unit-rows form with a workspace)
@@ -534,8 +540,8 @@ template <int AMAJ>
 inline bool nce3_takes(int64_t M, int64_t Kd, int64_t P, int64_t ldz, const float* Z, bool expz, bool vec4, const float* ws) {
   static const bool off = getenv("EGNN_NCE_DMA") && getenv("EGNN_NCE_DMA")[0] == '0';   // A/B switch: EGNN_NCE_DMA=0 keeps the staged pipeline
   constexpr int BM = AMAJ == KMAJOR ? 128 : 256, BN = AMAJ == KMAJOR ? 128 : 256, BKT = AMAJ == KMAJOR ? 32 : 16;
-  return !off && egnn_split_pipe() && expz && vec4 && ws && M % BM == 0 && P % BN == 0 && Kd % (kNce3Split * BKT) == 0 && ldz % 4 == 0 &&
-         egnn_aligned16(Z) && Kd / kNce3Split >= 4 * BKT;
+  return !off && egnn_split_pipe() && expz && vec4 && ws && M % BM == 0 && P % BN == 0 && Kd % (kNce3SplitMax * BKT) == 0 && ldz % 4 == 0 &&
+         egnn_aligned16(Z) && Kd / kNce3SplitMax >= 4 * BKT;
 }
 
 template <int AMAJ>
@@ -543,7 +549,8 @@ int launch_bwd3(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag
                 int64_t ldb, const float* Im, int64_t ldi, float coef, const float* g, float* C, int64_t ldc, float* ws, hipStream_t st) {
   using namespace egnn_gemm3;
   float* partial = ws;
-  char* planes = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws + (size_t)kNce3Split * M * P) + 1023) & ~(uintptr_t)1023);
+  const int kNce3Split = nce3_split();
+  char* planes = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws + (size_t)kNce3SplitMax * M * P) + 1023) & ~(uintptr_t)1023);
   const int64_t k_per_split = Kd / kNce3Split;
   int rc;
   if constexpr (AMAJ == KMAJOR) {
