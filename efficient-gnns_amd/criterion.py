@@ -85,7 +85,7 @@ def rows_fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=No
     """``fitnet_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
     loss_cls = _CLS(logits, labels, rows)
     loss_aux = ops.fitnet_loss(feat, teacher_feat)
-    return loss_cls + beta * loss_aux, loss_cls, loss_aux
+    return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 
 
 def at_criterion(logits, labels, feat, teacher_feat, beta=1000):
@@ -97,7 +97,7 @@ def rows_at_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=None):
     """``at_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
     loss_cls = _CLS(logits, labels, rows)
     loss_aux = ops.at_loss(feat, teacher_feat)
-    return loss_cls + beta * loss_aux, loss_cls, loss_aux
+    return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 
 
 def gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, max_samples=8192):
@@ -105,15 +105,16 @@ def gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, m
     return rows_gpw_criterion(logits, labels, feat, teacher_feat, kernel, beta, max_samples, rows=None)
 
 
-def rows_gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, max_samples=8192, rows=None):
-    """``gpw_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
+def rows_gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, max_samples=8192, rows=None, presampled=False):
+    """``gpw_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call).
+    ``presampled``: ``feat`` / ``teacher_feat`` already are the sampled rows (the caller made the draw with ``_sample_rows``)."""
     from .ops_pairwise import gsp_loss
     if kernel not in ("cosine", "poly", "l2", "rbf"):
         raise NotImplementedError
     loss_cls = _CLS(logits, labels, rows)
-    idx = _sample_rows(feat.shape[0], max_samples, feat.device)
+    idx = None if presampled else _sample_rows(feat.shape[0], max_samples, feat.device)
     loss_aux = gsp_loss(feat, teacher_feat, idx, kernel)
-    return loss_cls + beta * loss_aux, loss_cls, loss_aux
+    return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 
 
 def lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="cosine", beta=100, criterion="kld"):
@@ -128,7 +129,7 @@ def rows_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="c
         raise NotImplementedError
     loss_cls = _CLS(logits, labels, rows)
     loss_aux = lsp_loss(feat, teacher_feat, edge_index, kernel, criterion)
-    return loss_cls + beta * loss_aux, loss_cls, loss_aux
+    return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 
 
 def nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max_samples=8192):
@@ -136,14 +137,15 @@ def nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max
     return rows_nce_criterion(logits, labels, feat, teacher_feat, beta, nce_T, max_samples, rows=None)
 
 
-def rows_nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max_samples=8192, rows=None):
-    """``nce_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
+def rows_nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max_samples=8192, rows=None, presampled=False):
+    """``nce_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call).
+    ``presampled``: as in ``rows_gpw_criterion``."""
     loss_cls = _CLS(logits, labels, rows)
-    idx = _sample_rows(feat.shape[0], max_samples, feat.device)
+    idx = None if presampled else _sample_rows(feat.shape[0], max_samples, feat.device)
     fhat = ops.gather_normalize(feat, idx)
     that = ops.gather_normalize(teacher_feat, idx)
     loss_aux = ops.nce_unit(fhat, that, nce_T)
-    return loss_cls + beta * loss_aux, loss_cls, loss_aux
+    return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 
 
 class _PpiCriteria:

@@ -22,6 +22,8 @@ from .sparse import SparseTensor
 
 _EVAL_BN_FOLD = os.environ.get("EGNN_EVAL_BN_FOLD", "1") == "1"   # A/B switch of the eval-mode BatchNorm fold
 _TRAIN_ROWS = os.environ.get("EGNN_TRAIN_ROWS", "1") == "1"       # A/B switch: [train_idx] row picks inside the CE / KD kernels
+_FUSED_TAIL = os.environ.get("EGNN_FUSED_TAIL", "1") == "1"        # A/B switch: ops.bn_act_linear for the last hidden layer of a GCN
+_SAMPLED_HEADS = os.environ.get("EGNN_SAMPLED_HEADS", "1") == "1"  # A/B switch: projection heads form only the rows a sampled criterion keeps
 
 
 class _Student(nn.Module):
@@ -37,8 +39,17 @@ class _Student(nn.Module):
         for m in list(self.convs) + list(self.bns):
             m.reset_parameters()
 
+    def _fused_tail(self, x, adj_t):
+        """True when the last hidden layer's BatchNorm + activation and the output conv's narrow ``x @ W`` can run as one op
+        (``ops.bn_act_linear``): GCN on a plain SparseTensor adjacency, training, classes <= 64."""
+        last = self.convs[-1]
+        return (_FUSED_TAIL and self.training and torch.is_grad_enabled() and x.is_cuda and isinstance(adj_t, SparseTensor)
+                and isinstance(last, GCNConv) and type(self.bns[-1]) is nn.BatchNorm1d and last.in_channels >= last.out_channels
+                and last.out_channels <= 64 and last.in_channels % 64 == 0 and not hasattr(adj_t, "gcn_normalized"))
+
     def forward(self, x, adj_t):
-        for conv, bn in zip(self.convs[:-1], self.bns):
+        n_hidden = len(self.bns)
+        for li, (conv, bn) in enumerate(zip(self.convs[:-1], self.bns)):
             if (_EVAL_BN_FOLD and not self.training and not torch.is_grad_enabled() and isinstance(conv, GCNConv) and type(bn) is nn.BatchNorm1d
                     and bn.track_running_stats and x.is_cuda and isinstance(adj_t, SparseTensor) and not conv._uses_memoised_input(x)):
                 # test(): BatchNorm on running statistics folded into the conv's weights, ReLU in the last kernel's store
@@ -50,6 +61,13 @@ class _Student(nn.Module):
                 x = conv(x, adj_t, bn_stats_shift=bn.running_mean, want_bn_stats=True)
             else:
                 x = conv(x, adj_t)
+            if li == n_hidden - 1 and self._fused_tail(x, adj_t):
+                # last hidden layer: BatchNorm + ReLU + dropout, the gradient tap and the output conv's x @ W as one op, whose
+                # backward is one pass over the [N, hidden] tensors (ops._BnActLinear)
+                both = ops.bn_act_linear(x, bn, self.convs[-1].weight, relu=True, p=self.dropout, training=True)
+                if both is not None:
+                    self.out_feat, xw = both
+                    return self.convs[-1](self.out_feat, adj_t, xw=xw)
             if isinstance(bn, nn.BatchNorm1d) and x.is_cuda:   # fused BN + ReLU + dropout kernels (gnn.py:48-50)
                 x = ops.bn_act(x, bn, relu=True, p=self.dropout, training=self.training)
             elif hasattr(bn, "fused_act"):                      # dist.SyncBatchNorm1d on sharded runs (all-rank statistics)
@@ -104,17 +122,22 @@ class ProjectionHead(nn.Sequential):
             return super().forward(x)
         return ops.bn_act(ops.linear(x, lin.weight, lin.bias), bn, relu=True, p=0.0, training=self.training)
 
-    def forward_rows(self, x, idx):
-        """``self(x[idx])`` for unique row ids: the gather is fused into the GEMM's operand load (gnn.py:150-156)."""
+    def forward_rows(self, x, idx, pick=None):
+        """``self(x[idx])`` for unique row ids: the gather is fused into the GEMM's operand load (gnn.py:150-156).
+        ``pick`` (unique ids into ``idx``): ``self(x[idx])[pick]`` -- what a sampled criterion keeps of the head's output
+        (criterion.py:62-65,134-137); the BatchNorm statistics span all of ``idx``, only the picked rows are normalised and stored."""
         lin, bn = self[0], self[1]
         if not _lib.on_gpu(x):
-            return self(x[idx])
+            y = self(x[idx])
+            return y if pick is None else y[pick]
         y = ops.linear_rows(x, idx, lin.weight, lin.bias)
         if hasattr(bn, "fused_act"):                            # dist.SyncBatchNorm1d
-            return bn.fused_act(y, True, 0.0, self.training)
+            y = bn.fused_act(y, True, 0.0, self.training)
+            return y if pick is None else y[pick]
         if not isinstance(bn, nn.BatchNorm1d):
-            return self[2](bn(y))
-        return ops.bn_act(y, bn, relu=True, p=0.0, training=self.training)
+            y = self[2](bn(y))
+            return y if pick is None else y[pick]
+        return ops.bn_act(y, bn, relu=True, p=0.0, training=self.training, pick=pick)
 
 
 def make_projection(in_dim, proj_dim):
@@ -149,10 +172,16 @@ def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_
         return loss, loss, loss * 0
     if mode == "kd":
         return C.rows_kd_criterion(out, labels, kd_teacher(), hp["alpha"], hp["kd_T"], rows=rows)
+    picked = False
     if mode in ("fitnet", "gpw", "nce"):
         if hasattr(student_proj, "forward_rows") and hasattr(teacher_proj, "forward_rows") and not _CACHE_CONST_ROWS:
-            f = student_proj.forward_rows(model.out_feat, train_idx)       # proj(feat[train_idx]) without the copies
-            t = teacher_proj.forward_rows(teacher_out_feat, train_idx)
+            pick = None
+            if mode in ("gpw", "nce") and _SAMPLED_HEADS and _lib.on_gpu(model.out_feat):
+                # the criterion's one host draw (criterion.py:62-65,134-137), made here: the heads then form only the sampled rows
+                pick = C._sample_rows(train_idx.numel(), hp["max_samples"], model.out_feat.device)
+                picked = pick is not None
+            f = student_proj.forward_rows(model.out_feat, train_idx, pick=pick)   # proj(feat[train_idx]) without the copies
+            t = teacher_proj.forward_rows(teacher_out_feat, train_idx, pick=pick)
         else:
             f = student_proj(ops.take_rows(model.out_feat, train_idx))
             t = teacher_proj(_const_rows(teacher_out_feat, train_idx))
@@ -168,11 +197,11 @@ def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_
     elif mode == "at":
         res = C.rows_at_criterion(out, labels, f, t, hp["beta"], rows=rows)
     elif mode == "gpw":
-        res = C.rows_gpw_criterion(out, labels, f, t, hp["kernel"], hp["beta"], hp["max_samples"], rows=rows)
+        res = C.rows_gpw_criterion(out, labels, f, t, hp["kernel"], hp["beta"], hp["max_samples"], rows=rows, presampled=picked)
     elif mode == "lpw":
         res = C.rows_lpw_criterion(out, labels, f, t, edge_index, hp["kernel"], hp["beta"], rows=rows)
     else:
-        res = C.rows_nce_criterion(out, labels, f, t, hp["beta"], hp["nce_T"], hp["max_samples"], rows=rows)
+        res = C.rows_nce_criterion(out, labels, f, t, hp["beta"], hp["nce_T"], hp["max_samples"], rows=rows, presampled=picked)
     if not kd_and_aux:
         return res
     loss_aux = res[2]

@@ -97,12 +97,14 @@ class GCNConv(nn.Module):
         self._cached_ax = None
 
     def forward(self, x: Tensor, edge_index, edge_weight=None, bn_stats_shift: Tensor | None = None, want_bn_stats: bool = False,
-                eval_bn=None) -> Tensor:
+                eval_bn=None, xw: Tensor | None = None) -> Tensor:
         """``bn_stats_shift`` / ``want_bn_stats`` (extension, off by default): the caller applies a BatchNorm to the result next
         and wants its column statistics formed in the aggregation's epilogue (``ops.spmm``).
         ``eval_bn`` (extension, no autograd): an eval-mode ``BatchNorm1d`` that follows, with a ReLU behind it (gnn.py:47-49 under
         ``model.eval()``): returns ``relu(eval_bn(conv(x)))`` with the BatchNorm folded into W / b (``ops.bn_fold``) and the ReLU
-        in the last kernel's store -- the separate normalisation pass disappears from ``test()``."""
+        in the last kernel's store -- the separate normalisation pass disappears from ``test()``.
+        ``xw`` (extension): ``x @ self.weight`` when the caller has it already (``ops.bn_act_linear`` forms it together with x); only
+        taken on the transform-first order of a plain SparseTensor adjacency."""
         if edge_weight is not None:
             raise NotImplementedError("GCNConv with edge_weight is not used by the reference")
         agg_first = self.in_channels < self.out_channels
@@ -148,7 +150,7 @@ class GCNConv(nn.Module):
             return out + self.bias if self.bias is not None else out
         if agg_first:
             return ops.matmul(ops.spmm(norm, x, "sum"), self.weight, self.bias)
-        return ops.spmm(norm, ops.matmul(x, self.weight), "sum", bias=self.bias,  # bias added in the kernel's store
+        return ops.spmm(norm, ops.matmul(x, self.weight) if xw is None else xw, "sum", bias=self.bias,  # bias added in the kernel's store
                         bn_stats_shift=bn_stats_shift, want_bn_stats=want_bn_stats)
 
     def _uses_memoised_input(self, x: Tensor) -> bool:

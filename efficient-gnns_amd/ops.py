@@ -815,24 +815,37 @@ def _bn_shape_ok(x: Tensor) -> bool:
 
 
 class _BnAct(torch.autograd.Function):
+    """``pick`` (int64 [S], unique row ids) = form only the output rows ``pick``: y[i] = act(bn(x[pick[i]])) -- the statistics still span
+    all rows of x, and so does dx (egnn_bn_act_rows_*_f32)."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, mean, var, eps, relu, p, seed, batch_stats):
+    def forward(ctx, x, gamma, beta, mean, var, eps, relu, p, seed, batch_stats, pick=None):
         x = _rowmajor(x)
         n, C = x.shape
-        y = torch.empty(n, C, dtype=torch.float32, device=x.device)
         seed_dev = _DROPOUT_SEED_DEV if p > 0 else None
-        rc = _lib.load().egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
-                                             _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(seed_dev), _lib.ptr(y), y.stride(0),
-                                             _lib.stream())
-        _lib.check(rc, "egnn_bn_act_fwd_f32")
-        ctx.save_for_backward(x, gamma, beta, mean, var)
+        if pick is None:
+            y = torch.empty(n, C, dtype=torch.float32, device=x.device)
+            rc = _lib.load().egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
+                                                 _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(seed_dev), _lib.ptr(y), y.stride(0),
+                                                 _lib.stream())
+            _lib.check(rc, "egnn_bn_act_fwd_f32")
+        else:
+            if pick.dtype != torch.int64 or pick.dim() != 1 or not pick.is_contiguous() or pick.numel() > n or pick.numel() == 0:
+                raise ValueError("bn_act: `pick` must be a non-empty contiguous 1-D int64 tensor of unique row ids")
+            y = torch.empty(pick.numel(), C, dtype=torch.float32, device=x.device)
+            rc = _lib.load().egnn_bn_act_rows_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(pick), pick.numel(), _lib.ptr(mean), _lib.ptr(var),
+                                                      float(eps), _lib.ptr(gamma), _lib.ptr(beta), int(relu), float(p), int(seed),
+                                                      _lib.ptr(seed_dev), _lib.ptr(y), y.stride(0), _lib.stream())
+            _lib.check(rc, "egnn_bn_act_rows_fwd_f32")
+        ctx.save_for_backward(x, gamma, beta, mean, var, *([] if pick is None else [pick]))
         ctx.cfg = (float(eps), int(relu), float(p), int(seed), int(batch_stats))
         ctx.seed_dev = seed_dev
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, gamma, beta, mean, var = ctx.saved_tensors
+        x, gamma, beta, mean, var = ctx.saved_tensors[:5]
+        pick = ctx.saved_tensors[5] if len(ctx.saved_tensors) > 5 else None
         eps, relu, p, seed, batch_stats = ctx.cfg
         gy = _rowmajor(gy)
         n, C = x.shape
@@ -845,25 +858,29 @@ class _BnAct(torch.autograd.Function):
         # the producer of x usually added a bias (GCNConv / nn.Linear in front of the BatchNorm): its gradient is the column
         # sum of dx, formed in the same pass (ops.colsum picks the tag up)
         cs = torch.empty(C, dtype=torch.float32, device=dev) if batch_stats else None
-        rc = lib.egnn_bn_act_bwd_colsum_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), eps,
-                                            _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), batch_stats, _lib.ptr(dgamma),
-                                            _lib.ptr(dbeta), _lib.ptr(dx), dx.stride(0), _lib.ptr(cs), _lib.ptr(ws), nws, _lib.stream())
-        _lib.check(rc, "egnn_bn_act_bwd_colsum_f32")
+        if pick is None:
+            rc = lib.egnn_bn_act_bwd_colsum_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), eps,
+                                                _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), batch_stats,
+                                                _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dx), dx.stride(0), _lib.ptr(cs), _lib.ptr(ws), nws,
+                                                _lib.stream())
+            _lib.check(rc, "egnn_bn_act_bwd_colsum_f32")
+        else:
+            rc = lib.egnn_bn_act_rows_bwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(pick), pick.numel(), _lib.ptr(gy), gy.stride(0),
+                                              _lib.ptr(mean), _lib.ptr(var), eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed,
+                                              _lib.ptr(ctx.seed_dev), batch_stats, _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dx), dx.stride(0),
+                                              _lib.ptr(cs), _lib.ptr(ws), nws, _lib.stream())
+            _lib.check(rc, "egnn_bn_act_rows_bwd_f32")
         if cs is not None:
             dx._egnn_colsum = (cs, dx._version)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
-def bn_act(x: Tensor, bn: "torch.nn.BatchNorm1d", relu: bool = True, p: float = 0.0, training: bool | None = None) -> Tensor:
-    """dropout(relu(bn(x)), p) in two kernels (statistics + apply); same module state updates as nn.BatchNorm1d.
-
-    Falls back to the torch operators (still on the GPU) for shapes the kernel does not take (C % 4 != 0, C > 1024)."""
-    training = bn.training if training is None else training
+def _bn_prepare(x: Tensor, bn, p: float, training: bool):
+    """Statistics + module state update of a fused BatchNorm call; None when the kernels do not take the shape (torch fallback).
+    Returns (x row-major, mean, var, use_batch, drop, seed)."""
     x_in = x
     if not _bn_shape_ok(_rowmajor(x)) or not bn.track_running_stats or bn.weight is None:
-        y = bn(x)
-        y = torch.relu(y) if relu else y
-        return torch.nn.functional.dropout(y, p, training) if p > 0 else y
+        return None
     x = _rowmajor(x)
     n, C = x.shape
     use_batch = training  # nn.BatchNorm1d: batch statistics in training mode, running statistics in eval mode
@@ -893,7 +910,160 @@ def bn_act(x: Tensor, bn: "torch.nn.BatchNorm1d", relu: bool = True, p: float = 
         mean, var = bn.running_mean, bn.running_var
     drop = p if (training and p > 0) else 0.0
     seed = int(torch.empty((), dtype=torch.int64).random_()) if drop > 0 else 0  # host generator: torch.manual_seed reproducible
-    return _BnAct.apply(x, bn.weight, bn.bias, mean, var, bn.eps, relu, drop, seed & 0x7FFFFFFFFFFFFFFF, use_batch)
+    return x, mean, var, use_batch, drop, seed & 0x7FFFFFFFFFFFFFFF
+
+
+def bn_act(x: Tensor, bn: "torch.nn.BatchNorm1d", relu: bool = True, p: float = 0.0, training: bool | None = None,
+           pick: Tensor | None = None) -> Tensor:
+    """dropout(relu(bn(x)), p) in two kernels (statistics + apply); same module state updates as nn.BatchNorm1d.
+    ``pick``: return only the rows ``pick`` of that result (unique int64 ids; the statistics still span all rows of x).
+
+    Falls back to the torch operators (still on the GPU) for shapes the kernel does not take (C % 4 != 0, C > 1024)."""
+    training = bn.training if training is None else training
+    prep = _bn_prepare(x, bn, p, training)
+    if prep is None:
+        y = bn(x)
+        y = torch.relu(y) if relu else y
+        y = torch.nn.functional.dropout(y, p, training) if p > 0 else y
+        return y if pick is None else y[pick]
+    x, mean, var, use_batch, drop, seed = prep
+    return _BnAct.apply(x, bn.weight, bn.bias, mean, var, bn.eps, relu, drop, seed, use_batch, pick)
+
+
+_TAIL_ONE_PASS = os.environ.get("EGNN_TAIL_ONE_PASS", "1") == "1"   # A/B switch: _BnActLinear.forward as one kernel
+_INV_ROWS: dict = {}
+
+
+def _inverse_rows(idx: Tensor, n: int) -> Tensor:
+    """int32 [n]: position of row r in the unique id list ``idx``, -1 where r is not listed.  Built once per index tensor (identity +
+    version + length: the train split does not change between steps), the entry keeps ``idx`` alive."""
+    key = (idx.data_ptr(), idx._version, idx.numel(), n, str(idx.device))
+    hit = _INV_ROWS.get(key)
+    if hit is None:
+        if len(_INV_ROWS) > 8:
+            _INV_ROWS.clear()
+        inv = torch.full((n,), -1, dtype=torch.int32, device=idx.device)
+        inv[idx] = torch.arange(idx.numel(), dtype=torch.int32, device=idx.device)
+        hit = _INV_ROWS[key] = (inv, idx)
+    return hit[0]
+
+
+class _BnActLinear(torch.autograd.Function):
+    """(h, h @ w) with h = drop(relu(bn(x))) and a NARROW w [C, Ks] (the class count): the student's last hidden layer feeding its
+    output conv (gnn.py:47-52).  h also carries the gradient tap of ``grad_tap`` (the projection head's row-compact input gradient).
+    Backward: dh = G w^T + tap rows (+ any dense gradient of h) is formed in MFMA tiles and goes through the BatchNorm backward
+    without being stored (egnn_skinny_dx_bn_bwd_f32): one pass over [n, C] instead of four."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, var, eps, relu, p, seed, batch_stats, w, box):
+        x = _rowmajor(x)
+        n, C = x.shape
+        h = torch.empty(n, C, dtype=torch.float32, device=x.device)
+        seed_dev = _DROPOUT_SEED_DEV if p > 0 else None
+        w = _rowmajor(w)
+        lib = _lib.load()
+        rc = _lib.EGNN_EALIGN
+        if _TAIL_ONE_PASS and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0:
+            # one pass over x: h is stored and multiplied by w while its pieces are in registers
+            xw = torch.empty(n, w.shape[1], dtype=torch.float32, device=x.device)
+            rc = lib.egnn_bn_act_linear_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
+                                                _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(seed_dev), _lib.ptr(w), w.stride(0), 0,
+                                                w.shape[1], _lib.ptr(h), h.stride(0), _lib.ptr(xw), xw.stride(0), _lib.stream())
+            if rc != _lib.EGNN_EALIGN:
+                _lib.check(rc, "egnn_bn_act_linear_fwd_f32")
+        if rc == _lib.EGNN_EALIGN:
+            rc = lib.egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
+                                         _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(seed_dev), _lib.ptr(h), h.stride(0),
+                                         _lib.stream())
+            _lib.check(rc, "egnn_bn_act_fwd_f32")
+            xw = gemm_raw(h, w, False, False)
+        ctx.save_for_backward(x, gamma, beta, mean, var, h, w)
+        ctx.cfg = (float(eps), int(relu), float(p), int(seed), int(batch_stats))
+        ctx.seed_dev, ctx.box = seed_dev, box
+        ctx.set_materialize_grads(False)
+        return h, xw
+
+    @staticmethod
+    def backward(ctx, g_h, g_xw):
+        x, gamma, beta, mean, var, h, w = ctx.saved_tensors
+        eps, relu, p, seed, batch_stats = ctx.cfg
+        pend = []
+        if ctx.box is not None:
+            pend, ctx.box.pending = ctx.box.pending, []
+        n, C = x.shape
+        Ks = w.shape[1]
+        lib, dev = _lib.load(), x.device
+        gw = None
+        if g_xw is not None:
+            g_xw = _rowmajor(g_xw)
+            if ctx.needs_input_grad[10]:
+                gw = gemm_raw(h, g_xw, True, False)                       # dW = h^T G
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None, None, None, None, None, None, gw, None
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        cs = torch.empty(C, dtype=torch.float32, device=dev) if batch_stats else None
+        if g_h is not None:
+            g_h = _rowmajor(g_h.to_dense() if g_h.is_sparse else g_h)
+        fused = (g_xw is not None and len(pend) <= 1 and C % 64 == 0 and Ks <= 64 and x.stride(0) % 4 == 0
+                 and (g_h is None or (g_h.stride(0) % 4 == 0 and g_h.data_ptr() % 16 == 0)))
+        rows = inv = None
+        if fused and pend:
+            idx, rows = pend[0]
+            rows = _rowmajor(rows)
+            fused = rows.stride(0) % 4 == 0 and rows.data_ptr() % 16 == 0 and rows.shape[1] == C
+            if fused:
+                inv = _inverse_rows(idx, n)
+        if fused:
+            nws = lib.egnn_skinny_dx_bn_ws_floats(n, C)
+            ws = torch.empty(nws, dtype=torch.float32, device=dev)
+            rc = lib.egnn_skinny_dx_bn_bwd_f32(_lib.ptr(g_xw), g_xw.stride(0), _lib.ptr(w), w.stride(0), 1, n, C, Ks, 1.0,
+                                               _lib.ptr(g_h), 0 if g_h is None else g_h.stride(0), _lib.ptr(rows),
+                                               0 if rows is None else rows.stride(0), _lib.ptr(inv), _lib.ptr(x), x.stride(0), _lib.ptr(mean),
+                                               _lib.ptr(var), eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev),
+                                               batch_stats, _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dx), dx.stride(0), _lib.ptr(cs),
+                                               _lib.ptr(ws), nws, _lib.stream())
+            _lib.check(rc, "egnn_skinny_dx_bn_bwd_f32")
+        else:
+            # the separate passes: dense dh, the tap rows added into it, the BatchNorm backward
+            dh = gemm_raw(g_xw, w, False, True) if g_xw is not None else None
+            if dh is None:
+                dh = g_h.clone() if g_h is not None else torch.zeros_like(x)
+            elif g_h is not None:
+                dh = dh + g_h
+            for idx, rows in pend:
+                rows = _rowmajor(rows)
+                _lib.check(lib.egnn_rows_add_f32(_lib.ptr(dh), dh.stride(0), _lib.ptr(idx), _lib.ptr(rows), rows.stride(0), rows.shape[0],
+                                                 rows.shape[1], _lib.stream()), "egnn_rows_add_f32")
+            nws = lib.egnn_bn_ws_floats(C)
+            ws = torch.empty(nws, dtype=torch.float32, device=dev)
+            rc = lib.egnn_bn_act_bwd_colsum_f32(_lib.ptr(x), x.stride(0), _lib.ptr(dh), dh.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), eps,
+                                                _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), batch_stats,
+                                                _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dx), dx.stride(0), _lib.ptr(cs), _lib.ptr(ws), nws,
+                                                _lib.stream())
+            _lib.check(rc, "egnn_bn_act_bwd_colsum_f32")
+        if cs is not None:
+            dx._egnn_colsum = (cs, dx._version)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, gw, None
+
+
+def bn_act_linear(x: Tensor, bn: "torch.nn.BatchNorm1d", w: Tensor, relu: bool = True, p: float = 0.0, training: bool | None = None):
+    """(h, h @ w) for h = dropout(relu(bn(x)), p) and a narrow ``w`` [C, Ks <= 64] -- ``bn_act`` + ``grad_tap`` + ``matmul`` with ONE
+    backward pass over the [n, C] tensors (see _BnActLinear).  h carries the tap for ``linear_rows``.  None when the fused kernels do
+    not take the shape (the caller then composes the three calls)."""
+    training = bn.training if training is None else training
+    if not (torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and w.dim() == 2 and w.shape[0] == x.shape[1] and w.shape[1] <= 64
+            and x.shape[1] % 64 == 0):
+        return None
+    prep = _bn_prepare(x, bn, p, training)
+    if prep is None:
+        return None
+    x, mean, var, use_batch, drop, seed = prep
+    box = _TapBox()
+    h, xw = _BnActLinear.apply(x, bn.weight, bn.bias, mean, var, bn.eps, relu, drop, seed, use_batch, w, box)
+    h._egnn_tap = box
+    return h, xw
 
 
 # ------------------------------------------------------------------------------------------------

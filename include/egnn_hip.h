@@ -421,6 +421,41 @@ int egnn_bn_act_bwd_colsum_f32(const float* x, int64_t ld, const float* dy, int6
                                const uint64_t* seed_dev, int batch_stats, float* dgamma, float* dbeta, float* dx, int64_t ld_dx,
                                float* dx_colsum, float* ws, size_t ws_floats, void* stream);
 
+/* The fused BatchNorm + activation when only the OUTPUT ROWS `pick` (n_pick unique ids into the n rows of x) are read afterwards: the
+ * projection heads feeding the sampled criteria (/root/reference/arxiv_pyg/gnn.py:296-306 -> criterion.py:62-65,134-137: the
+ * statistics span all train rows, the criterion keeps max_samples of the output rows).
+ *   fwd: y [n_pick, C], y[i] = act(bn(x[pick[i]]))  (mean / var: the statistics of ALL n rows, egnn_bn_stats_f32)
+ *   bwd: dy [n_pick, C] -> dgamma, dbeta (sums over the picked rows: every other output row has no gradient), dx [n, C] (all rows:
+ *        the mean / variance terms reach every row), dx_colsum nullable as in egnn_bn_act_bwd_colsum_f32.  Same arithmetic as
+ *        scattering dy into a zero [n, C] gradient and calling egnn_bn_act_bwd_colsum_f32, without the zero rows. */
+int egnn_bn_act_rows_fwd_f32(const float* x, int64_t ld, int64_t n, int64_t C, const int64_t* pick, int64_t n_pick, const float* mean,
+                             const float* var, float eps, const float* gamma, const float* beta, int relu, float p, uint64_t seed,
+                             const uint64_t* seed_dev, float* y, int64_t ldy, void* stream);
+int egnn_bn_act_rows_bwd_f32(const float* x, int64_t ld, int64_t n, int64_t C, const int64_t* pick, int64_t n_pick, const float* dy,
+                             int64_t ld_dy, const float* mean, const float* var, float eps, const float* gamma, const float* beta,
+                             int relu, float p, uint64_t seed, const uint64_t* seed_dev, int batch_stats, float* dgamma, float* dbeta,
+                             float* dx, int64_t ld_dx, float* dx_colsum, float* ws, size_t ws_floats, void* stream);
+
+/* Backward of  h = act(bn(x)) [M, C]  followed by the narrow Linear  h W  (W [C, Ks] as w_kmajor = 1, or [Ks, C] rows as 0; Ks <= 64, C % 64 == 0)
+ * in one pass over the [M, C] tensors -- the last hidden layer of the students (/root/reference/arxiv_pyg/gnn.py:47-52 under loss.backward()):
+ *   dh = alpha G W^T (+ addend, nullable dense [M, C]) (+ add_rows[add_inv[row]] where add_inv[row] >= 0: the row-compact input gradient of
+ *   the projection head, gnn.py:150; add_inv int32 [M], -1 = no row), d = dh * gate(x) never stored as dh; dgamma / dbeta / dx / dx_colsum as
+ *   egnn_bn_act_bwd_colsum_f32 would return them for dy = dh.  ws: egnn_skinny_dx_bn_ws_floats(M, C) floats. */
+/* Forward of the same pair in one pass over x: h = act(bn(x)) [n, C] is stored AND multiplied by the narrow W ([C, Ks] for w_kmajor = 0 /
+ * [Ks, C] rows for 1) while its 16-byte pieces are in registers: xw = h W [n, Ks].  h is bit-identical to egnn_bn_act_fwd_f32.
+ * EGNN_EALIGN when the shape is not taken (Ks > 64, C % 16 != 0, C > 1024): the caller then makes the two calls. */
+int egnn_bn_act_linear_fwd_f32(const float* x, int64_t ld, int64_t n, int64_t C, const float* mean, const float* var, float eps,
+                               const float* gamma, const float* beta, int relu, float p, uint64_t seed, const uint64_t* seed_dev,
+                               const float* W, int64_t ldw, int w_kmajor, int64_t Ks, float* h, int64_t ldh, float* xw, int64_t ld_xw,
+                               void* stream);
+size_t egnn_skinny_dx_bn_ws_floats(int64_t M, int64_t C);
+int egnn_skinny_dx_bn_bwd_f32(const float* G, int64_t ldg, const float* W, int64_t ldw, int w_kmajor, int64_t M, int64_t C, int64_t Ks,
+                              float alpha, const float* addend, int64_t ld_addend, const float* add_rows, int64_t ld_add_rows,
+                              const int32_t* add_inv, const float* x, int64_t ldx, const float* mean, const float* var, float eps,
+                              const float* gamma, const float* beta, int relu, float p, uint64_t seed, const uint64_t* seed_dev,
+                              int batch_stats, float* dgamma, float* dbeta, float* dx, int64_t ld_dx, float* dx_colsum, float* ws,
+                              size_t ws_floats, void* stream);
+
 /* nn.BatchNorm1d's training-step state update in one launch (torch/nn/modules/batchnorm.py: num_batches_tracked += 1,
  * running = (1 - m) running + m stat with the unbiased variance n/(n-1) var):  mean / var [C] = this batch's statistics,
  * momentum < 0 = cumulative average (momentum=None); num_batches_tracked: nullable device int64. */

@@ -1098,6 +1098,126 @@ def test_fused_bn_act_matches_torch_batchnorm(n, C, relu):
         assert int(bn_dev.num_batches_tracked) == int(bn_ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize("n,C,S,relu,p", [(5000, 256, 1200, True, 0.0), (777, 128, 777, True, 0.0), (9000, 256, 64, False, 0.0),
+                                         (6000, 256, 2000, True, 0.4)])
+def test_fused_bn_act_on_picked_rows_equals_the_full_call_indexed(n, C, S, relu, p):
+    """ops.bn_act(..., pick=idx) == ops.bn_act(...)[idx] in value, in dx / dgamma / dbeta, in the bias-gradient tag and in the module
+    state (what the projection heads of the sampled criteria use, gnn.py:296-306 -> criterion.py:62-65,134-137)."""
+    g = torch.Generator().manual_seed(n + S)
+    x = (torch.randn(n, C, generator=g) * 2 + torch.randn(C, generator=g) * 3).to(DEV)
+    idx = torch.randperm(n, generator=g)[:S].to(DEV)
+    gy = torch.randn(S, C, generator=g).to(DEV)
+    bns = []
+    for _ in range(2):
+        bn = torch.nn.BatchNorm1d(C).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C))
+            bn.bias.copy_(torch.linspace(-0.5, 0.5, C))
+        bns.append(bn)
+    for training in (True, False):
+        outs = []
+        for k, bn in enumerate(bns):
+            bn.train(training)
+            bn.zero_grad()
+            xk = x.clone().requires_grad_(True)
+            torch.manual_seed(99)                       # same dropout seed for both calls
+            if k == 0:
+                y = ops.bn_act(xk, bn, relu=relu, p=p, training=True if p > 0 else None)[idx]
+            else:
+                y = ops.bn_act(xk, bn, relu=relu, p=p, training=True if p > 0 else None, pick=idx)
+            assert y.shape == (S, C)
+            y.backward(gy)
+            outs.append((y.detach(), xk.grad, bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone()))
+        (y0, dx0, dg0, db0, rm0, rv0), (y1, dx1, dg1, db1, rm1, rv1) = outs
+        assert torch.equal(y0, y1), f"forward rows differ (training={training})"
+        close(dx1, dx0, rtol=2e-5, atol_scale=2e-6, msg=f"dx training={training}")
+        close(dg1, dg0, rtol=2e-5, atol_scale=2e-6, msg="dgamma")
+        close(db1, db0, rtol=2e-5, atol_scale=2e-6, msg="dbeta")
+        assert torch.equal(rm0, rm1) and torch.equal(rv0, rv1)
+    # the column sums of dx (gradient of a bias in front of the BatchNorm) carried by the tag: mathematically 0 with batch statistics
+    bn = bns[1]
+    bn.train(True)
+    lin = torch.nn.Linear(C, C).to(DEV)
+    xin = torch.randn(n, C, generator=g).to(DEV)
+    y = ops.bn_act(ops.linear(xin, lin.weight, lin.bias), bn, relu=relu, p=0.0, pick=idx)
+    y.backward(gy)
+    ref_scale = float(gy.abs().sum(0).max())
+    assert float(lin.bias.grad.abs().max()) <= 1e-4 * ref_scale
+
+
+@pytest.mark.parametrize("n,C,Ks,p,dense_consumer,tap", [(9000, 256, 40, 0.5, False, True), (5000, 128, 40, 0.0, True, True),
+                                                         (4100, 256, 47, 0.3, False, False), (700, 64, 7, 0.0, True, False)])
+def test_bn_act_linear_equals_the_three_separate_ops(n, C, Ks, p, dense_consumer, tap):
+    """ops.bn_act_linear == bn_act -> grad_tap -> matmul: values, and every gradient when h also feeds linear_rows (tap rows) and / or a
+    dense consumer (the last hidden layer of the GCN student, gnn.py:47-52,150)."""
+    g = torch.Generator().manual_seed(n + Ks)
+    x0 = (torch.randn(n, C, generator=g) * 2 + torch.randn(C, generator=g)).to(DEV)
+    w0 = (torch.randn(C, Ks, generator=g) * 0.1).to(DEV)
+    wp0 = (torch.randn(32, C, generator=g) * 0.1).to(DEV)
+    idx = torch.randperm(n, generator=g)[: n // 2].to(DEV)
+    g_xw = torch.randn(n, Ks, generator=g).to(DEV)
+    g_rows = torch.randn(idx.numel(), 32, generator=g).to(DEV)
+    res = []
+    for fused in (False, True):
+        bn = torch.nn.BatchNorm1d(C).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C))
+            bn.bias.copy_(torch.linspace(-0.5, 0.5, C))
+        x = x0.clone().requires_grad_(True)
+        w = w0.clone().requires_grad_(True)
+        wp = wp0.clone().requires_grad_(True)
+        torch.manual_seed(7)
+        if fused:
+            both = ops.bn_act_linear(x, bn, w, relu=True, p=p, training=True)
+            assert both is not None
+            h, xw = both
+        else:
+            h = ops.grad_tap(ops.bn_act(x, bn, relu=True, p=p, training=True))
+            xw = ops.matmul(h, w)
+        loss = (xw * g_xw).sum()
+        if tap:
+            loss = loss + (ops.linear_rows(h, idx, wp) * g_rows).sum()
+        if dense_consumer:
+            loss = loss + (h * h).sum() * 0.01
+        loss.backward()
+        res.append((h.detach(), xw.detach(), x.grad, w.grad, wp.grad if tap else None, bn.weight.grad, bn.bias.grad))
+    a, b = res
+    assert torch.equal(a[0], b[0])                          # h: the same per-element arithmetic
+    close(b[1], a[1], rtol=2e-5, atol_scale=2e-6, msg="xw")    # the fused forward adds the k-ranges in another order
+    for name, u, v in zip(("dx", "dW", "dWp", "dgamma", "dbeta"), a[2:], b[2:]):
+        if u is not None:
+            close(v, u, rtol=2e-5, atol_scale=2e-6, msg=name)
+
+
+def test_gcn_train_step_with_the_fused_tail_equals_the_separate_ops():
+    """models.GCN.forward with ops.bn_act_linear for the last hidden layer vs the composed path: same logits, same parameter gradients."""
+    d = D.arxiv_like(scale=0.04, seed=5, with_teacher=False)
+    x, adj, y, tr = d.x.to(DEV), d.adj_t.to(DEV), d.y.to(DEV), d.split_idx["train"].to(DEV)
+    grads = []
+    for fused in (False, True):
+        prev = PM._FUSED_TAIL
+        PM._FUSED_TAIL = fused
+        try:
+            torch.manual_seed(3)
+            model = PM.GCN(d.num_features, 256, d.num_classes, 3, 0.5).to(DEV)
+            proj = PM.make_projection(256, 64).to(DEV)
+            model.train(), proj.train()
+            torch.manual_seed(11)
+            out = model(x, adj)
+            f = proj.forward_rows(model.out_feat, tr)
+            loss = ops.cross_entropy(out, y.view(-1), tr) + (f * f).mean()
+            loss.backward()
+            named = list(model.named_parameters()) + list(proj.named_parameters())
+            grads.append((out.detach(), [(k, q.grad.clone()) for k, q in named]))
+        finally:
+            PM._FUSED_TAIL = prev
+    close(grads[1][0], grads[0][0], rtol=2e-5, atol_scale=2e-6, msg="logits")
+    for (k, u), (_, v) in zip(grads[0][1], grads[1][1]):
+        if k in ("convs.0.bias", "convs.1.bias", "0.bias"):
+            continue   # a bias in front of a BatchNorm: its gradient is rounding noise around 0 (DESIGN.md 4)
+        close(v, u, rtol=5e-5, atol_scale=5e-6, msg=k)
+
+
 def test_fused_bn_dropout_mask_is_consistent_and_unbiased():
     n, C, p = 20000, 256, 0.5
     torch.manual_seed(0)
