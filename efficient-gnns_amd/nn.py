@@ -19,6 +19,7 @@ from .sparse import SparseTensor, _ind2ptr, csr_from_coo, gcn_norm
 
 # opt-in: the headline bench keeps the reference's per-step work (aggregate every layer every step)
 _MEMOISE_AX = os.environ.get("EGNN_GCN_MEMOISE_AX", "0") == "1"
+_SAGE_NARROW_FIRST = os.environ.get("EGNN_SAGE_NARROW_FIRST", "1") == "1"   # A/B switch: SAGEConv aggregates lin_l(x) when out < in
 
 
 def _adj_from_edge_index(edge_index: Tensor, n: int, value: Tensor | None = None) -> SparseTensor:
@@ -181,9 +182,15 @@ class SAGEConv(nn.Module):
     def forward(self, x: Tensor, edge_index) -> Tensor:
         if hasattr(edge_index, "aggregate"):  # node-range shard (dist.ShardedAdj)
             agg = edge_index.aggregate(x, self.aggr, valueless=True)
-        else:
-            adj = edge_index if isinstance(edge_index, SparseTensor) else _adj_from_edge_index(edge_index, x.shape[0])
-            agg = ops.spmm(adj.set_value(None), x, self.aggr)
+            return ops.linear(agg, self.lin_l.weight, self.lin_l.bias) + ops.linear(x, self.lin_r.weight, None)
+        adj = edge_index if isinstance(edge_index, SparseTensor) else _adj_from_edge_index(edge_index, x.shape[0])
+        if _SAGE_NARROW_FIRST and self.out_channels < self.in_channels and self.aggr in ("mean", "sum") and _lib.on_gpu(x):
+            # mean / sum are linear: aggr_j(x_j) W^T == aggr_j(x_j W^T).  On the output layer (256 -> 40 classes, gnn.py:84) the HBM-bound
+            # gather then moves `out` instead of `in` floats per neighbour, forward and backward -- the re-association GCNConv makes.
+            # The bias goes in after the aggregation (a row without neighbours gets lin_l(0) = bias either way).
+            return ops.spmm(adj.set_value(None), ops.linear(x, self.lin_l.weight, None), self.aggr, bias=self.lin_l.bias) \
+                + ops.linear(x, self.lin_r.weight, None)
+        agg = ops.spmm(adj.set_value(None), x, self.aggr)
         return ops.linear(agg, self.lin_l.weight, self.lin_l.bias) + ops.linear(x, self.lin_r.weight, None)
 
     def __repr__(self):

@@ -712,6 +712,28 @@ def test_conv_layers_vs_oracle(kind):
         close(a.grad, b.grad, rtol=1e-4, msg=f"{kind}:{k}")
 
 
+@pytest.mark.parametrize("aggr", ["mean", "sum"])
+def test_sageconv_output_layer_transforms_before_aggregating(aggr):
+    """SAGEConv with out < in (the 256 -> 40 output layer, gnn.py:84) aggregates lin_l(x) instead of x: same result as the oracle's
+    aggregate-first order, rows without neighbours included (they get the bias), forward and backward."""
+    n, fin, fout = 5000, 256, 40
+    row, col = random_csr(n, n, 6, seed=7, hubs=((3, 900),), empty_frac=0.2)
+    o, p = make_pair(row, col, None, (n, n))
+    torch.manual_seed(1)
+    co, cp = ON.SAGEConv(fin, fout, aggr=aggr), E.SAGEConv(fin, fout, aggr=aggr).to(DEV)
+    cp.load_state_dict(co.state_dict())
+    x = torch.randn(n, fin)
+    xo, xp = x.clone().requires_grad_(True), x.to(DEV).requires_grad_(True)
+    yo, yp = co(xo, o), cp(xp, p)
+    close(yp, yo, rtol=2e-5, msg=aggr)
+    gy = torch.randn(n, fout)
+    yo.backward(gy)
+    yp.backward(gy.to(DEV))
+    close(xp.grad, xo.grad, rtol=1e-4, msg=aggr)
+    for (k, a), (_, b) in zip(cp.named_parameters(), co.named_parameters()):
+        close(a.grad, b.grad, rtol=1e-4, msg=f"{aggr}:{k}")
+
+
 def test_gcnconv_edge_index_input_ppi_path():
     n = 300
     g = torch.Generator().manual_seed(4)
