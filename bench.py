@@ -479,7 +479,14 @@ def main():
     import efficient_gnns_amd.ops as ops
 
     if world > 1 or args.force_sharded or args.workload == "mag":
-        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+        if "MASTER_PORT" not in os.environ:
+            # one process started by hand (--force-sharded / --workload mag): any free port -- a fixed one collides with the lingering
+            # socket of a run that has just ended (seen once in a back-to-back series)
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
         import efficient_gnns_amd.dist as dist_mod
         dist_mod.bench_main(args, hp, MODEL, rank, world, device)   # prints the line on rank 0; ends with barrier + destroy_process_group

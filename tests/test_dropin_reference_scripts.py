@@ -121,7 +121,11 @@ def test_reference_train_loop_runs_unchanged_on_the_new_operators(gnn, mode):
         got = [ref.train(model, data, train_idx, opt, args, tf, tl, sp, tp, edge_index) for _ in range(3)]
         np.random.seed(3)
         want = [PM.train_step(mine, data.x, data.adj_t, data.y, train_idx, mopt, mode, hp, tf, tl, msp, mtp, edge_index) for _ in range(3)]
-        np.testing.assert_allclose(np.array(got), np.array(want), rtol=2e-4, atol=1e-6)
+        # step 1: same weights, same draw -> the kernels' rounding only.  Steps 2-3 are a trajectory: Adam's g / sqrt(v) turns rounding
+        # differences of small gradients into O(lr) weight differences, and GSP at beta = 100 multiplies what the loss sees of them
+        # (the two sides differ in association order only: fused heads / SAGE's output layer aggregating lin_l(x))
+        np.testing.assert_allclose(np.array(got[0]), np.array(want[0]), rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(np.array(got), np.array(want), rtol=1e-3 if mode == "gpw" else 2e-4, atol=1e-6)
         assert all(np.isfinite(v) for step in got for v in step)
         out, accs = ref.test(model, data, split_idx, _Evaluator())
         assert out.shape == (d.num_nodes, d.num_classes) and all(0 <= a <= 1 for a in accs)
