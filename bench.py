@@ -480,8 +480,8 @@ def main():
 
     if world > 1 or args.force_sharded or args.workload == "mag":
         if "MASTER_PORT" not in os.environ:
-            # one process started by hand (--force-sharded / --workload mag): any free port -- a fixed one collides with the lingering
-            # socket of a run that has just ended (seen once in a back-to-back series)
+            # one process started by hand (--force-sharded / --workload mag): any free port (a fixed one can collide with the lingering
+            # socket of a run that has just ended; one run of a back-to-back series produced no line)
             import socket
             with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
                 sk.bind(("127.0.0.1", 0))
