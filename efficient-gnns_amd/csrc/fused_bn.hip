@@ -812,10 +812,12 @@ namespace {
 // added in wave order and xw rows are stored.  h is bit-identical to bn_act_fwd_kernel; x is read once, h is never re-read.
 // N = 169 343, Ks = 40: 115 us against 77 + 67 us of bn_act_fwd_kernel + skinny_fwd_kernel (the same transform inside skinny_fwd_kernel's
 // operand load, on its MFMA-shaped 64-byte pieces: 163 us).
-template <int NT>
+// BN = false: the plain narrow product XW = alpha x W + bias of a 256-wide x in the same form (rows streamed into the LDS tile as they
+// are; q carries only x / ldx / n): the output conv in test() and SAGEConv's two narrow Linears.
+template <int NT, bool BN = true>
 __global__ __launch_bounds__(256, 4) void tail_fwd_tile_kernel(const BnParams q, const float* __restrict__ W, int64_t ldw, int w_kmajor,
-                                                                             int Ks, float* __restrict__ H, int64_t ldh, float* __restrict__ XW,
-                                                                             int64_t ldxw) {
+                                                               int Ks, float* __restrict__ H, int64_t ldh, float* __restrict__ XW,
+                                                               int64_t ldxw, const float* __restrict__ bias = nullptr, float alpha = 1.f) {
   constexpr int RB = 16, LDH = 256 + 4, NP = NT * 16, LDP = NP + 1, RTL = RB / 16;   // 32-row blocks measured slower (2 workgroups per CU)
   __shared__ __attribute__((aligned(16))) float sH[RB * LDH];
   __shared__ float sP[4 * RB * LDP];
@@ -826,10 +828,10 @@ __global__ __launch_bounds__(256, 4) void tail_fwd_tile_kernel(const BnParams q,
   float mean[4], rstd[4], gm[4], bt[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    mean[k] = q.mean[c2 + k];
-    rstd[k] = rsqrtf(q.var[c2 + k] + q.eps);
-    gm[k] = q.gamma ? q.gamma[c2 + k] : 1.f;
-    bt[k] = q.beta ? q.beta[c2 + k] : 0.f;
+    mean[k] = BN ? q.mean[c2 + k] : 0.f;
+    rstd[k] = BN ? rsqrtf(q.var[c2 + k] + q.eps) : 1.f;
+    gm[k] = (BN && q.gamma) ? q.gamma[c2 + k] : 1.f;
+    bt[k] = (BN && q.beta) ? q.beta[c2 + k] : 0.f;
   }
   // W fragments of this wave's k-range: step s <-> k = 64 wave + 4 s + qq, tile j <-> n = 16 j + r16
   float bfr[16][NT];
@@ -857,18 +859,22 @@ __global__ __launch_bounds__(256, 4) void tail_fwd_tile_kernel(const BnParams q,
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int lr = wave + 4 * (4 * g4 + u);
-        const float xv[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
-        float o[4];
+        if constexpr (BN) {
+          const float xv[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
+          float o[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float xhat, gate;
-          bn_elem(q, xv[k], mean[k], rstd[k], gm[k], bt[k], (int64_t)rowc[u], c2 + k, xhat, gate);
-          o[k] = (gm[k] * xhat + bt[k]) * gate;
+          for (int k = 0; k < 4; ++k) {
+            float xhat, gate;
+            bn_elem(q, xv[k], mean[k], rstd[k], gm[k], bt[k], (int64_t)rowc[u], c2 + k, xhat, gate);
+            o[k] = (gm[k] * xhat + bt[k]) * gate;
+          }
+          const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+          if (m0 + lr < M) *reinterpret_cast<float4*>(H + (rowc[u] * (unsigned)ldh + (unsigned)c2)) = ov;
+          *reinterpret_cast<float4*>(sH + lr * LDH + c2) = ov;
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          *reinterpret_cast<float4*>(sH + lr * LDH + c2) = yv[u];
         }
-        const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
-        if (m0 + lr < M) *reinterpret_cast<float4*>(H + (rowc[u] * (unsigned)ldh + (unsigned)c2)) = ov;
-        *reinterpret_cast<float4*>(sH + lr * LDH + c2) = ov;
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
@@ -897,12 +903,33 @@ __global__ __launch_bounds__(256, 4) void tail_fwd_tile_kernel(const BnParams q,
     // (C) the four k-ranges in wave order
     for (int i = threadIdx.x; i < RB * Ks; i += 256) {
       const int r = i / Ks, c = i % Ks;
-      if (m0 + r < M)
-        XW[(m0 + r) * ldxw + c] = ((sP[(0 * RB + r) * LDP + c] + sP[(1 * RB + r) * LDP + c]) + sP[(2 * RB + r) * LDP + c]) + sP[(3 * RB + r) * LDP + c];
+      if (m0 + r < M) {
+        const float v = ((sP[(0 * RB + r) * LDP + c] + sP[(1 * RB + r) * LDP + c]) + sP[(2 * RB + r) * LDP + c]) + sP[(3 * RB + r) * LDP + c];
+        XW[(m0 + r) * ldxw + c] = BN ? v : alpha * v + (bias ? bias[c] : 0.f);
+      }
     }
   }
 }
 }  // namespace
+
+// Y = alpha X W + bias for a 256-wide X and a narrow W in the tile form (see tail_fwd_tile_kernel<NT, false>); 1 = shape not taken.
+// Called by gemm.hip in front of egnn_skinny_fwd (gemm_skinny.hip).  EGNN_SKINNY_TILE=0 is the A/B switch.
+int egnn_skinny_fwd_tile(const float* X, int64_t ldx, const float* W, int64_t ldw, int w_kmajor, const float* bias, float* Y, int64_t ldy, int64_t M,
+                         int64_t N, int64_t K, float alpha, hipStream_t st) {
+  static const bool off = getenv("EGNN_SKINNY_TILE") && getenv("EGNN_SKINNY_TILE")[0] == '0';
+  if (off || K != 256 || N < 1 || N > 64 || M < 4096 || ldx % 4 != 0 || !egnn_aligned16(X) || M * ldx >= (1LL << 31) - 64) return 1;
+  const BnParams q{X, ldx, M, K, nullptr, nullptr, 0.f, nullptr, nullptr, 0, 0.f, 0ull, nullptr, nullptr};
+  const int nt = (int)((N + 15) / 16);
+  const int64_t nblk = (M + 15) / 16;
+  const unsigned grid = (unsigned)(nblk < 1024 ? nblk : 1024);
+  switch (nt) {
+    case 1: hipLaunchKernelGGL((tail_fwd_tile_kernel<1, false>), dim3(grid), dim3(256), 0, st, q, W, ldw, w_kmajor, (int)N, (float*)nullptr, (int64_t)0, Y, ldy, bias, alpha); break;
+    case 2: hipLaunchKernelGGL((tail_fwd_tile_kernel<2, false>), dim3(grid), dim3(256), 0, st, q, W, ldw, w_kmajor, (int)N, (float*)nullptr, (int64_t)0, Y, ldy, bias, alpha); break;
+    case 3: hipLaunchKernelGGL((tail_fwd_tile_kernel<3, false>), dim3(grid), dim3(256), 0, st, q, W, ldw, w_kmajor, (int)N, (float*)nullptr, (int64_t)0, Y, ldy, bias, alpha); break;
+    default: hipLaunchKernelGGL((tail_fwd_tile_kernel<4, false>), dim3(grid), dim3(256), 0, st, q, W, ldw, w_kmajor, (int)N, (float*)nullptr, (int64_t)0, Y, ldy, bias, alpha); break;
+  }
+  return egnn_launch_status();
+}
 
 extern "C" int egnn_bn_act_linear_fwd_f32(const float* x, int64_t ld, int64_t n, int64_t C, const float* mean, const float* var, float eps,
                                           const float* gamma, const float* beta, int relu, float p, uint64_t seed, const uint64_t* seed_dev,
@@ -917,10 +944,10 @@ extern "C" int egnn_bn_act_linear_fwd_f32(const float* x, int64_t ld, int64_t n,
   const unsigned grid = (unsigned)(nblk < 1024 ? nblk : 1024);   // 4 workgroups per CU (29 KB of LDS, <= 128 VGPRs each)
   hipStream_t st = (hipStream_t)stream;
   switch (nt) {
-    case 1: hipLaunchKernelGGL((tail_fwd_tile_kernel<1>), dim3(grid), dim3(256), 0, st, q, W, ldw, w_kmajor, (int)Ks, h, ldh, xw, ld_xw); break;
-    case 2: hipLaunchKernelGGL((tail_fwd_tile_kernel<2>), dim3(grid), dim3(256), 0, st, q, W, ldw, w_kmajor, (int)Ks, h, ldh, xw, ld_xw); break;
-    case 3: hipLaunchKernelGGL((tail_fwd_tile_kernel<3>), dim3(grid), dim3(256), 0, st, q, W, ldw, w_kmajor, (int)Ks, h, ldh, xw, ld_xw); break;
-    default: hipLaunchKernelGGL((tail_fwd_tile_kernel<4>), dim3(grid), dim3(256), 0, st, q, W, ldw, w_kmajor, (int)Ks, h, ldh, xw, ld_xw); break;
+    case 1: hipLaunchKernelGGL((tail_fwd_tile_kernel<1, true>), dim3(grid), dim3(256), 0, st, q, W, ldw, w_kmajor, (int)Ks, h, ldh, xw, ld_xw, (const float*)nullptr, 1.f); break;
+    case 2: hipLaunchKernelGGL((tail_fwd_tile_kernel<2, true>), dim3(grid), dim3(256), 0, st, q, W, ldw, w_kmajor, (int)Ks, h, ldh, xw, ld_xw, (const float*)nullptr, 1.f); break;
+    case 3: hipLaunchKernelGGL((tail_fwd_tile_kernel<3, true>), dim3(grid), dim3(256), 0, st, q, W, ldw, w_kmajor, (int)Ks, h, ldh, xw, ld_xw, (const float*)nullptr, 1.f); break;
+    default: hipLaunchKernelGGL((tail_fwd_tile_kernel<4, true>), dim3(grid), dim3(256), 0, st, q, W, ldw, w_kmajor, (int)Ks, h, ldh, xw, ld_xw, (const float*)nullptr, 1.f); break;
   }
   return egnn_launch_status();
 }
@@ -944,8 +971,9 @@ extern "C" int egnn_skinny_dx_bn_bwd_f32(const float* G, int64_t ldg, const floa
   if (!shape_ok(x, ldx, C) || !shape_ok(dx, ld_dx, C)) return EGNN_EALIGN;
   if (addend && !shape_ok(addend, ld_addend, C)) return EGNN_EALIGN;
   if (add_rows && !shape_ok(add_rows, ld_add_rows, C)) return EGNN_EALIGN;
-  if (!w_kmajor && (ldw % 4 != 0 || !egnn_aligned16(W))) return EGNN_EALIGN;
+  if (w_kmajor && (ldw % 4 != 0 || !egnn_aligned16(W))) return EGNN_EALIGN;
   if (ws_floats < egnn_skinny_dx_bn_ws_floats(M, C) || !egnn_aligned16(ws)) return EGNN_EWORKSPACE;
+  const int b_kmajor = w_kmajor ? 0 : 1;   // the kernels index W^T as B[k = class][n = column]: "k-major" there = W stored [C, Ks]
   const int64_t lim = (1LL << 31) - 64;   // the kernel addresses with 32-bit element offsets
   if (M * ldx >= lim || M * ld_dx >= lim || (addend && M * ld_addend >= lim) || (add_rows && M * ld_add_rows >= lim)) return EGNN_EALIGN;
   hipStream_t st = (hipStream_t)stream;
@@ -957,7 +985,7 @@ extern "C" int egnn_skinny_dx_bn_bwd_f32(const float* G, int64_t ldg, const floa
     const int64_t nblk = (M + 31) / 32;
     sbs = nblk < kTailTileBlocks ? nblk : kTailTileBlocks;
 #define EGNN_TAIL_TILE(KS, ADD)                                                                                                              \
-  hipLaunchKernelGGL((tail_bwd_tile_kernel<KS, ADD>), dim3((unsigned)sbs), dim3(256), 0, st, G, ldg, W, ldw, w_kmajor, (int)Ks, alpha, addend,   \
+  hipLaunchKernelGGL((tail_bwd_tile_kernel<KS, ADD>), dim3((unsigned)sbs), dim3(256), 0, st, G, ldg, W, ldw, b_kmajor, (int)Ks, alpha, addend,   \
                      ld_addend, add_rows, ld_add_rows, add_inv, q, dx, ld_dx, ws)
     if (ksteps <= 4) { if (addend) EGNN_TAIL_TILE(4, true); else EGNN_TAIL_TILE(4, false); }
     else { if (addend) EGNN_TAIL_TILE(10, true); else EGNN_TAIL_TILE(10, false); }
@@ -967,7 +995,7 @@ extern "C" int egnn_skinny_dx_bn_bwd_f32(const float* G, int64_t ldg, const floa
     const int64_t items = sbs * (C / 64);
     const unsigned grid = (unsigned)((items + 3) / 4);
 #define EGNN_DX_BN(KS, ADD)                                                                                                                  \
-  hipLaunchKernelGGL((skinny_dx_bn_kernel<KS, 1, 3, ADD>), dim3(grid), dim3(256), 0, st, G, ldg, W, ldw, w_kmajor, (int)Ks, alpha,              \
+  hipLaunchKernelGGL((skinny_dx_bn_kernel<KS, 1, 3, ADD>), dim3(grid), dim3(256), 0, st, G, ldg, W, ldw, b_kmajor, (int)Ks, alpha,              \
                      kDxBnRows / 16, addend, ld_addend, add_rows, ld_add_rows, add_inv, q, dx, ld_dx, ws)
     if (ksteps <= 4) { if (addend) EGNN_DX_BN(4, true); else EGNN_DX_BN(4, false); }
     else if (ksteps <= 10) { if (addend) EGNN_DX_BN(10, true); else EGNN_DX_BN(10, false); }

@@ -13,6 +13,9 @@ int egnn_skinny_fwd(const float* X, int64_t ldx, const float* W, int64_t ldw, in
 int egnn_skinny_dx(const float* G, int64_t ldg, const float* B, int64_t ldb, int b_kmajor, float* Y, int64_t ldy, int64_t M, int64_t Nbig,
                    int64_t Ks, float alpha, hipStream_t st);
 size_t egnn_skinny_dw_ws_floats(int64_t R, int64_t Ns, int64_t Nb);
+// fused_bn.hip: the narrow forward of a 256-wide X with its rows streamed through an LDS tile (1 = shape not taken)
+int egnn_skinny_fwd_tile(const float* X, int64_t ldx, const float* W, int64_t ldw, int w_kmajor, const float* bias, float* Y, int64_t ldy, int64_t M,
+                         int64_t N, int64_t K, float alpha, hipStream_t st);
 int egnn_skinny_dw(const float* S, int64_t lds_, const float* Bg, int64_t ldb, int64_t R, int64_t Ns, int64_t Nb, float alpha, float* C,
                    int64_t c_ld_s, int64_t c_ld_b, float* ws, size_t ws_floats, hipStream_t st);
 
@@ -341,7 +344,10 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   if (!a_rows && !b_rows && flags == 0) {   // class-count-wide shapes: dedicated HBM-bound kernels (gemm_skinny.hip); rc 1 = shape not taken
     const int kind = skinny_kind(trans_a, trans_b, M, N, K, bias != nullptr);
     int rc = 1;
-    if (kind == 1) rc = egnn_skinny_fwd(A, lda, B, ldb, trans_b, bias, C, ldc, M, N, K, alpha, st0);
+    if (kind == 1) {
+      rc = egnn_skinny_fwd_tile(A, lda, B, ldb, trans_b, bias, C, ldc, M, N, K, alpha, st0);
+      if (rc == 1) rc = egnn_skinny_fwd(A, lda, B, ldb, trans_b, bias, C, ldc, M, N, K, alpha, st0);
+    }
     else if (kind == 2) rc = egnn_skinny_dx(A, lda, B, ldb, trans_b, C, ldc, M, N, K, alpha, st0);
     else if (kind == 3) rc = egnn_skinny_dw(A, lda, B, ldb, K, M, N, alpha, C, ldc, 1, ws, ws_bytes / sizeof(float), st0);
     else if (kind == 4) rc = egnn_skinny_dw(B, ldb, A, lda, K, N, M, alpha, C, 1, ldc, ws, ws_bytes / sizeof(float), st0);

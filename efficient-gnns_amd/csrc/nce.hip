@@ -523,11 +523,13 @@ __global__ __launch_bounds__(256, OCC) void nce3_bwd_kernel(const float* __restr
 }
 
 constexpr int kNce3SplitMax = 8;   // k ranges of the reduction (fixed-order reduce afterwards); the workspace is sized for the maximum
-static inline int nce3_split() {
+static inline int nce3_split(int64_t M) {
   // 4 k-ranges: 2 378 vs 2 433 us (8) vs 2 718 us (2) for forward + backward at S = 16 384, P = 256 (fewer partials to reduce, still one
-  // workgroup per CU on the 256 x 256 side); EGNN_NCE_KSPLIT = 2 | 4 | 8 is the lab knob
-  static const int n = getenv("EGNN_NCE_KSPLIT") ? atoi(getenv("EGNN_NCE_KSPLIT")) : 4;
-  return n == 2 || n == 8 ? n : 4;
+  // workgroup per CU on the 256 x 256 side).  At S = 8 192 the 256 x 256 side has 32 tiles: 8 ranges fill the 256 CUs, 4 leave half of
+  // them idle (735 vs 814 us).  EGNN_NCE_KSPLIT = 2 | 4 | 8 is the lab knob.
+  static const int n = getenv("EGNN_NCE_KSPLIT") ? atoi(getenv("EGNN_NCE_KSPLIT")) : 0;
+  if (n == 2 || n == 4 || n == 8) return n;
+  return (M / 256) * 4 >= 256 ? 4 : 8;
 }
 
 // floats of workspace the DMA backward needs for one side: partials + the packed planes of the small operand (+ slack for alignment)
@@ -549,7 +551,7 @@ int launch_bwd3(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag
                 int64_t ldb, const float* Im, int64_t ldi, float coef, const float* g, float* C, int64_t ldc, float* ws, hipStream_t st) {
   using namespace egnn_gemm3;
   float* partial = ws;
-  const int kNce3Split = nce3_split();
+  const int kNce3Split = nce3_split(M);
   char* planes = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws + (size_t)kNce3SplitMax * M * P) + 1023) & ~(uintptr_t)1023);
   const int64_t k_per_split = Kd / kNce3Split;
   int rc;

@@ -1018,7 +1018,7 @@ class _BnActLinear(torch.autograd.Function):
         if fused:
             nws = lib.egnn_skinny_dx_bn_ws_floats(n, C)
             ws = torch.empty(nws, dtype=torch.float32, device=dev)
-            rc = lib.egnn_skinny_dx_bn_bwd_f32(_lib.ptr(g_xw), g_xw.stride(0), _lib.ptr(w), w.stride(0), 1, n, C, Ks, 1.0,
+            rc = lib.egnn_skinny_dx_bn_bwd_f32(_lib.ptr(g_xw), g_xw.stride(0), _lib.ptr(w), w.stride(0), 0, n, C, Ks, 1.0,
                                                _lib.ptr(g_h), 0 if g_h is None else g_h.stride(0), _lib.ptr(rows),
                                                0 if rows is None else rows.stride(0), _lib.ptr(inv), _lib.ptr(x), x.stride(0), _lib.ptr(mean),
                                                _lib.ptr(var), eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev),

@@ -436,7 +436,8 @@ int egnn_bn_act_rows_bwd_f32(const float* x, int64_t ld, int64_t n, int64_t C, c
                              int relu, float p, uint64_t seed, const uint64_t* seed_dev, int batch_stats, float* dgamma, float* dbeta,
                              float* dx, int64_t ld_dx, float* dx_colsum, float* ws, size_t ws_floats, void* stream);
 
-/* Backward of  h = act(bn(x)) [M, C]  followed by the narrow Linear  h W  (W [C, Ks] as w_kmajor = 1, or [Ks, C] rows as 0; Ks <= 64, C % 64 == 0)
+/* Backward of  h = act(bn(x)) [M, C]  followed by the narrow Linear  h W  (W [C, Ks] for w_kmajor = 0, [Ks, C] rows for 1 -- the same
+ * flag as egnn_bn_act_linear_fwd_f32; Ks <= 64, C % 64 == 0)
  * in one pass over the [M, C] tensors -- the last hidden layer of the students (/root/reference/arxiv_pyg/gnn.py:47-52 under loss.backward()):
  *   dh = alpha G W^T (+ addend, nullable dense [M, C]) (+ add_rows[add_inv[row]] where add_inv[row] >= 0: the row-compact input gradient of
  *   the projection head, gnn.py:150; add_inv int32 [M], -1 = no row), d = dh * gate(x) never stored as dh; dgamma / dbeta / dx / dx_colsum as
