@@ -411,16 +411,20 @@ def gather_ceiling(adj_gcn, K, device):
 
 
 def lib_sha16() -> str:
-    """Identity of the kernel library the run uses: first 16 hex digits of the SHA-256 of libegnn_hip.so."""
-    import hashlib
-    from efficient_gnns_amd import _lib
-    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    """Identity of the kernels the run uses: ``build.source_stamp()`` -- SHA-256[:16] over the compile flags and the library's sources
+    (the binary embeds its build time, so a rebuild of the same sources changes its bytes but not this value).  The library is built
+    from these sources by ``__graft_entry__.build()`` (stale objects are recompiled) before any bench run of the driver."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("egnn_build", os.path.join(ROOT, "efficient-gnns_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b.source_stamp()
 
 
 def measured_traffic(name):
     """HBM-side bytes per aggregation call from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in their own rocprofv3 runs
     over the lab driver by tools/evidence.sh, calibrated on a copy of known size; profiles/<name>).  The file records the
-    SHA-256 of the libegnn_hip.so it was measured on: a file from another build is STALE and is not reported
+    stamp of the kernel sources it was measured on (lib_sha16): a file from other kernels is STALE and is not reported
     (traffic = null) -- the counters cannot be collected inside this process (rocprofv3 wraps the process it profiles)."""
     tj = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(tj):

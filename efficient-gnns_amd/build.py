@@ -29,6 +29,21 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_stamp() -> str:
+    """Identity of the kernel library as a build-independent value: first 16 hex digits of the SHA-256 over the compile flags and the
+    bytes of every source the library is built from (csrc/*.hip, csrc/*.h, include/egnn_hip.h).  The binary itself carries its build
+    time (egnn_version_string), so two builds of the same sources differ byte for byte; measurements that must be tied to "these
+    kernels" (profiles/spmm_traffic*.json) are stamped with this value instead."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    files.append(os.path.join(os.path.dirname(HERE), "include", "egnn_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")

@@ -5,8 +5,9 @@ passes, counters only), calibrated on the two 256 MiB device-to-device copies th
 
     python tools/lab/traffic.py gpurun_out/r03/pmc chunglu default 367506008 > profiles/spmm_traffic.json
 
-The JSON records ``lib_sha16`` (SHA-256 of the libegnn_hip.so the passes ran on): bench.py reports the traffic only when it
-runs on that very build."""
+The JSON records ``lib_sha16`` (build.source_stamp(): SHA-256 over the compile flags and the sources of the libegnn_hip.so the passes ran
+on -- the binary embeds its build time, its own hash would not survive a rebuild of the same sources): bench.py reports the traffic
+only when it runs on those kernels."""
 import csv
 import hashlib
 import json
@@ -15,9 +16,9 @@ import sys
 
 d, graph, var, alg = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 COPY = 256 << 20
-LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "efficient-gnns_amd", "lib", "libegnn_hip.so")
-out = {"graph": graph, "variant": var, "algorithmic_bytes_per_call": alg,
-       "lib_sha16": hashlib.sha256(open(LIB, "rb").read()).hexdigest()[:16]}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import bench  # noqa: E402  (repo root: the one definition of the stamp)
+out = {"graph": graph, "variant": var, "algorithmic_bytes_per_call": alg, "lib_sha16": bench.lib_sha16()}
 total = 0.0
 for key, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     rows = [r for r in csv.DictReader(open(os.path.join(d, f"{graph}_{var}_{key}.csv"))) if r["Counter_Name"] == counter]
