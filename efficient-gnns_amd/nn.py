@@ -184,7 +184,7 @@ class SAGEConv(nn.Module):
             agg = edge_index.aggregate(x, self.aggr, valueless=True)
             return ops.linear(agg, self.lin_l.weight, self.lin_l.bias) + ops.linear(x, self.lin_r.weight, None)
         adj = edge_index if isinstance(edge_index, SparseTensor) else _adj_from_edge_index(edge_index, x.shape[0])
-        if _SAGE_NARROW_FIRST and self.out_channels < self.in_channels and self.aggr in ("mean", "sum") and _lib.on_gpu(x):
+        if _SAGE_NARROW_FIRST and self.out_channels < self.in_channels and self.aggr in ("mean", "sum") and x.is_cuda:
             # mean / sum are linear: aggr_j(x_j) W^T == aggr_j(x_j W^T).  On the output layer (256 -> 40 classes, gnn.py:84) the HBM-bound
             # gather then moves `out` instead of `in` floats per neighbour, forward and backward -- the re-association GCNConv makes.
             # The bias goes in after the aggregation (a row without neighbours gets lin_l(0) = bias either way).
