@@ -366,3 +366,45 @@ def test_community_order_and_permute_host_logic():
     assert torch.equal(perm[d.split_idx["train"]], tr0), "index sets keep pointing at the same nodes"
     after = near(d.adj_t, n // 40)
     assert after > 5 * before and after > 0.3, (before, after)
+
+
+def test_traffic_files_are_tied_to_the_kernel_sources(tmp_path, monkeypatch):
+    """bench.measured_traffic reports a PMC file only when it carries the stamp of the kernel sources in the tree (build.source_stamp:
+    compile flags + csrc + header; independent of the binary's embedded build time), and the committed files carry it."""
+    import importlib.util
+    import json
+    import shutil
+    import bench
+    spec = importlib.util.spec_from_file_location("egnn_build_t", os.path.join(ROOT, "efficient-gnns_amd", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    stamp = b.source_stamp()
+    assert re.fullmatch(r"[0-9a-f]{16}", stamp) and stamp == bench.lib_sha16() == b.source_stamp()
+    for name in ("spmm_traffic.json", "spmm_traffic_local.json"):
+        j = json.load(open(os.path.join(ROOT, "profiles", name)))
+        val, why = bench.measured_traffic(name)
+        if j["lib_sha16"] == stamp:
+            assert val == float(j["hbm_bytes_per_call"]) and stamp in why
+        else:   # kernels edited since the last evidence run: the line will say traffic = null until tools/evidence.sh <tag> traffic is re-run
+            import warnings
+            warnings.warn(f"profiles/{name} was measured on other kernel sources ({j['lib_sha16']} != {stamp}): bench.py reports traffic = null")
+            assert val is None and "stale" in why
+    # a file from other sources is refused; one changed source byte changes the stamp
+    fake_root = tmp_path / "repo"
+    os.makedirs(fake_root / "profiles")
+    j["lib_sha16"] = "0" * 16
+    json.dump(j, open(fake_root / "profiles" / "spmm_traffic.json", "w"))
+    monkeypatch.setattr(bench, "ROOT", str(fake_root))
+    monkeypatch.setattr(bench, "lib_sha16", lambda: stamp)
+    val, why = bench.measured_traffic("spmm_traffic.json")
+    assert val is None and "stale" in why
+    csrc2 = tmp_path / "pkg" / "csrc"
+    shutil.copytree(os.path.join(ROOT, "efficient-gnns_amd", "csrc"), csrc2)
+    os.makedirs(tmp_path / "include")
+    shutil.copy(os.path.join(ROOT, "include", "egnn_hip.h"), tmp_path / "include" / "egnn_hip.h")
+    monkeypatch.setattr(b, "CSRC", str(csrc2))
+    monkeypatch.setattr(b, "HERE", str(tmp_path / "pkg"))
+    assert b.source_stamp() == stamp
+    with open(csrc2 / "common.h", "a") as f:
+        f.write("\n// one more byte\n")
+    assert b.source_stamp() != stamp
