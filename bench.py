@@ -430,7 +430,8 @@ def measured_traffic(name):
     if not os.path.exists(tj):
         return None, f"profiles/{name} absent"
     try:
-        j = json.load(open(tj))
+        with open(tj) as fh:
+            j = json.load(fh)
     except Exception as e:  # noqa: BLE001
         return None, f"profiles/{name} unreadable: {e}"
     have = lib_sha16()

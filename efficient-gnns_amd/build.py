@@ -40,7 +40,8 @@ def source_stamp() -> str:
     files.append(os.path.join(os.path.dirname(HERE), "include", "egnn_hip.h"))
     for f in files:
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
     return h.hexdigest()[:16]
 
 

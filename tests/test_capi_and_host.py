@@ -381,7 +381,8 @@ def test_traffic_files_are_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     stamp = b.source_stamp()
     assert re.fullmatch(r"[0-9a-f]{16}", stamp) and stamp == bench.lib_sha16() == b.source_stamp()
     for name in ("spmm_traffic.json", "spmm_traffic_local.json"):
-        j = json.load(open(os.path.join(ROOT, "profiles", name)))
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            j = json.load(fh)
         val, why = bench.measured_traffic(name)
         if j["lib_sha16"] == stamp:
             assert val == float(j["hbm_bytes_per_call"]) and stamp in why
@@ -393,7 +394,8 @@ def test_traffic_files_are_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     fake_root = tmp_path / "repo"
     os.makedirs(fake_root / "profiles")
     j["lib_sha16"] = "0" * 16
-    json.dump(j, open(fake_root / "profiles" / "spmm_traffic.json", "w"))
+    with open(fake_root / "profiles" / "spmm_traffic.json", "w") as fh:
+        json.dump(j, fh)
     monkeypatch.setattr(bench, "ROOT", str(fake_root))
     monkeypatch.setattr(bench, "lib_sha16", lambda: stamp)
     val, why = bench.measured_traffic("spmm_traffic.json")
