@@ -22,6 +22,7 @@ from .sparse import SparseTensor
 
 _EVAL_BN_FOLD = os.environ.get("EGNN_EVAL_BN_FOLD", "1") == "1"   # A/B switch of the eval-mode BatchNorm fold
 _TRAIN_ROWS = os.environ.get("EGNN_TRAIN_ROWS", "1") == "1"       # A/B switch: [train_idx] row picks inside the CE / KD kernels
+_LSP_FULL_ROWS = os.environ.get("EGNN_LSP_FULL_ROWS", "1") == "1"    # A/B switch: LSP on the full tensors through composed edge ids
 _FUSED_TAIL = os.environ.get("EGNN_FUSED_TAIL", "1") == "1"        # A/B switch: ops.bn_act_linear for the last hidden layer of a GCN
 _SAMPLED_HEADS = os.environ.get("EGNN_SAMPLED_HEADS", "1") == "1"  # A/B switch: projection heads form only the rows a sampled criterion keeps
 
@@ -162,6 +163,21 @@ def _const_rows(t, idx):
     return hit[0]
 
 
+_GLOBAL_EDGES: dict = {}
+
+
+def _global_edges(edge_index, train_idx):
+    """``train_idx[edge_index]``: the edge list of the train-induced subgraph (relabelled, gnn.py:274) in node ids of the full graph.
+    Built once per (edge list, index) identity + version; the entry keeps both alive."""
+    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), train_idx.data_ptr(), train_idx._version, train_idx.numel())
+    hit = _GLOBAL_EDGES.get(key)
+    if hit is None:
+        if len(_GLOBAL_EDGES) > 4:
+            _GLOBAL_EDGES.clear()
+        hit = _GLOBAL_EDGES[key] = (train_idx[edge_index].contiguous(), edge_index, train_idx)
+    return hit[0]
+
+
 def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_logits, hp,
                  student_proj=None, teacher_proj=None, edge_index=None, adj_t=None, kd_and_aux=False, rows=None):
     """``rows`` = None: ``out`` / ``labels`` are the compact train rows (gnn.py:109-110).  ``rows`` = train_idx: they are the FULL
@@ -185,6 +201,11 @@ def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_
         else:
             f = student_proj(ops.take_rows(model.out_feat, train_idx))
             t = teacher_proj(_const_rows(teacher_out_feat, train_idx))
+    elif mode == "lpw" and _LSP_FULL_ROWS and edge_index is not None and _lib.on_gpu(model.out_feat):
+        # LSP reads rows only through the edge list (criterion.py:100-104): the train-subgraph ids of gnn.py:274 are composed with
+        # train_idx once, and the edge kernels then address the FULL feature tensors -- feat[train_idx] / teacher_feat[train_idx] (366 MB of
+        # copies per step) and the zero-fill + scatter of their backward never exist; the loss is a mean over the same edges.
+        f, t, edge_index = model.out_feat, teacher_out_feat, _global_edges(edge_index, train_idx)
     elif mode in ("at", "lpw"):
         f, t = ops.take_rows(model.out_feat, train_idx), _const_rows(teacher_out_feat, train_idx)
     elif mode == "gcd":
