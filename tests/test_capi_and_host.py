@@ -410,3 +410,31 @@ def test_traffic_files_are_tied_to_the_kernel_sources(tmp_path, monkeypatch):
     with open(csrc2 / "common.h", "a") as f:
         f.write("\n// one more byte\n")
     assert b.source_stamp() != stamp
+
+
+def test_index_helpers_of_the_fused_paths_on_host():
+    """Pure index logic behind two fused paths: ops._inverse_rows (row id -> position in the unique train index, -1 elsewhere; what the
+    fused last-layer backward uses to find the projection head's row) and models._global_edges (the relabelled edge list of the
+    train-induced subgraph, gnn.py:274, composed with train_idx); both cached on the identity AND version of their inputs."""
+    import efficient_gnns_amd.models as PM
+    import efficient_gnns_amd.ops as ops
+    from efficient_gnns_amd.utils import subgraph
+    g = torch.Generator().manual_seed(0)
+    n = 500
+    idx = torch.randperm(n, generator=g)[:200]
+    inv = ops._inverse_rows(idx, n)
+    assert inv.dtype == torch.int32 and inv.shape == (n,)
+    assert torch.equal(inv[idx].long(), torch.arange(200)) and int((inv >= 0).sum()) == 200 and int(inv.min()) == -1
+    assert ops._inverse_rows(idx, n) is inv                      # cached
+    idx[0], idx[1] = idx[1].clone(), idx[0].clone()             # in-place edit bumps the version: a new inverse
+    inv2 = ops._inverse_rows(idx, n)
+    assert inv2 is not inv and torch.equal(inv2[idx].long(), torch.arange(200))
+    # edges of the induced subgraph, relabelled -> back in full-graph ids they are exactly the edges with both ends in the index set
+    ei = torch.randint(0, n, (2, 4000), generator=g)
+    sub, _ = subgraph(idx, ei, relabel_nodes=True, num_nodes=n)
+    glob = PM._global_edges(sub, idx)
+    member = torch.zeros(n, dtype=torch.bool)
+    member[idx] = True
+    keep = member[ei[0]] & member[ei[1]]
+    assert glob.shape == sub.shape and torch.equal(glob, ei[:, keep])
+    assert PM._global_edges(sub, idx) is glob
