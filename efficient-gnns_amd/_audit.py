@@ -1,0 +1,57 @@
+"""Audit of the operators a step issues before it is captured into a hipGraph.
+
+Why: torch's multi-block reductions (ATen/native/cuda/Reduce.cuh) zero their inter-block semaphores with a
+``cudaMemsetAsync`` -- a MEMSET NODE once captured -- and never reset them in the kernel.  Inside the replayed train step on
+this stack (ROCm 7.2, gfx950) such reductions were seen to leave their output unwritten: ``kl_div(..., 'mean')`` over 680 k
+edges returned the stale bytes of an earlier workspace, 368.4 instead of 1.9e-5, in EVERY replay when the first launch found
+the device idle (profiles/r04_lsp_trace.txt).  The step therefore forms every long sum in this package's own fixed-order
+kernels, and ``GraphedEpoch`` refuses to capture a step that still contains a long torch reduction.
+"""
+from __future__ import annotations
+
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+# aten operators that run (or may run) through gpu_reduce_kernel
+_REDUCTIONS = {"sum", "mean", "amax", "amin", "max", "min", "prod", "any", "all", "norm", "linalg_vector_norm", "logsumexp", "var",
+               "std", "var_mean", "std_mean", "nansum", "argmax", "argmin", "count_nonzero", "mse_loss", "l1_loss", "smooth_l1_loss",
+               "huber_loss", "binary_cross_entropy", "binary_cross_entropy_with_logits", "kl_div", "_log_softmax", "_softmax",
+               "nll_loss_forward", "dot", "vdot", "trace", "median", "aminmax"}
+LONG = 2048   # reduced elements per output from which a reduction may be split over blocks
+
+
+class LongReductionInCapture(RuntimeError):
+    pass
+
+
+class CaptureAudit(TorchDispatchMode):
+    """Records (operator, reduced length, input shape) of every torch reduction over GPU tensors whose reduced length per output
+    is >= ``LONG``."""
+
+    def __init__(self, any_device: bool = False):
+        super().__init__()
+        self.flagged: list = []
+        self.any_device = any_device   # CPU tensors count too (the CPU test of this class)
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        out = func(*args, **(kwargs or {}))
+        name = func.overloadpacket.__name__ if hasattr(func, "overloadpacket") else str(func)
+        if name in _REDUCTIONS:
+            src = next((a for a in args if isinstance(a, torch.Tensor)), None)
+            res = out[0] if isinstance(out, (tuple, list)) else out
+            if src is not None and (src.is_cuda or self.any_device) and isinstance(res, torch.Tensor):
+                per_out = src.numel() // max(res.numel(), 1)
+                # row-wise softmax / losses reduce along the last dimension only
+                if name in ("_log_softmax", "_softmax"):
+                    per_out = src.shape[-1] if src.dim() else 1
+                if per_out >= LONG:
+                    self.flagged.append((name, per_out, tuple(src.shape)))
+        return out
+
+    def check(self, what: str) -> None:
+        if self.flagged:
+            ops = ", ".join(f"aten.{n} over {k} elements of {s}" for n, k, s in self.flagged[:6])
+            raise LongReductionInCapture(
+                f"{what}: the step contains long torch reductions ({ops}); their multi-block form relies on a memset node that does not "
+                "take effect reliably in replayed hipGraphs on this stack -- use the package's fixed-order kernels (ops.colsum, "
+                "ops_edge._LspLoss, ...) or run the step with eager launches")

@@ -69,6 +69,11 @@ SIGNATURES = {
     "egnn_segment_softmax_fwd_f32": (_i32, [_p, _p, _i64, _p, _p]),
     "egnn_segment_softmax_bwd_f32": (_i32, [_p, _p, _p, _i64, _p, _p]),
     "egnn_segment_sum_f32": (_i32, [_p, _p, _i64, _p, _p]),
+    "egnn_lsp_loss_ws_floats": (_sz, []),
+    "egnn_lsp_loss_fwd_f32": (_i32, [_p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p]),
+    "egnn_lsp_loss_bwd_f32": (_i32, [_p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p]),
+    "egnn_colsum_ws_floats": (_sz, [_i64]),
+    "egnn_colsum_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p]),
     "egnn_bn_ws_floats": (_sz, [_i64]),
     "egnn_bn_stats_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p, _sz, _p]),
     "egnn_bn_act_fwd_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _i64, _p]),
@@ -88,6 +93,7 @@ SIGNATURES = {
     "egnn_bn_running_update_f32": (_i32, [_p, _p, _i64, _i64, _f32, _p, _p, _p, _p]),
     "egnn_split_accuracy_ws_ints": (_sz, []),
     "egnn_split_accuracy_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
+    "egnn_split_counts_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _sz, _p]),
     "egnn_rows_add_f32": (_i32, [_p, _i64, _p, _p, _i64, _i64, _i64, _p]),
     "egnn_feature_loss_ws_floats": (_sz, [_i64]),
     "egnn_fitnet_fwd_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _f32, _p, _p, _sz, _p]),
@@ -119,7 +125,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.egnn_abi_version() != 4:
+    if lib.egnn_abi_version() != 5:
         raise HipExtensionError("libegnn_hip.so ABI version mismatch")
     _lib = lib
     return lib

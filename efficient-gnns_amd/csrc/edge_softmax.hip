@@ -133,6 +133,142 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const int64_t* __restrict_
   }
 }
 
+// ---- LSP criterion tail (criterion.py:103-122) as ONE pass per direction ----------------------------------------------------
+// loss = mean_e term(p_s[e], p_t[e]) with p_* = segment softmax of the similarity vectors (PyG softmax: / (sum + 1e-16)):
+//   KLD: F.kl_div(log p_s, p_t, reduction='mean')  ->  term = p_t (log p_t - log p_s), 0 where p_t == 0
+//   MSE: F.mse_loss(p_s, p_t)                      ->  term = (p_s - p_t)^2
+// Both softmaxes, the element-wise term and its sum are formed by the wave that owns the segment; the sum over segments is a fixed
+// grid-stride assignment + a fixed-order finalize (deterministic, and no torch reduction -- whose multi-block form zeroes its
+// semaphores with a memset node that was seen NOT to take effect in hipGraph replays on this stack, profiles/r04_lsp_trace.txt).
+constexpr int kLspBlocks = 1024;
+
+__device__ __forceinline__ void seg_softmax_stats(const float* __restrict__ x, int64_t b, int64_t e, int lane, float& m, float& den) {
+  m = -INFINITY;
+  for (int64_t i = b + lane; i < e; i += 64) m = fmaxf(m, x[i]);
+  m = egnn_wave_max(m);
+  float z = 0.f;
+  for (int64_t i = b + lane; i < e; i += 64) z += expf(x[i] - m);
+  den = egnn_wave_sum(z) + 1e-16f;
+}
+
+__global__ __launch_bounds__(256) void lsp_loss_fwd_kernel(const int64_t* __restrict__ ptr, const float* __restrict__ xs,
+                                                           const float* __restrict__ xt, int64_t n_seg, int mse,
+                                                           float* __restrict__ ps, float* __restrict__ pt,
+                                                           float* __restrict__ partials) {
+  __shared__ float s_part[4];
+  const int lane = egnn_lane();
+  const int wave = egnn_wave_id();
+  float acc = 0.f;
+  for (int64_t s = blockIdx.x * 4LL + wave; s < n_seg; s += (int64_t)gridDim.x * 4) {
+    const int64_t b = ptr[s], e = ptr[s + 1];
+    if (b == e) continue;
+    float ms, ds, mt, dt;
+    seg_softmax_stats(xs, b, e, lane, ms, ds);
+    seg_softmax_stats(xt, b, e, lane, mt, dt);
+    for (int64_t i = b + lane; i < e; i += 64) {
+      const float a = expf(xs[i] - ms) / ds;   // a DIVISION per entry as in the reference (see seg_softmax_fwd_kernel)
+      const float t = expf(xt[i] - mt) / dt;
+      ps[i] = a;
+      pt[i] = t;
+      if (mse) { const float d = a - t; acc = fmaf(d, d, acc); }
+      else acc += t > 0.f ? t * (logf(t) - logf(a)) : 0.f;
+    }
+  }
+  acc = egnn_wave_sum(acc);
+  if (lane == 0) s_part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+__global__ __launch_bounds__(256) void lsp_loss_final_kernel(const float* __restrict__ partials, int nblocks, float inv_count,
+                                                             float* __restrict__ loss) {
+  __shared__ float s[256];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) a += partials[i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = s[0] * inv_count;
+}
+
+// d loss / d sim_s (and, when asked for, d loss / d sim_t) through the two softmaxes: gx = p * (gp - sum_seg p * gp) with
+//   KLD: gp_s = -g p_t / (E p_s)          gp_t = g (log p_t - log p_s + 1) / E   (0 where p_t == 0)
+//   MSE: gp_s = 2 g (p_s - p_t) / E       gp_t = -gp_s
+__global__ __launch_bounds__(256) void lsp_loss_bwd_kernel(const int64_t* __restrict__ ptr, const float* __restrict__ ps,
+                                                           const float* __restrict__ pt, int64_t n_seg, int mse,
+                                                           const float* __restrict__ g, float inv_count,
+                                                           float* __restrict__ gxs, float* __restrict__ gxt) {
+  const int lane = egnn_lane();
+  const float gs = g[0] * inv_count;
+  for (int64_t s = blockIdx.x * 4LL + egnn_wave_id(); s < n_seg; s += (int64_t)gridDim.x * 4) {
+    const int64_t b = ptr[s], e = ptr[s + 1];
+    if (b == e) continue;
+    float d_s = 0.f, d_t = 0.f;   // sum_seg p * gp for the student / teacher side
+    for (int64_t i = b + lane; i < e; i += 64) {
+      const float a = ps[i], t = pt[i];
+      if (mse) {
+        const float gp = 2.f * gs * (a - t);
+        d_s = fmaf(a, gp, d_s);
+        d_t = fmaf(t, -gp, d_t);
+      } else {
+        d_s -= gs * t;                                       // p_s * (-g p_t / (E p_s))
+        if (gxt != nullptr && t > 0.f) d_t = fmaf(t, gs * (logf(t) - logf(a) + 1.f), d_t);
+      }
+    }
+    d_s = egnn_wave_sum(d_s);
+    if (gxt != nullptr) d_t = egnn_wave_sum(d_t);
+    for (int64_t i = b + lane; i < e; i += 64) {
+      const float a = ps[i], t = pt[i];
+      if (mse) {
+        const float gp = 2.f * gs * (a - t);
+        gxs[i] = a * (gp - d_s);
+        if (gxt != nullptr) gxt[i] = t * (-gp - d_t);
+      } else {
+        gxs[i] = -gs * t - a * d_s;
+        if (gxt != nullptr) gxt[i] = t > 0.f ? t * (gs * (logf(t) - logf(a) + 1.f) - d_t) : 0.f;
+      }
+    }
+  }
+}
+
+// Column sums of a [n, C] matrix: fixed row stripes per block, fixed-order finalize (bias gradients; no torch reduction, see above)
+constexpr int kColsumBlocks = 256;
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t n, int64_t C,
+                                                             float* __restrict__ partials) {
+  // thread -> (row lane r, column c): 256 threads cover rpb rows x cw columns per step
+  const int cw = C >= 256 ? 256 : (C >= 128 ? 128 : (C >= 64 ? 64 : 32));
+  const int rpb = 256 / cw;
+  const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+  __shared__ float s[256];
+  for (int64_t c0 = 0; c0 < C; c0 += cw) {
+    const int64_t c = c0 + tc;
+    float acc = 0.f;
+    if (c < C)
+      for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < n; r += (int64_t)gridDim.x * rpb) acc += x[r * ld + c];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    if (tr == 0 && c < C) {
+      float t = s[tc];
+      for (int k = 1; k < rpb; ++k) t += s[k * cw + tc];
+      partials[(int64_t)blockIdx.x * C + c] = t;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partials, int nblocks, int64_t C,
+                                                           float* __restrict__ out) {
+  const int64_t c = blockIdx.x * 256LL + threadIdx.x;
+  if (c >= C) return;
+  float t = 0.f;
+  for (int b = 0; b < nblocks; ++b) t += partials[(int64_t)b * C + c];
+  out[c] = t;
+}
+
 inline unsigned wave_grid(int64_t n) {
   const int64_t b = (n + 3) / 4;
   return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
@@ -232,5 +368,40 @@ extern "C" int egnn_segment_sum_f32(const int64_t* seg_ptr, const float* x, int6
   if (n_seg == 0) return EGNN_OK;
   EGNN_CHECK_ARG(seg_ptr && x && out);
   hipLaunchKernelGGL(seg_sum_kernel, dim3(wave_grid(n_seg)), dim3(256), 0, (hipStream_t)stream, seg_ptr, x, n_seg, out);
+  return egnn_launch_status();
+}
+
+extern "C" size_t egnn_lsp_loss_ws_floats(void) { return (size_t)kLspBlocks; }
+
+extern "C" int egnn_lsp_loss_fwd_f32(const int64_t* seg_ptr, const float* sim_s, const float* sim_t, int64_t n_seg, int64_t E,
+                                     int criterion, float* p_s, float* p_t, float* loss, float* ws, void* stream) {
+  EGNN_CHECK_ARG(n_seg >= 0 && E > 0 && (criterion == 0 || criterion == 1));
+  EGNN_CHECK_ARG(seg_ptr && sim_s && sim_t && p_s && p_t && loss && ws && n_seg > 0);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t want = (n_seg + 3) / 4;
+  const int nb = (int)(want < kLspBlocks ? want : kLspBlocks);
+  hipLaunchKernelGGL(lsp_loss_fwd_kernel, dim3(nb), dim3(256), 0, st, seg_ptr, sim_s, sim_t, n_seg, criterion, p_s, p_t, ws);
+  hipLaunchKernelGGL(lsp_loss_final_kernel, dim3(1), dim3(256), 0, st, ws, nb, 1.f / (float)E, loss);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_lsp_loss_bwd_f32(const int64_t* seg_ptr, const float* p_s, const float* p_t, int64_t n_seg, int64_t E,
+                                     int criterion, const float* g, float* gsim_s, float* gsim_t, void* stream) {
+  EGNN_CHECK_ARG(n_seg > 0 && E > 0 && (criterion == 0 || criterion == 1));
+  EGNN_CHECK_ARG(seg_ptr && p_s && p_t && g && gsim_s);
+  hipLaunchKernelGGL(lsp_loss_bwd_kernel, dim3(wave_grid(n_seg)), dim3(256), 0, (hipStream_t)stream, seg_ptr, p_s, p_t, n_seg,
+                     criterion, g, 1.f / (float)E, gsim_s, gsim_t);
+  return egnn_launch_status();
+}
+
+extern "C" size_t egnn_colsum_ws_floats(int64_t C) { return (size_t)kColsumBlocks * (size_t)(C > 0 ? C : 0); }
+
+extern "C" int egnn_colsum_f32(const float* x, int64_t ld, int64_t n, int64_t C, float* out, float* ws, void* stream) {
+  EGNN_CHECK_ARG(n > 0 && C > 0 && ld >= C && x && out && ws);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t want = (n + 7) / 8;
+  const int nb = (int)(want < kColsumBlocks ? want : kColsumBlocks);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, x, ld, n, C, ws);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, ws, nb, C, out);
   return egnn_launch_status();
 }

@@ -327,6 +327,23 @@ __global__ __launch_bounds__(64) void split_accuracy_final_kernel(const int* __r
   if (lane < 3) acc3[lane] = v[3 + lane] > 0 ? (double)v[lane] / (double)v[3 + lane] : 0.0 / 0.0;   // empty split: nan, like mean of nothing
 }
 
+// the raw counts instead of the ratios: out6 = (hits of train / valid / test, sizes of train / valid / test) -- what a node-range shard
+// contributes to the all-rank accuracies
+__global__ __launch_bounds__(64) void split_counts_final_kernel(const int* __restrict__ part, int nblocks, double* __restrict__ out6) {
+  const int lane = threadIdx.x;
+  long long v[6] = {0, 0, 0, 0, 0, 0};
+  for (int b = lane; b < nblocks; b += 64)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] += part[b * 6 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) out6[k] = (double)v[k];
+}
+
 // dst[idx[r], :] += src[r, :] for UNIQUE ids (a row-compact gradient joining a dense one, ops._GradTap): one wave per row
 __global__ __launch_bounds__(256) void rows_add_kernel(float* __restrict__ dst, int64_t ldd, const int64_t* __restrict__ idx,
                                                        const float* __restrict__ src, int64_t lds_, int64_t n, int64_t C, int vec4) {
@@ -359,6 +376,18 @@ extern "C" int egnn_split_accuracy_f32(const float* logits, int64_t ld, int64_t 
   const int nb = (int)(want < kAccBlocks ? want : kAccBlocks);
   hipLaunchKernelGGL(split_accuracy_kernel, dim3(nb), dim3(256), 0, st, logits, ld, n, C, y, (const signed char*)split_id, (int*)ws);
   hipLaunchKernelGGL(split_accuracy_final_kernel, dim3(1), dim3(64), 0, st, (const int*)ws, nb, acc3);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_split_counts_f32(const float* logits, int64_t ld, int64_t n, int64_t C, const int64_t* y, const int8_t* split_id,
+                                     double* out6, int32_t* ws, size_t ws_ints, void* stream) {
+  EGNN_CHECK_ARG(n > 0 && C > 0 && ld >= C && logits && y && split_id && out6 && ws);
+  if (ws_ints < egnn_split_accuracy_ws_ints()) return EGNN_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t want = (n + 15) / 16;
+  const int nb = (int)(want < kAccBlocks ? want : kAccBlocks);
+  hipLaunchKernelGGL(split_accuracy_kernel, dim3(nb), dim3(256), 0, st, logits, ld, n, C, y, (const signed char*)split_id, (int*)ws);
+  hipLaunchKernelGGL(split_counts_final_kernel, dim3(1), dim3(64), 0, st, (const int*)ws, nb, out6);
   return egnn_launch_status();
 }
 

@@ -771,7 +771,8 @@ def sharded_train_step_tensors(model, prob: ShardedProblem, optimizer, mode: str
     zero = torch.zeros((), dtype=torch.float32, device=dev)
     # A rank that owns no train row still has to run the SAME backward collectives as its peers (halo exchange and
     # SyncBN reductions of every layer): its loss terms are exact zeros that stay attached to the model's graph.
-    attached_zero = out.sum() * 0.0
+    # (formed only on such a rank: ``out`` is then empty and the sum is a trivial launch, never a long reduction inside a captured step)
+    attached_zero = (out.sum() * 0.0) if out.shape[0] == 0 else None
     if mode == "supervised":
         loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else attached_zero
         loss_aux = zero
@@ -847,8 +848,12 @@ def sharded_evaluate_tensors(model, prob: ShardedProblem):
     """``test()`` on shards without the host read: (local logits, device tensor of the three GLOBAL hit counts)."""
     model.eval()
     out = model(prob.x, prob.adj)
-    y_pred = out.argmax(dim=-1, keepdim=True)
-    correct = torch.stack([(prob.y[prob.split_local[k]] == y_pred[prob.split_local[k]]).sum() for k in ("train", "valid", "test")]).float()
+    if _lib.on_gpu(out):
+        # argmax + the three hit counts in one pass of this package's kernel (no long torch reduction inside the captured epoch, _audit.py)
+        correct = ops.split_accuracy(out, prob.y, prob.split_local, counts=True)[:3].to(torch.float32)
+    else:
+        y_pred = out.argmax(dim=-1, keepdim=True)
+        correct = torch.stack([(prob.y[prob.split_local[k]] == y_pred[prob.split_local[k]]).sum() for k in ("train", "valid", "test")]).float()
     dist.all_reduce(correct, group=prob.group)
     return out, correct
 
@@ -899,9 +904,15 @@ class ShardedGraphedEpoch:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                for _ in range(warmup):
+                for i in range(warmup):
                     self._refresh()
-                    body()
+                    if i == warmup - 1:   # no long torch reduction may be captured (their memset node: _audit.py); same check on every rank
+                        from ._audit import CaptureAudit
+                        with CaptureAudit() as audit:
+                            body()
+                        audit.check("ShardedGraphedEpoch")
+                    else:
+                        body()
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()

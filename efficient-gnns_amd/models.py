@@ -332,9 +332,17 @@ class GraphedEpoch:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side), self._installed():
-            for _ in range(warmup):
+            for i in range(warmup):
                 self._refresh()
-                body()
+                if i == warmup - 1:
+                    # the step about to be captured must not contain a long torch reduction (see _audit.py: their semaphore memset
+                    # node was seen not to take effect in replays -- outputs silently stale)
+                    from ._audit import CaptureAudit
+                    with CaptureAudit() as audit:
+                        body()
+                    audit.check("GraphedEpoch")
+                else:
+                    body()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()

@@ -255,7 +255,40 @@ def colsum(g: Tensor) -> Tensor:
     tag = getattr(g, "_egnn_colsum", None)
     if tag is not None and tag[1] == g._version and tag[0].shape[0] == g.shape[1]:
         return tag[0]
-    return g.sum(0)
+    if not g.is_cuda or g.dim() != 2 or g.dtype != torch.float32 or g.shape[0] == 0:
+        _lib.on_gpu(g)
+        return g.sum(0)
+    # egnn_colsum_f32, not ``g.sum(0)``: torch's multi-block reduction zeroes its semaphores with a memset node, and inside replayed
+    # hipGraphs on this stack such reductions were seen to leave their output unwritten (ops_edge._LspLoss)
+    g = _rowmajor(g)
+    n, C = g.shape
+    lib = _lib.load()
+    out = torch.empty(C, dtype=torch.float32, device=g.device)
+    ws = torch.empty(lib.egnn_colsum_ws_floats(C), dtype=torch.float32, device=g.device)
+    _lib.check(lib.egnn_colsum_f32(_lib.ptr(g), g.stride(0), n, C, _lib.ptr(out), _lib.ptr(ws), _lib.stream()), "egnn_colsum_f32")
+    return out
+
+
+class _AddBias(torch.autograd.Function):
+    """x + bias (broadcast over rows); the bias gradient is ``colsum`` -- not autograd's ``sum_to_size``, a long torch reduction over
+    the node dimension (see _audit.py)."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        return x + bias
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, (colsum(g) if ctx.needs_input_grad[1] else None)
+
+
+def add_bias(x: Tensor, bias: Tensor | None) -> Tensor:
+    if bias is None:
+        return x
+    if not x.is_cuda:
+        _lib.on_gpu(x)
+        return x + bias
+    return _AddBias.apply(x, bias)
 
 
 def spmm(adj, x: Tensor, reduce: str = "sum", bias: Tensor | None = None, bn_stats_shift: Tensor | None = None,
@@ -487,23 +520,27 @@ def split_ids(split_idx: dict, n: int, device) -> Tensor:
     return hit[0]
 
 
-def split_accuracy(logits: Tensor, y: Tensor, split_idx: dict) -> Tensor:
+def split_accuracy(logits: Tensor, y: Tensor, split_idx: dict, counts: bool = False) -> Tensor:
     """float64 [3]: the Evaluator accuracies of test() (gnn.py:198-218) for train / valid / test in one pass over the
-    logits (egnn_split_accuracy_f32: first-max argmax, integer hit counts over split sizes)."""
+    logits (egnn_split_accuracy_f32: first-max argmax, integer hit counts over split sizes).
+    ``counts``: float64 [6] = (hits of the three splits, sizes of the three splits) instead of the ratios (a shard's contribution
+    to the all-rank accuracies)."""
     _lib.require_gpu(logits, y)
     logits = _rowmajor(logits)
     n, C = logits.shape
     yv = y.reshape(-1)
     if yv.dtype != torch.int64 or yv.numel() != n:
         raise TypeError("split_accuracy: labels must be int64 [n] or [n,1]")
+    if n == 0:
+        return torch.zeros(6, dtype=torch.float64, device=logits.device) if counts else torch.full((3,), float("nan"), dtype=torch.float64, device=logits.device)
     yv = yv.contiguous()
     sid = split_ids(split_idx, n, logits.device)
     lib = _lib.load()
     nws = lib.egnn_split_accuracy_ws_ints()
     ws = torch.empty(nws, dtype=torch.int32, device=logits.device)
-    acc = torch.empty(3, dtype=torch.float64, device=logits.device)
-    _lib.check(lib.egnn_split_accuracy_f32(_lib.ptr(logits), logits.stride(0), n, C, _lib.ptr(yv), _lib.ptr(sid), _lib.ptr(acc), _lib.ptr(ws), nws,
-                                           _lib.stream()), "egnn_split_accuracy_f32")
+    acc = torch.empty(6 if counts else 3, dtype=torch.float64, device=logits.device)
+    fn, name = (lib.egnn_split_counts_f32, "egnn_split_counts_f32") if counts else (lib.egnn_split_accuracy_f32, "egnn_split_accuracy_f32")
+    _lib.check(fn(_lib.ptr(logits), logits.stride(0), n, C, _lib.ptr(yv), _lib.ptr(sid), _lib.ptr(acc), _lib.ptr(ws), nws, _lib.stream()), name)
     return acc
 
 
@@ -809,6 +846,13 @@ def nce_block_bwd(fhat: Tensor, t_all: Tensor, diag_off: int, scale: float, Z: T
 _DROPOUT_SEED_DEV: Tensor | None = None
 
 
+def _draw_dropout_seed() -> int:
+    """The per-call 63-bit seed of a fused dropout mask, from torch's HOST generator (``torch.manual_seed`` reproducible).  The mask of
+    element (r, c) is a counter hash of (seed [+ the device-side per-step seed], r * C + c): csrc/bn_common.h.  One function so that
+    the training-parity harness (oracle/training_parity.py) can record the seeds and rebuild the masks for the oracle."""
+    return int(torch.empty((), dtype=torch.int64).random_()) & 0x7FFFFFFFFFFFFFFF
+
+
 def _bn_shape_ok(x: Tensor) -> bool:
     C = x.shape[1]
     return x.is_cuda and C % 4 == 0 and C <= 1024 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
@@ -909,8 +953,8 @@ def _bn_prepare(x: Tensor, bn, p: float, training: bool):
     else:
         mean, var = bn.running_mean, bn.running_var
     drop = p if (training and p > 0) else 0.0
-    seed = int(torch.empty((), dtype=torch.int64).random_()) if drop > 0 else 0  # host generator: torch.manual_seed reproducible
-    return x, mean, var, use_batch, drop, seed & 0x7FFFFFFFFFFFFFFF
+    seed = _draw_dropout_seed() if drop > 0 else 0
+    return x, mean, var, use_batch, drop, seed
 
 
 def bn_act(x: Tensor, bn: "torch.nn.BatchNorm1d", relu: bool = True, p: float = 0.0, training: bool | None = None,
@@ -1135,8 +1179,8 @@ def sync_bn_act(x: Tensor, bn, relu: bool, p: float, training: bool, group=None)
     """Training-mode dropout(relu(bn(x))) with all-rank statistics; returns (y, mean, biased var, total rows) so that the
     module can update its running statistics.  ``bn`` needs weight / bias / eps (dist.SyncBatchNorm1d)."""
     drop = p if (training and p > 0) else 0.0
-    seed = int(torch.empty((), dtype=torch.int64).random_()) if drop > 0 else 0
-    return _SyncBnAct.apply(x, bn.weight, bn.bias, bn.eps, relu, drop, seed & 0x7FFFFFFFFFFFFFFF, group)
+    seed = _draw_dropout_seed() if drop > 0 else 0
+    return _SyncBnAct.apply(x, bn.weight, bn.bias, bn.eps, relu, drop, seed, group)
 
 
 def bn_shape_ok(x: Tensor) -> bool:

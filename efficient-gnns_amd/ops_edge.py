@@ -1,6 +1,8 @@
 """LSP: per-edge similarity + segment softmax loss (kernels in csrc/edge_softmax.hip, csrc/spmm.hip)."""
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import Tensor
 
@@ -121,14 +123,78 @@ class _EdgeSim(torch.autograd.Function):
         return gF, None, None
 
 
+class _LspLoss(torch.autograd.Function):
+    """mean_e criterion(softmax_seg(sim_s), softmax_seg(sim_t)) -- both segment softmaxes, the KL / MSE term and the mean over the
+    edges in one kernel per direction (egnn_lsp_loss_{fwd,bwd}_f32).  No torch reduction is involved: the multi-block form of
+    ``tensor.mean()`` zeroes its semaphores with a memset node, and inside replayed hipGraphs on this stack such a reduction was seen
+    to leave its output unwritten (profiles/r04_lsp_trace.txt: loss_aux kept the stale bytes of an earlier workspace)."""
+
+    @staticmethod
+    def forward(ctx, sim_s, sim_t, seg_ptr, criterion):
+        _lib.require_gpu(sim_s, sim_t, seg_ptr)
+        sim_s, sim_t = sim_s.contiguous(), sim_t.contiguous()
+        E, n_seg = sim_s.numel(), seg_ptr.numel() - 1
+        dev = sim_s.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        if E == 0:     # F.kl_div / F.mse_loss of empty tensors with reduction='mean': nan
+            ctx.empty = True
+            ctx.shapes = (sim_s.shape, sim_t.shape)
+            return loss.fill_(float("nan"))
+        ctx.empty = False
+        lib = _lib.load()
+        p_s, p_t = torch.empty_like(sim_s), torch.empty_like(sim_t)
+        ws = torch.empty(lib.egnn_lsp_loss_ws_floats(), dtype=torch.float32, device=dev)
+        _lib.check(lib.egnn_lsp_loss_fwd_f32(_lib.ptr(seg_ptr), _lib.ptr(sim_s), _lib.ptr(sim_t), n_seg, E, criterion, _lib.ptr(p_s),
+                                             _lib.ptr(p_t), _lib.ptr(loss), _lib.ptr(ws), _lib.stream()), "egnn_lsp_loss_fwd_f32")
+        ctx.save_for_backward(p_s, p_t, seg_ptr)
+        ctx.criterion = criterion
+        if _DEBUG_CHECKS and not torch.cuda.is_current_stream_capturing():
+            _check_lsp_invariants(p_s, p_t, seg_ptr, loss, sim_s, sim_t, criterion)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.empty:
+            return torch.zeros(ctx.shapes[0], device=g.device), None, None, None
+        p_s, p_t, seg_ptr = ctx.saved_tensors
+        E, n_seg = p_s.numel(), seg_ptr.numel() - 1
+        g = g.contiguous().to(torch.float32)
+        gs = torch.empty_like(p_s)
+        gt = torch.empty_like(p_t) if ctx.needs_input_grad[1] else None
+        _lib.check(_lib.load().egnn_lsp_loss_bwd_f32(_lib.ptr(seg_ptr), _lib.ptr(p_s), _lib.ptr(p_t), n_seg, E, ctx.criterion, _lib.ptr(g),
+                                                     _lib.ptr(gs), _lib.ptr(gt), _lib.stream()), "egnn_lsp_loss_bwd_f32")
+        return gs, gt, None, None
+
+
+_DEBUG_CHECKS = os.environ.get("EGNN_DEBUG_CHECKS", "0") == "1"
+
+
+def _check_lsp_invariants(p_s, p_t, seg_ptr, loss, sim_s, sim_t, criterion):
+    """Debug (EGNN_DEBUG_CHECKS=1, eager launches only; host reads): every non-empty segment of both softmaxes sums to 1, and the
+    KL mean respects the bound that holds for ANY finite features when the similarities lie in [lo, hi]:
+    -log p_s <= (hi - lo) + ln(deg), sum_seg p_t = 1  =>  0 <= loss <= (n_seg / E) * ((hi - lo) + ln(max_deg))."""
+    import math
+    n_seg = seg_ptr.numel() - 1
+    deg = seg_ptr[1:] - seg_ptr[:-1]
+    has = deg > 0
+    seg = torch.repeat_interleave(torch.arange(n_seg, device=p_s.device), deg)
+    for name, p in (("p_s", p_s), ("p_t", p_t)):
+        tot = torch.zeros(n_seg, dtype=torch.float64, device=p.device).index_add_(0, seg, p.double())
+        worst = float((tot[has] - 1).abs().max())
+        if not worst <= 1e-4:
+            raise AssertionError(f"lsp_loss: a segment of {name} sums to 1 +- {worst:.3e}")
+    if criterion == 0:
+        span = float(torch.maximum(sim_s.max() - sim_s.min(), sim_t.max() - sim_t.min()))
+        bound = float(has.sum()) / p_s.numel() * (span + math.log(max(int(deg.max()), 1))) + 1e-6
+        val = float(loss)
+        if not (-1e-6 <= val <= bound):
+            raise AssertionError(f"lsp_loss: KL mean {val:.6e} outside [0, {bound:.4f}]")
+
+
 def lsp_loss(feat: Tensor, teacher_feat: Tensor, edge_index: Tensor, kernel: str, criterion: str = "kld") -> Tensor:
     """criterion.py:100-122: softmax over the edges sharing ``dst`` of the per-edge similarity, KL or MSE vs the teacher."""
     n = feat.shape[0]
     plan = edge_plan(edge_index, n)
-    p_s = _SegSoftmax.apply(_EdgeSim.apply(feat, plan, kernel), plan.ptr_b)
-    p_t = _SegSoftmax.apply(_EdgeSim.apply(teacher_feat, plan, kernel), plan.ptr_b)
-    if criterion == "mse":
-        d = p_s - p_t
-        return (d * d).mean()
-    # F.kl_div(log p_s, p_t, reduction='mean'): mean over edges of p_t (log p_t - log p_s), 0 where p_t == 0
-    return torch.nn.functional.kl_div(torch.log(p_s), p_t, log_target=False, reduction="mean")
+    sim_s = _EdgeSim.apply(feat, plan, kernel)
+    sim_t = _EdgeSim.apply(teacher_feat, plan, kernel)
+    return _LspLoss.apply(sim_s, sim_t, plan.ptr_b, 1 if criterion == "mse" else 0)

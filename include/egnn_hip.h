@@ -34,7 +34,7 @@ extern "C" {
 #define EGNN_EWORKSPACE (-3) /* caller-provided workspace too small */
 #define EGNN_EALIGN (-4)   /* pointer / leading dimension not aligned as the entry point requires */
 
-#define EGNN_ABI_VERSION 4
+#define EGNN_ABI_VERSION 5
 int egnn_abi_version(void);
 const char* egnn_error_string(int code);
 /* Number of distinct kernels-families compiled in; used by the loader's self check. */
@@ -361,6 +361,23 @@ int egnn_segment_softmax_fwd_f32(const int64_t* seg_ptr, const float* x, int64_t
 int egnn_segment_softmax_bwd_f32(const int64_t* seg_ptr, const float* p, const float* gp, int64_t n_seg, float* gx, void* stream);
 int egnn_segment_sum_f32(const int64_t* seg_ptr, const float* x, int64_t n_seg, float* out, void* stream);
 
+/* Tail of lpw_criterion (/root/reference/arxiv_pyg/criterion.py:103-122) in one pass per direction: both segment softmaxes of
+ * the student / teacher similarity vectors (same PyG form as above), the element-wise criterion and its mean over the E edges:
+ *   criterion 0 (kld): F.kl_div(log p_s, p_t, reduction='mean') = mean_e p_t (log p_t - log p_s), 0 where p_t == 0   (:118)
+ *   criterion 1 (mse): F.mse_loss(p_s, p_t)                                                                          (:120)
+ * p_s, p_t [E] are written for the backward; loss [1]; ws: egnn_lsp_loss_ws_floats() floats.  Fixed summation order.
+ * bwd: g [1] = dL/dloss on the device; gsim_s [E] = dL/dsim_s; gsim_t [E] nullable (= dL/dsim_t when the teacher side needs one). */
+size_t egnn_lsp_loss_ws_floats(void);
+int egnn_lsp_loss_fwd_f32(const int64_t* seg_ptr, const float* sim_s, const float* sim_t, int64_t n_seg, int64_t E,
+                          int criterion, float* p_s, float* p_t, float* loss, float* ws, void* stream);
+int egnn_lsp_loss_bwd_f32(const int64_t* seg_ptr, const float* p_s, const float* p_t, int64_t n_seg, int64_t E,
+                          int criterion, const float* g, float* gsim_s, float* gsim_t, void* stream);
+
+/* out[c] = sum_r x[r, c] of a row-major [n, C] matrix (leading dimension ld): the bias gradients of GCNConv / nn.Linear
+ * (arxiv_pyg/gnn.py:28-33 modules' `bias`), fixed row stripes + fixed-order finalize.  ws: egnn_colsum_ws_floats(C) floats. */
+size_t egnn_colsum_ws_floats(int64_t C);
+int egnn_colsum_f32(const float* x, int64_t ld, int64_t n, int64_t C, float* out, float* ws, void* stream);
+
 /* GAT attention coefficients (the teacher that the PPI / MAG train loops run inside the student step,
  * /root/reference/ppi_pyg/gnn.py:86-117,208-209; PyG <=1.7 GATConv.message + utils.softmax):
  *   s[e,h]   = leaky_relu(alpha_src[col[e],h] + alpha_dst[row(e),h], negative_slope)          (u_add_v SDDMM)
@@ -477,6 +494,10 @@ int egnn_bn_fold_f32(const float* W, int64_t ldw, int64_t rows, int64_t C, const
 size_t egnn_split_accuracy_ws_ints(void);
 int egnn_split_accuracy_f32(const float* logits, int64_t ld, int64_t n, int64_t C, const int64_t* y, const int8_t* split_id,
                             double* acc3, int32_t* ws, size_t ws_ints, void* stream);
+/* The same pass returning the raw counts: out6 = (hits_train, hits_valid, hits_test, n_train, n_valid, n_test) as doubles -- what
+ * one node-range shard contributes to the all-rank accuracies of test() (summed over ranks by an all-reduce). */
+int egnn_split_counts_f32(const float* logits, int64_t ld, int64_t n, int64_t C, const int64_t* y, const int8_t* split_id,
+                          double* out6, int32_t* ws, size_t ws_ints, void* stream);
 
 /* dst[idx[r], :] += src[r, :], r < n, for UNIQUE ids: the row-compact gradient of x[idx] joins the dense gradient of x
  * (the backward of gnn.py:150 `feat[train_idx]` next to the conv's gradient) without a zero-filled [N,C] temporary. */

@@ -1,0 +1,152 @@
+"""Per-step trace of the LSP (lpw) training path at full size on the GPU, with the criterion's intermediates checked
+against a torch re-computation from the SAME tensors the kernels read.
+
+For each step it prints loss / cls / aux as the step returned them, then (from the tensors ``lsp_loss`` saw)
+  min/max of both similarity vectors, the worst |sum_seg p - 1| of both softmaxes, the loss a torch restatement gives on
+  the same similarities, and the bound 2 + ln(max_deg) the loss cannot exceed for similarities in [-1, 1].
+Environment: MODEL=sage|gcn  KERNEL=rbf|cosine  DROPOUT=0.5  GRAPH=1 (GraphedEpoch replays)  STEPS=30
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import efficient_gnns_amd.data as D
+import efficient_gnns_amd.models as PM
+import efficient_gnns_amd.ops as ops
+import efficient_gnns_amd.ops_edge as OE
+from efficient_gnns_amd.utils import subgraph
+
+steps = int(os.environ.get("STEPS", 30))
+kernel = os.environ.get("KERNEL", "rbf")
+p_drop = float(os.environ.get("DROPOUT", 0.5))
+model_name = os.environ.get("MODEL", "sage")
+graph = os.environ.get("GRAPH", "0") == "1"
+scale = float(os.environ.get("SCALE", 1.0))
+dev = torch.device("cuda:0")
+d = D.arxiv_like(scale=scale, seed=0)
+hp = dict(alpha=0.9, kd_T=4.0, beta=100.0, nce_T=0.075, max_samples=16384, kernel=kernel)
+torch.manual_seed(0)
+np.random.seed(0)
+cls = PM.SAGE if model_name == "sage" else PM.GCN
+m = cls(d.num_features, 256, d.num_classes, 3, p_drop).to(dev)
+A = d.adj_t.to(dev)
+tr = d.split_idx["train"].to(dev)
+ei = subgraph(tr, torch.stack(A.coo()[:2]), relabel_nodes=True, num_nodes=d.num_nodes)[0]
+X, Y, T, TL = d.x.to(dev), d.y.to(dev), ops.pad_pitch(d.teacher_out_feat.to(dev)), d.teacher_logits.to(dev)
+T_sum0 = float(T.double().sum())
+
+seen = {}
+_orig = OE.lsp_loss
+
+
+def traced(feat, teacher_feat, edge_index, kern, criterion="kld"):
+    n = feat.shape[0]
+    plan = OE.edge_plan(edge_index, n)
+    s_s = OE._EdgeSim.apply(feat, plan, kern)
+    s_t = OE._EdgeSim.apply(teacher_feat, plan, kern)
+    p_s = OE._SegSoftmax.apply(s_s, plan.ptr_b)
+    p_t = OE._SegSoftmax.apply(s_t, plan.ptr_b)
+    loss = torch.nn.functional.kl_div(torch.log(p_s), p_t, log_target=False, reduction="mean")
+    seen.update(plan=plan, s_s=s_s.detach(), s_t=s_t.detach(), p_s=p_s.detach(), p_t=p_t.detach(), loss=loss.detach(),
+                feat=feat.detach(), teacher=teacher_feat.detach())
+    return loss
+
+
+def report(step, vals):
+    plan = seen["plan"]
+    seg = plan.b_in_b
+    n = plan.n
+    deg = (plan.ptr_b[1:] - plan.ptr_b[:-1])
+    has = deg > 0
+    out = []
+    for name in ("s", "t"):
+        sim, p = seen["s_" + name], seen["p_" + name]
+        tot = torch.zeros(n, device=dev, dtype=torch.float64).index_add_(0, seg, p.double())
+        out.append(f"{name}: sim[{float(sim.min()):.3e},{float(sim.max()):.3e}] finite={bool(torch.isfinite(sim).all())} "
+                   f"max|sum_seg p-1|={float((tot[has] - 1).abs().max()):.2e} p[min={float(p.min()):.2e}]")
+    # torch restatement on the same similarity vectors (PyG softmax)
+    def soft(x):
+        mx = torch.full((n,), -float("inf"), device=dev).scatter_reduce_(0, seg, x, "amax")
+        e = torch.exp(x - mx[seg])
+        z = torch.zeros(n, device=dev).index_add_(0, seg, e)
+        return e / (z[seg] + 1e-16)
+    ref = torch.nn.functional.kl_div(torch.log(soft(seen["s_s"])), soft(seen["s_t"]), reduction="mean")
+    # and from the features themselves (rbf / cosine), fp64
+    f, t = seen["feat"], seen["teacher"]
+    a, b = plan.a_in_b, plan.b_in_b
+    def sims(F):
+        F = F[:, :750] if F.shape[1] == 752 else F
+        out = torch.empty(a.numel(), device=dev, dtype=torch.float64)
+        for lo in range(0, a.numel(), 1 << 18):
+            fa, fb = F[a[lo:lo + (1 << 18)]].double(), F[b[lo:lo + (1 << 18)]].double()
+            if kernel == "rbf":
+                out[lo:lo + (1 << 18)] = torch.exp(-0.5 * ((fa - fb) ** 2).sum(1))
+            else:
+                out[lo:lo + (1 << 18)] = torch.nn.functional.cosine_similarity(fa, fb)
+        return out
+    ss, st = sims(f), sims(t)
+    dsim = max(float((ss - seen["s_s"].double()).abs().max()), float((st - seen["s_t"].double()).abs().max()))
+    bound = 2 + math.log(max(int(deg.max()), 1))
+    print(f"step {step:2d} loss {vals[0]:.5f} cls {vals[1]:.5f} aux {vals[2]:.4e} | traced aux {float(seen['loss']):.4e} "
+          f"torch-on-sims {float(ref):.4e} sim-err-vs-f64 {dsim:.2e} bound {bound:.2f} | {out[0]} | {out[1]} | "
+          f"teacher-sum-drift {float(T.double().sum()) - T_sum0:.3e} feat-finite {bool(torch.isfinite(f).all())} "
+          f"|feat|max {float(f.abs().max()):.3e}", flush=True)
+
+
+variant = os.environ.get("VARIANT", "refs")
+scal = {}
+
+
+def scalars(feat, teacher_feat, edge_index, kern, criterion="kld"):
+    """The product's op order, no references to the big intermediates kept: only in-graph scalar diagnostics survive."""
+    n = feat.shape[0]
+    plan = OE.edge_plan(edge_index, n)
+    seg = plan.b_in_b
+    def norm_dev(p):
+        tot = torch.zeros(n, device=p.device).index_add_(0, seg, p)
+        return torch.where(plan.ptr_b[1:] > plan.ptr_b[:-1], (tot - 1).abs(), torch.zeros_like(tot)).max()
+    s_s = OE._EdgeSim.apply(feat, plan, kern)
+    p_s = OE._SegSoftmax.apply(s_s, plan.ptr_b)
+    scal["s_s"] = torch.stack([s_s.detach().min(), s_s.detach().max()])
+    s_t = OE._EdgeSim.apply(teacher_feat, plan, kern)
+    p_t = OE._SegSoftmax.apply(s_t, plan.ptr_b)
+    scal["s_t"] = torch.stack([s_t.min(), s_t.max()])
+    scal["dev"] = torch.stack([norm_dev(p_s.detach()), norm_dev(p_t)])
+    del s_s, s_t
+    loss = torch.nn.functional.kl_div(torch.log(p_s), p_t, log_target=False, reduction="mean")
+    scal["loss"] = loss.detach().clone()
+    return loss
+
+
+def report_scalars(step, vals):
+    print(f"step {step:2d} loss {vals[0]:.5f} cls {vals[1]:.5f} aux {vals[2]:.4e} | in-graph aux {float(scal['loss']):.4e} "
+          f"s_s[min,max] {scal['s_s'].tolist()} s_t[min,max] {scal['s_t'].tolist()} max|sum_seg p-1| (s,t) {scal['dev'].tolist()}", flush=True)
+
+
+if variant == "refs":
+    OE.lsp_loss = traced
+elif variant == "scalars":
+    OE.lsp_loss = scalars
+    report = report_scalars
+else:
+    report = lambda step, vals: print(f"step {step:2d} loss {vals[0]:.5f} cls {vals[1]:.5f} aux {vals[2]:.4e}", flush=True)
+print(f"# variant={variant} model={model_name} kernel={kernel} dropout={p_drop} graph={graph} N={d.num_nodes} E_tr={ei.shape[1]} "
+      f"EGNN_LSP_FULL_ROWS={os.environ.get('EGNN_LSP_FULL_ROWS', '1')}", flush=True)
+if graph:
+    opt = torch.optim.Adam(m.parameters(), lr=0.01, fused=True, capturable=True)
+    split = {k: v.to(dev) for k, v in d.split_idx.items()}
+    ge = PM.GraphedEpoch(m, X, A, Y, tr, opt, "lpw", hp, T, TL, None, None, edge_index=ei, split_idx=split, warmup=3)
+    if os.environ.get("SYNC", "0") == "1":
+        torch.cuda.synchronize()
+    for s in range(steps):
+        l, a = ge.step()
+        report(s, l)     # the captured tensors ARE the ones the replay just wrote
+else:
+    opt = torch.optim.Adam(m.parameters(), lr=0.01)
+    for s in range(steps):
+        r = PM.train_step(m, X, A, Y, tr, opt, "lpw", hp, T, TL, None, None, ei)
+        report(s, r)

@@ -1,0 +1,16 @@
+#!/bin/bash
+set +e
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r04/call4; mkdir -p $O
+cd $R
+run() { echo "== $*"; env "$@" timeout 150 python tools/checks/lsp_benchflow.py 2>&1 | grep -E "^#|^step|Error|error" | cut -c1-300; }
+{
+run SW=
+run SW=ownmodel
+run SW=owntrain
+run SW=ownsplit
+run SW=nosplit
+run SW=threads
+} > $O/lsp_benchflow.txt 2>&1
+cat $O/lsp_benchflow.txt
