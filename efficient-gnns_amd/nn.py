@@ -125,7 +125,7 @@ class GCNConv(nn.Module):
             if agg_first:
                 return ops.matmul(edge_index.gcn_normalized().aggregate(x, "sum"), self.weight, self.bias)
             out = edge_index.gcn_normalized().aggregate(ops.matmul(x, self.weight), "sum")
-            return out + self.bias if self.bias is not None else out
+            return ops.add_bias(out, self.bias)
         norm = self._cached_adj_t
         if norm is None:
             if isinstance(edge_index, SparseTensor):
@@ -148,7 +148,7 @@ class GCNConv(nn.Module):
                 with torch.no_grad():
                     self._cached_ax = (key, ops.spmm_raw(norm, x, "sum")[0], x)   # holds x: its address cannot be reused meanwhile
             out = ops.matmul(self._cached_ax[1], self.weight)
-            return out + self.bias if self.bias is not None else out
+            return ops.add_bias(out, self.bias)
         if agg_first:
             return ops.matmul(ops.spmm(norm, x, "sum"), self.weight, self.bias)
         return ops.spmm(norm, ops.matmul(x, self.weight) if xw is None else xw, "sum", bias=self.bias,  # bias added in the kernel's store
@@ -277,7 +277,7 @@ class GATConv(nn.Module):
             ops.spmm_raw(adj.set_value(att[h]), xl[:, h * C:(h + 1) * C], "sum", out=out[:, h * C:(h + 1) * C])
         if not self.concat:
             out = out.view(n, H, C).mean(dim=1)
-        return out + self.bias if self.bias is not None else out
+        return ops.add_bias(out, self.bias)
 
     def __repr__(self):
         return f"GATConv({self.in_channels}, {self.out_channels}, heads={self.heads})"
