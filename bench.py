@@ -12,8 +12,10 @@ One "step" = one epoch of the reference loop /root/reference/arxiv_pyg/gnn.py:33
 beta=0.1, nce_T=0.075, max_samples=16384, proj_dim=256).  Inputs are resident in HBM before timing.
 
 Rank 0 prints ONE JSON line (contract in the task statement) carrying also
-  "roofline":     the SpMM aggregate kernel (K=256 GCN layer) timed with HIP events on its own stream
-                  inside the timed region; achieved = algorithmic bytes / avg launch time
+  "roofline":     the SpMM aggregate kernel (K=256 GCN layer) timed with HIP events on its launch stream; with the epoch
+                  replayed as a hipGraph (default) the timed region has no per-kernel events, so the brackets are taken on
+                  --probe-epochs EAGER epochs of the same problem right after it (over the timed region itself with --graph off);
+                  achieved = algorithmic bytes / avg launch time
   "roofline_mfma": (extra) the G-CRD entry points -- the largest share of the step, matrix-pipe-bound -- timed the same way;
                   achieved = 6 S^2 P flops per step / their time
   "cpu_baseline": the CPU oracle (pure-PyTorch restatement of the reference path) timed on the host cores
@@ -46,7 +48,7 @@ MODE_HP = {"lpw": dict(beta=100.0, kernel="rbf"), "gpw": dict(beta=100.0, kernel
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=200, help="timed epochs (default: a timed region of ~1.4 s)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scale", type=float, default=1.0, help="graph size multiplier (1.0 = ogbn-arxiv shape)")
     ap.add_argument("--max-samples", type=int, default=HP["max_samples"])
@@ -57,6 +59,10 @@ def parse():
     ap.add_argument("--cpu-epochs", type=int, default=10, help="CPU-oracle epochs timed for cpu_baseline (0 = skip)")
     ap.add_argument("--cpu-warmup", type=int, default=3, help="untimed CPU-oracle warm-up epochs (BASELINE.md section 3: >= 3)")
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size GPU-vs-oracle parity step")
+    ap.add_argument("--parity-trajectory-steps", type=int, default=3,
+                    help="replayed steps with dropout 0.5 compared against the oracle with the same masks injected (0 = skip)")
+    ap.add_argument("--repeat-blocks", type=int, default=4,
+                    help="further blocks of --steps replays timed after the contract's block (spread of the measurement; 0 = none)")
     ap.add_argument("--graph", default="on", choices=["on", "off", "auto"],
                     help="on: the epoch (train step + eval) is captured once as a hipGraph and replayed (models.GraphedEpoch) -- a "
                          "capture failure ends the run with a non-zero exit code; off: eager launches; auto: replay if the capture "
@@ -325,7 +331,12 @@ def parity_check(args, data, d, device, hp, PM):
     loss_ok = all(abs(g - c) <= rtol * abs(c) or abs(g - t) <= max(rtol * abs(t), 4.0 * abs(c - t)) for g, c, t in zip(got, ref, ref64))
     ok = bool(loss_ok and logit_err <= PARITY_BARS["logits"] and gworst <= 1.0
               and all(abs(a - b) <= 1e-4 for a, b in zip(accs_p, accs_o)))
-    return dict(ok=ok, what="first train step (dropout 0) + initial eval, GPU path vs CPU oracle, full size, same seeds/draw/weights",
+    traj = None
+    if args.parity_trajectory_steps > 0:
+        traj = trajectory_dropout(args, data, d, device, hp, PM)
+        ok = bool(ok and traj["ok"])
+    return dict(ok=ok, trajectory_dropout=traj,
+                what="first train step (dropout 0) + initial eval, GPU path vs CPU oracle, full size, same seeds/draw/weights",
                 loss=dict(gpu=got[0], cpu=ref[0], cpu_f64=ref64[0]), loss_cls=dict(gpu=got[1], cpu=ref[1], cpu_f64=ref64[1]),
                 loss_aux=dict(gpu=got[2], cpu=ref[2], cpu_f64=ref64[2]),
                 max_rel_err=rel, max_rel_err_vs_f64=rel64, rtol=rtol, losses_ok=loss_ok,
@@ -335,6 +346,29 @@ def parity_check(args, data, d, device, hp, PM):
                            bar=f"per parameter tensor: |gpu - f64| <= {PARITY_BARS['grad_rtol']} |f64| + {PARITY_BARS['grad_atol_over_max']} max|f64|, or "
                                "max|gpu - f64| <= 1.5 max|cpu_f32 - f64| (ReLU-mask flips at full size: bench.grad_errors)"),
                 accs=dict(gpu=[round(a, 6) for a in accs_p], cpu=[round(a, 6) for a in accs_o]))
+
+
+def trajectory_dropout(args, data, d, device, hp, PM):
+    """The regime the benchmark times -- dropout 0.5, hipGraph replays, Adam moving -- against the oracle: the replays' dropout
+    masks (counter hash of the recorded seeds, csrc/bn_common.h) are rebuilt on the host and injected into the oracle's F.dropout
+    (oracle/training_parity.py; gnn.py:48-50), both sides start from the post-warm-up state and make the same np.random draws.
+    Bar: every loss term of every step within 2e-4 (the golden trajectories' bar; GSP 1.5e-3, rbf-LSP 2e-3: differences of nearly
+    equal O(1) sums).  The first replay is launched on an idle device -- the condition under which long torch reductions inside a
+    replay returned stale values (profiles/r04_lsp_trace.txt)."""
+    import efficient_gnns_amd.ops as ops
+    import oracle.training_parity as TP
+    from efficient_gnns_amd.utils import subgraph
+    r = TP.trajectory(PM, ops, data, d, device, args.gnn, args.training, hp, steps=args.parity_trajectory_steps, graph=True,
+                      subgraph_fn=subgraph, hidden=MODEL["hidden"], layers=MODEL["layers"], dropout=MODEL["dropout"], lr=MODEL["lr"],
+                      seed=args.seed + 29, warmup=2, sync_before_first_replay=True)
+    rtol = {"gpw": 1.5e-3, "lpw": 2e-3}.get(args.training, 2e-4)
+    worst = 0.0
+    for g, c in zip(r["got"], r["ref"]):
+        for a, b in zip(g, c):
+            worst = max(worst, abs(a - b) / max(abs(b), 1e-30) if b != 0 else (0.0 if a == 0 else float("inf")))
+    return dict(ok=bool(worst <= rtol and all(np.isfinite(v) for g in r["got"] for v in g)), steps=len(r["got"]), dropout=MODEL["dropout"],
+                launch="hipGraph replays (models.GraphedEpoch), first replay on an idle device", rtol=rtol, max_rel_err=worst,
+                gpu=[[round(v, 6) for v in g] for g in r["got"]], cpu_oracle_same_masks=[[round(v, 6) for v in c] for c in r["ref"]])
 
 
 def local_graph_roofline(args, device, ops):
@@ -536,6 +570,7 @@ def main():
     torch.cuda.synchronize()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     train_ms = eval_ms = 0.0
+    block_ms: list = []
     from efficient_gnns_amd import _lib as _egnn_lib
     if graphed is not None:
         torch.cuda.synchronize()
@@ -544,6 +579,14 @@ def main():
             losses, accs = graphed.step()      # one replay + one device->host read per epoch
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        # the contract's block is the one above; further blocks of the same length show the spread of the measurement
+        for _ in range(args.repeat_blocks):
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(args.steps):
+                graphed.step()
+            torch.cuda.synchronize()
+            block_ms.append((time.perf_counter() - tb) * 1e3 / args.steps)
     # per-kernel brackets (HIP events on the launch stream) need eager launches: with a graph the timed region above has no
     # per-kernel events, so the roofline objects are measured on `probe_epochs` eager epochs of the same problem right after
     # it; without a graph they are measured over the timed region itself
@@ -650,6 +693,7 @@ def main():
                    note="eager launches with per-kernel event brackets (where the roofline objects are measured)"),
         phases_ms=dict(train_step=round(train_ms / max(1, n_probe), 3), eval=round(eval_ms / max(1, n_probe), 3)),
         last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs],
+        repeat_blocks_ms_per_step=[round(v, 3) for v in block_ms],   # further blocks of `steps` replays after the contract's block
     )
     if cpu:
         out["speedup_vs_cpu_baseline"] = round(out["value"] / cpu["value"], 1)

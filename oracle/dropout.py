@@ -17,30 +17,26 @@ import torch
 import torch.nn.functional as F
 
 
-def _mix32(x: np.ndarray) -> np.ndarray:
-    x = x.astype(np.uint32, copy=True)
-    x ^= x >> np.uint32(16)
-    x *= np.uint32(0x7FEB352D)
-    x ^= x >> np.uint32(15)
-    x *= np.uint32(0x846CA68B)
-    x ^= x >> np.uint32(16)
-    return x
+_M32 = 0xFFFFFFFF
+
+
+def _mix32(x: torch.Tensor) -> torch.Tensor:
+    """lowbias32 on int64 tensors holding 32-bit values (products wrap mod 2^64; the low 32 bits are exact)."""
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & _M32
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & _M32
+    return x ^ (x >> 16)
 
 
 def counter_uniform(seed: int, n: int, C: int) -> np.ndarray:
-    """u[r, c] in [0, 1) of element index r * C + c under the 64-bit ``seed`` (bn_common.h ``uniform01``)."""
+    """u[r, c] in [0, 1) of element index r * C + c under the 64-bit ``seed`` (bn_common.h ``uniform01``); float32 [n, C]."""
     seed &= 0xFFFFFFFFFFFFFFFF
-    total = n * C
-    with np.errstate(over="ignore"):
-        if total <= 1 << 32:      # the high half of every index is 0: stay in 32-bit arrays
-            h = _mix32(np.arange(total, dtype=np.uint32) ^ np.uint32(seed & 0xFFFFFFFF))
-            h = _mix32(h + np.uint32(seed >> 32))
-        else:
-            idx = np.arange(total, dtype=np.uint64)
-            lo, hi = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32)
-            h = _mix32(lo ^ np.uint32(seed & 0xFFFFFFFF))
-            h = _mix32(h + np.uint32(seed >> 32) + hi * np.uint32(0x9E3779B9))
-    return ((h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).reshape(n, C)
+    idx = torch.arange(n * C, dtype=torch.int64)
+    lo, hi = idx & _M32, idx >> 32
+    h = _mix32(lo ^ (seed & _M32))
+    h = _mix32((h + (seed >> 32) + ((hi * 0x9E3779B9) & _M32)) & _M32)
+    return ((h >> 8).to(torch.float32) * (1.0 / 16777216.0)).reshape(n, C).numpy()
 
 
 def counter_mask(seed: int, n: int, C: int, p: float) -> torch.Tensor:
