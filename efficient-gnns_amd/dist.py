@@ -581,6 +581,176 @@ class _GatherSampledRows(torch.autograd.Function):
         return g[off:off + n].contiguous(), None, None, None
 
 
+# ------------------------------------------------------------------------------------------------
+# the sampled criteria (G-CRD / GSP) in STATIC shapes: capturable into a hipGraph at any world size
+# ------------------------------------------------------------------------------------------------
+class StaticSample:
+    """The per-step row sample of criterion.py:62-65,134-137 laid out in shapes that do not depend on the draw.
+
+    The draw itself is unchanged: ONE ``np.random.choice(n_train, S, replace=False)`` over the global train list, the same on
+    every rank.  How many of the S rows a rank owns is a hypergeometric count that moves from step to step; here every rank
+    contributes a block of ``cap`` rows (its owned sampled rows first, in draw order, then rows that no consumer reads) to an
+    all-gather, and ``perm`` [S] picks the S valid rows out of the [world * cap] gathered ones IN DRAW ORDER.  cap = the
+    largest rank's expected count + ``sigmas`` standard deviations (never more than that rank owns); a draw that does not fit
+    (probability ~1e-9 per step at 6 sigma) is reported by ``fill`` and the caller runs that step with the dynamic shapes.
+    ``idx`` [m] (m = min(cap, rows this rank owns), fixed): local train positions to form -- the owned sampled rows, then DISTINCT
+    unsampled rows (distinct: the row-gather kernels' backward assumes unique ids; they receive a zero gradient)."""
+
+    def __init__(self, prob: "ShardedProblem", S: int, sigmas: float = 6.0):
+        ntr, world = prob.n_train_global, prob.world
+        self.S, self.world, self.rank = min(int(S), ntr), world, prob.rank
+        per_rank = torch.bincount(prob.train_owner, minlength=world)
+        n_max = int(per_rank.max())
+        p = n_max / max(ntr, 1)
+        # hypergeometric variance <= the binomial's S p (1 - p)
+        cap = int(np.ceil(self.S * p + sigmas * np.sqrt(max(self.S * p * (1.0 - p), 0.0)))) + 1
+        self.cap = max(1, min(cap, n_max, self.S))
+        self.n_mine = int(per_rank[prob.rank])
+        self.m = min(self.cap, self.n_mine)
+        self._owner, self._localpos = prob.train_owner.numpy(), prob.train_localpos.numpy()
+        dev = prob.device
+        self.idx_host = torch.zeros(max(self.m, 1), dtype=torch.int64)
+        self.perm_host = torch.zeros(self.S, dtype=torch.int64)
+        if torch.device(dev).type == "cuda":
+            self.idx_host, self.perm_host = self.idx_host.pin_memory(), self.perm_host.pin_memory()
+        self.idx_dev = torch.zeros(max(self.m, 1), dtype=torch.int64, device=dev)
+        self.perm_dev = torch.zeros(self.S, dtype=torch.int64, device=dev)
+        self.counts = [0] * world
+        self.external = False     # True: somebody else (ShardedGraphedEpoch) draws / fills / uploads before each step
+
+    def draw(self) -> np.ndarray:
+        ntr = self._owner.shape[0]
+        return np.random.choice(ntr, self.S, replace=False) if self.S < ntr else np.arange(ntr)
+
+    def fill(self, pick: np.ndarray) -> bool:
+        """Host side of one step: the padded id list of this rank and the permutation, from the draw.  False = the draw does not
+        fit ``cap`` (nothing is written)."""
+        owner = self._owner[pick]
+        counts = np.bincount(owner, minlength=self.world)
+        if counts.max() > self.cap:
+            return False
+        order = np.argsort(owner, kind="stable")
+        starts = np.cumsum(counts) - counts
+        k = np.empty(self.S, dtype=np.int64)
+        k[order] = np.arange(self.S) - starts[owner[order]]
+        self.perm_host.copy_(torch.from_numpy(owner.astype(np.int64) * self.cap + k))
+        if self.m > 0:
+            mine = self._localpos[pick[owner == self.rank]]
+            taken = np.zeros(self.n_mine, dtype=bool)
+            taken[mine] = True
+            fillers = np.flatnonzero(~taken)[:self.m - mine.shape[0]]
+            self.idx_host.copy_(torch.from_numpy(np.concatenate([mine, fillers]).astype(np.int64)))
+        self.counts = counts.tolist()
+        return True
+
+    def upload(self):
+        self.idx_dev.copy_(self.idx_host, non_blocking=True)
+        self.perm_dev.copy_(self.perm_host, non_blocking=True)
+
+
+class _GatherPadded(torch.autograd.Function):
+    """This rank's block x [m, Q] (zero-padded to [cap, Q]) -> the S sampled rows of ALL ranks in draw order (``perm`` into the
+    [world * cap, Q] all-gather).  backward: the [S, Q] gradient is spread back over the padded layout and -- ``reduce_grad`` --
+    summed over the ranks (each rank evaluated only its row block of the loss: G-CRD), then this rank's block is returned."""
+
+    @staticmethod
+    def forward(ctx, x, perm, cap, rank, world, reduce_grad, group):
+        m, Q = x.shape
+        pad = x.new_zeros(cap, Q)
+        pad[:m].copy_(x)
+        if world > 1:
+            allx = torch.empty(world * cap, Q, dtype=x.dtype, device=x.device)
+            dist.all_gather_into_tensor(allx, pad, group=group)
+        else:
+            allx = pad
+        ctx.save_for_backward(perm)
+        ctx.meta = (m, cap, rank, world, reduce_grad, group)
+        return allx.index_select(0, perm)
+
+    @staticmethod
+    def backward(ctx, g):
+        (perm,) = ctx.saved_tensors
+        m, cap, rank, world, reduce_grad, group = ctx.meta
+        gp = g.new_zeros(world * cap, g.shape[1])
+        gp.index_copy_(0, perm, g.contiguous())                # perm holds unique positions
+        if reduce_grad and world > 1:
+            if dist.get_backend(group) == "nccl":                # every rank only needs ITS block of the sum
+                mine = torch.empty(cap, g.shape[1], dtype=g.dtype, device=g.device)
+                dist.reduce_scatter_tensor(mine, gp, group=group)
+                return mine[:m], None, None, None, None, None, None
+            dist.all_reduce(gp, group=group)
+        return gp[rank * cap:rank * cap + m].contiguous(), None, None, None, None, None, None
+
+
+class _BalancedNCE(torch.autograd.Function):
+    """G-CRD (criterion.py:129-149) on the gathered sample: every rank evaluates rows [r0, r1) = its EVEN share of the S x S
+    problem on the MFMA kernels (fixed shapes: ceil(S / world) rows, diagonal offset r0), whoever owns those rows; the loss terms
+    are all-reduced, the partial gradients (its rows of dfhat, its contribution to every row of dthat) are summed over the
+    ranks by the gather's backward."""
+
+    @staticmethod
+    def forward(ctx, fhat_all, t_all, tau, rank, world, group):
+        fhat_all, t_all = fhat_all.contiguous(), t_all.contiguous()
+        S = fhat_all.shape[0]
+        per = (S + world - 1) // world
+        r0 = min(rank * per, S)
+        r1 = min(r0 + per, S)
+        loss = torch.zeros(1, dtype=torch.float32, device=fhat_all.device)
+        saved = [fhat_all, t_all]
+        if r1 > r0:
+            Z, lse, loss = ops.nce_block_fwd(fhat_all[r0:r1], t_all, r0, tau, 1.0 / S)
+            saved += [Z, lse]
+        if world > 1:
+            dist.all_reduce(loss, group=group)
+        ctx.save_for_backward(*saved)
+        ctx.meta = (tau, r0, r1, S)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        tau, r0, r1, S = ctx.meta
+        saved = ctx.saved_tensors
+        fhat_all, t_all = saved[0], saved[1]
+        df_all = torch.zeros_like(fhat_all)
+        dt_all = torch.zeros_like(t_all)
+        if r1 > r0:
+            df, dt_all = ops.nce_block_bwd(fhat_all[r0:r1], t_all, r0, 1.0 / (S * tau), saved[2], saved[3], g.contiguous().to(torch.float32), tau)
+            df_all[r0:r1].copy_(df)
+        return df_all, dt_all, None, None, None, None
+
+
+def _static_sample_ready(prob: "ShardedProblem") -> bool:
+    """True when this step's sampled criterion runs in the static shapes.  Eager steps make the step's ONE host draw here (the
+    point where the dynamic path makes it) and fall back to the dynamic shapes -- with the same draw -- when it does not fit."""
+    ss = prob.static_sample
+    if ss is None:
+        return False
+    if ss.external:
+        return True
+    pick = ss.draw()
+    if ss.fill(pick):
+        ss.upload()
+        return True
+    prob._forced_pick = pick
+    return False
+
+
+def _static_sampled_pair(prob: "ShardedProblem", f: Tensor, t: Tensor, normalize: bool, reduce_grad: bool):
+    """(student rows, teacher rows) [S, P] of the global sample in draw order, identical on every rank, from this rank's
+    projected train rows f / t -- ONE all-gather of the [cap, Ps + Pt] block."""
+    ss = prob.static_sample
+    idx = ss.idx_dev[:ss.m]
+    if ss.m > 0:
+        fs = ops.gather_normalize(f, idx) if normalize else ops.take_rows(f, idx)
+        ts = ops.gather_normalize(t, idx) if normalize else ops.take_rows(t, idx)
+        block = torch.cat([fs, ts], dim=1)
+    else:   # a rank without train rows: an empty block that stays attached to both heads' graphs
+        block = torch.cat([f[:0], t[:0]], dim=1)
+    both = _GatherPadded.apply(block, ss.perm_dev, ss.cap, prob.rank, prob.world, reduce_grad, prob.group)
+    Ps = f.shape[1]
+    return both[:, :Ps], both[:, Ps:]
+
+
 class _TrainSubgraph:
     """LSP on shards (criterion.py:95-126 over ``subgraph(train_idx, edge_index)``, gnn.py:246-250): this rank's slice of the
     train-node subgraph = the entries (row r, column c) of its own rows with r and c both train nodes.  The softmax groups
@@ -642,6 +812,8 @@ class ShardedProblem:
         self._rows_cpu = ((rowptr[lo:hi + 1] - e0).clone(), col[e0:e1].clone(), data.split_idx["train"].clone())   # for the LSP subgraph plan
         self._train_sub = None
         self.sample_hook = None          # ShardedGraphedEpoch: static device buffer instead of the per-step host draw + upload
+        self.static_sample = None        # StaticSample: the sampled criteria run in draw-independent shapes
+        self._forced_pick = None
         self.x = data.x[lo:hi].to(device)
         self.adj.register_static(self.x)          # input features never change: halo copy fetched once
         self.y = data.y[lo:hi].to(device)
@@ -727,7 +899,10 @@ def _sampled_rows(prob: ShardedProblem, S: int, dev):
     if prob.sample_hook is not None:
         return prob.sample_hook(S)
     ntr = prob.n_train_global
-    pick = np.random.choice(ntr, S, replace=False) if S < ntr else np.arange(ntr)
+    pick = prob._forced_pick                      # a draw already made for this step (StaticSample overflow fallback)
+    prob._forced_pick = None
+    if pick is None:
+        pick = np.random.choice(ntr, S, replace=False) if S < ntr else np.arange(ntr)
     pick_t = torch.from_numpy(pick)
     owner = prob.train_owner[pick_t]
     counts = torch.bincount(owner, minlength=prob.world).tolist()
@@ -792,10 +967,14 @@ def sharded_train_step_tensors(model, prob: ShardedProblem, optimizer, mode: str
         else:
             f = student_proj(take(model.out_feat, prob.train_local))
             t = teacher_proj(take(prob.teacher_out_feat, prob.train_local))
-        idx, counts = _sampled_rows(prob, hp["max_samples"], dev)
-        fhat = ops.gather_normalize(f, idx)
-        that = ops.gather_normalize(t, idx)
-        loss_aux = _DistNCE.apply(fhat, that, hp["nce_T"], counts, prob.rank, group)
+        if _static_sample_ready(prob):
+            fhat_all, t_all = _static_sampled_pair(prob, f, t, normalize=True, reduce_grad=True)
+            loss_aux = _BalancedNCE.apply(fhat_all, t_all, hp["nce_T"], prob.rank, prob.world, group)
+        else:
+            idx, counts = _sampled_rows(prob, hp["max_samples"], dev)
+            fhat = ops.gather_normalize(f, idx)
+            that = ops.gather_normalize(t, idx)
+            loss_aux = _DistNCE.apply(fhat, that, hp["nce_T"], counts, prob.rank, group)
         # loss_aux is already the global value on every rank: scale its gradient contribution once (1/world per rank
         # would double count the all-reduce of parameter grads), so only the local row block's graph carries grad
         loss = loss_cls + hp["beta"] * loss_aux
@@ -810,9 +989,12 @@ def sharded_train_step_tensors(model, prob: ShardedProblem, optimizer, mode: str
         else:
             f = student_proj(take(model.out_feat, prob.train_local))
             t = teacher_proj(take(prob.teacher_out_feat, prob.train_local))
-        idx, counts = _sampled_rows(prob, hp["max_samples"], dev)
-        fs = _GatherSampledRows.apply(f[idx], counts, prob.rank, group)
-        ts = _GatherSampledRows.apply(t[idx], counts, prob.rank, group)
+        if _static_sample_ready(prob):
+            fs, ts = _static_sampled_pair(prob, f, t, normalize=False, reduce_grad=False)
+        else:
+            idx, counts = _sampled_rows(prob, hp["max_samples"], dev)
+            fs = _GatherSampledRows.apply(f[idx], counts, prob.rank, group)
+            ts = _GatherSampledRows.apply(t[idx], counts, prob.rank, group)
         loss_aux = ops_pairwise.gsp_loss(fs, ts, None, hp["kernel"])      # the GLOBAL value on every rank
         loss = loss_cls + hp["beta"] * loss_aux
     elif mode == "lpw":
@@ -870,24 +1052,34 @@ class ShardedGraphedEpoch:
     and replayed -- the sharded counterpart of ``models.GraphedEpoch``: the ~250 launches and ~25 collectives of an epoch are
     enqueued by one call.  RCCL collectives are stream operations and are captured like kernels (all ranks capture and replay
     the same program, see tests/test_dist_gloo.py::test_every_rank_issues_the_same_collective_sequence).
-    Static shapes are required: every mode with ONE rank, and ``kd`` / ``supervised`` / ``lpw`` with any number of ranks.  With
-    several ranks the G-CRD / GSP row sample splits unevenly over the ranks from step to step (a binomial count per rank), so
-    those steps stay eager (``capturable()`` says which).  Host randomness as in the eager step: one np.random.choice per step
-    into a static device buffer, a fresh dropout seed per replay; one device->host read per epoch."""
+    Static shapes are required.  ``kd`` / ``supervised`` / ``lpw`` have them at any world size; the sampled criteria (G-CRD,
+    GSP) get them from ``StaticSample``: fixed-capacity row blocks per rank + a per-step permutation, so the BASELINE metric's
+    own step (GCN + G-CRD) is capturable on every rank count.  A draw that does not fit the capacity (~1e-9 per step) runs
+    that one step with eager launches and dynamic shapes -- every rank sees the same draw and takes the same branch.
+    Host randomness as in the eager step: one np.random.choice per step, a fresh dropout seed per replay; one device->host
+    read per epoch."""
 
     @staticmethod
     def capturable(world: int, mode: str) -> bool:
-        return world == 1 or mode in ("kd", "supervised", "lpw")
+        return mode in ("kd", "supervised", "lpw", "nce", "gpw")
 
-    def __init__(self, model, prob: ShardedProblem, optimizer, mode: str, hp: dict, student_proj=None, teacher_proj=None, warmup: int = 3):
+    def __init__(self, model, prob: ShardedProblem, optimizer, mode: str, hp: dict, student_proj=None, teacher_proj=None, warmup: int = 3,
+                 static_sample: bool | None = None):
         if not prob.x.is_cuda:
             raise ValueError("ShardedGraphedEpoch needs GPU tensors")
         if not self.capturable(prob.world, mode):
-            raise ValueError(f"the sharded '{mode}' step has step-dependent shapes on {prob.world} ranks: not capturable")
+            raise ValueError(f"the sharded '{mode}' step is not capturable")
         self.mode, self.hp, self.prob = mode, hp, prob
+        self._args = (model, prob, optimizer, mode, hp, student_proj, teacher_proj)
         dev = prob.x.device
         S = hp.get("max_samples", 0) if mode in ("nce", "gpw") else 0
         self.n_pick = min(S, prob.n_train_global) if S else 0
+        # one rank owns the whole sample: a static [S] id buffer does (the single-GPU GraphedEpoch's way); several ranks: StaticSample
+        self.static = None
+        if self.n_pick and (prob.world > 1 if static_sample is None else static_sample):
+            self.static = StaticSample(prob, self.n_pick)
+            self.static.external = True
+        self._overflow = None            # the draw of the NEXT step when it does not fit the static capacity
         self._pick_dev = torch.zeros(max(self.n_pick, 1), dtype=torch.int64, device=dev)
         self._pick_host = torch.zeros(max(self.n_pick, 1), dtype=torch.int64).pin_memory()
         self._seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -897,15 +1089,13 @@ class ShardedGraphedEpoch:
             rep = sharded_train_step_tensors(model, prob, optimizer, mode, hp, student_proj, teacher_proj)
             _, correct = sharded_evaluate_tensors(model, prob)
             return rep, correct
-        prev = (prob.sample_hook, ops._DROPOUT_SEED_DEV)
-        prob.sample_hook = lambda S_: (self._pick_dev[:self.n_pick], [self.n_pick])     # one rank owns the whole sample
-        ops._DROPOUT_SEED_DEV = self._seed_dev
-        try:
+        self._body = body
+        with self._installed():
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for i in range(warmup):
-                    self._refresh()
+                    self._refresh(require_fit=True)
                     if i == warmup - 1:   # no long torch reduction may be captured (their memset node: _audit.py); same check on every rank
                         from ._audit import CaptureAudit
                         with CaptureAudit() as audit:
@@ -916,19 +1106,46 @@ class ShardedGraphedEpoch:
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
-            self._refresh()
+            self._refresh(require_fit=True)
             torch.cuda.synchronize(dev)
             # thread-local capture mode: the process group's watchdog thread polls the events of the warm-up collectives; in the
             # default (global) mode a call from ANY thread invalidates the capture (seen: abort in capture_end)
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.rep, self.correct = body()
             torch.cuda.synchronize(dev)
-        finally:
-            prob.sample_hook, ops._DROPOUT_SEED_DEV = prev
         self._refresh()
 
-    def _draw(self):
-        if self.n_pick:
+    class _Install:
+        """The capture hooks (static sample buffers, device-side dropout seed) for the duration of a block."""
+
+        def __init__(self, owner):
+            self.o = owner
+
+        def __enter__(self):
+            o, prob = self.o, self.o.prob
+            self.prev = (prob.sample_hook, prob.static_sample, ops._DROPOUT_SEED_DEV)
+            if o.static is not None:
+                prob.sample_hook, prob.static_sample = None, o.static
+            else:
+                prob.sample_hook = lambda S_: (o._pick_dev[:o.n_pick], [o.n_pick])     # one rank owns the whole sample
+            ops._DROPOUT_SEED_DEV = o._seed_dev
+
+        def __exit__(self, *exc):
+            self.o.prob.sample_hook, self.o.prob.static_sample, ops._DROPOUT_SEED_DEV = self.prev
+
+    def _installed(self):
+        return ShardedGraphedEpoch._Install(self)
+
+    def _draw(self, require_fit: bool = False):
+        self._overflow = None
+        if self.static is not None:
+            pick = self.static.draw()
+            while not self.static.fill(pick):
+                if not require_fit:          # a replay cannot take this draw: step() runs it with eager launches
+                    self._overflow = pick
+                    break
+                pick = self.static.draw()    # warm-up / capture only need SOME sample that fits (their results are discarded)
+        elif self.n_pick:
             ntr = self.prob.n_train_global
             pick = np.random.choice(ntr, self.n_pick, replace=False) if self.n_pick < ntr else np.arange(ntr)
             self._pick_host.copy_(self.prob.train_localpos[torch.from_numpy(pick)])       # one rank: every picked row is local
@@ -936,19 +1153,42 @@ class ShardedGraphedEpoch:
         self._seed_host.bitwise_and_(0x3FFFFFFFFFFFFFFF)
 
     def _upload(self):
-        if self.n_pick:
+        if self.static is not None:
+            if self._overflow is None:
+                self.static.upload()
+        elif self.n_pick:
             self._pick_dev.copy_(self._pick_host, non_blocking=True)
         self._seed_dev.copy_(self._seed_host, non_blocking=True)
 
-    def _refresh(self):
-        self._draw()
+    def _refresh(self, require_fit: bool = False):
+        self._draw(require_fit)
         self._upload()
+
+    def redraw(self):
+        """Discard the randomness prepared for the next step and draw it again (after re-seeding NumPy / torch)."""
+        torch.cuda.current_stream().synchronize()
+        self._refresh()
+
+    def _eager_step(self, pick):
+        """The step whose draw does not fit the static capacity: same program with dynamic shapes and eager launches."""
+        prev = (self.prob.sample_hook, self.prob.static_sample, ops._DROPOUT_SEED_DEV)
+        self.prob.sample_hook, self.prob.static_sample, ops._DROPOUT_SEED_DEV = None, None, self._seed_dev
+        self.prob._forced_pick = pick
+        try:
+            rep, correct = self._body()
+        finally:
+            self.prob.sample_hook, self.prob.static_sample, ops._DROPOUT_SEED_DEV = prev
+        return rep, correct
 
     def step(self):
         """Replay one epoch; returns ((loss, loss_cls, loss_aux), (train, valid, test accuracies))."""
-        self.graph.replay()
+        if self._overflow is not None:
+            rep, correct = self._eager_step(self._overflow)
+        else:
+            self.graph.replay()
+            rep, correct = self.rep, self.correct
         self._draw()                                              # the next step's host draw overlaps the replay
-        vals = torch.cat([self.rep, self.correct]).tolist()       # one device->host read per epoch
+        vals = torch.cat([rep, correct]).tolist()                 # one device->host read per epoch
         self._upload()
         accs = tuple(vals[3 + i] / max(1, self.prob.split_sizes[k]) for i, k in enumerate(("train", "valid", "test")))
         return finish_losses(vals[:3], self.mode, self.hp), accs
@@ -1021,15 +1261,25 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
     graphed, graph_note = None, "eager launches"
     want_graph = getattr(args, "graph", "off") in ("on", "auto") and on_gpu
     if want_graph and ShardedGraphedEpoch.capturable(world, args.training):
+        err = None
         try:
             graphed = ShardedGraphedEpoch(model, prob, opt, args.training, hp, sp, tp, warmup=max(args.warmup, 3))
             graph_note = "hipGraph replay of the sharded train step + eval, collectives captured (dist.ShardedGraphedEpoch)"
         except Exception as e:  # noqa: BLE001
-            graph_note = f"capture of the sharded epoch failed, eager launches: {type(e).__name__}: {str(e)[:200]}"
+            err = f"{type(e).__name__}: {str(e)[:200]}"
+        # every rank must time the SAME collective program: agree on the outcome (a capture that failed on one rank only would
+        # leave it issuing eager warm-up collectives against its peers' replays -- a hang instead of a report)
+        failed = torch.tensor([0.0 if err is None else 1.0], device=device)
+        dist.all_reduce(failed)
+        if float(failed.item()) > 0:
             graphed = None
+            why = err or "capture failed on another rank"
+            if getattr(args, "graph", "off") == "on":    # the headline number is the replayed epoch: never silently time something else
+                raise SystemExit(f"bench.py: hipGraph capture of the sharded epoch failed on {int(failed.item())} of {world} ranks ({why}); "
+                                 f"use --graph auto or --graph off to time eager launches")
+            graph_note = f"capture of the sharded epoch failed, eager launches on every rank: {why}"
     elif want_graph:
-        graph_note = (f"eager launches: the sharded '{args.training}' step has step-dependent shapes on {world} ranks (the row sample splits "
-                      f"unevenly over the ranks), not capturable")
+        graph_note = f"eager launches: the sharded '{args.training}' step is not capturable"
     epoch = graphed.step if graphed is not None else eager_epoch
     if graphed is None:
         for _ in range(args.warmup):

@@ -93,6 +93,7 @@ HP = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=96, kernel="rb
 
 def _reference_run(gnn, mode, steps=3, hp=None):
     HP = dict(globals()["HP"], **(hp or {}))
+    HP.pop("static_sigmas", None)
     import oracle.models as OM
     d = _make_data(train_ids_below=HP.pop("train_ids_below", None))
     torch.manual_seed(0)
@@ -148,6 +149,8 @@ def _worker(rank, world, port, gnn, mode, q, hp=None):
         import efficient_gnns_amd.models as PM
         d = _make_data(train_ids_below=HP.pop("train_ids_below", None))
         prob = DD.ShardedProblem(d, world, rank, "cpu", None, need_gcn=True)
+        if "static_sigmas" in HP:    # the sampled criteria in draw-independent shapes (what ShardedGraphedEpoch captures on > 1 rank)
+            prob.static_sample = DD.StaticSample(prob, HP["max_samples"], sigmas=HP.pop("static_sigmas"))
         torch.manual_seed(0)
         np.random.seed(0)
         model = (PM.GCN if gnn == "gcn" else PM.SAGE)(d.num_features, 32, d.num_classes, 3, 0.0)
@@ -245,6 +248,8 @@ def _trace_worker(rank, world, port, gnn, mode, q, hp=None):
         import efficient_gnns_amd.models as PM
         d = _make_data(train_ids_below=HP.pop("train_ids_below", None))
         prob = DD.ShardedProblem(d, world, rank, "cpu", None, need_gcn=True)
+        if "static_sigmas" in HP:
+            prob.static_sample = DD.StaticSample(prob, HP["max_samples"], sigmas=HP.pop("static_sigmas"))
         torch.manual_seed(0)
         np.random.seed(0)
         model = (PM.GCN if gnn == "gcn" else PM.SAGE)(d.num_features, 32, d.num_classes, 3, 0.5)
@@ -433,3 +438,96 @@ def test_collective_plan_from_local_rows_equals_the_global_plan(world):
         p.join(300)
         assert p.exitcode == 0
     assert all(all(t) for t in got), got
+
+
+def _spawn(target, world, gnn, mode, hp):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, gnn, mode, q, hp)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    return out
+
+
+@pytest.mark.parametrize("gnn,mode,world,max_samples,sigmas", [
+    ("gcn", "nce", 2, 96, 6.0), ("gcn", "nce", 3, 96, 6.0), ("sage", "nce", 2, 96, 6.0), ("gcn", "gpw", 2, 96, 6.0), ("gcn", "gpw", 3, 40, 6.0),
+    ("gcn", "nce", 4, 5, 6.0),        # 5 samples over 4 ranks: row blocks of 2, 2, 1, 0 rows; ranks that own no sampled row
+    ("gcn", "nce", 3, -300, 6.0),     # the last rank owns no train row: an empty block in the all-gather, still every collective
+    ("gcn", "nce", 3, 96, -50.0),     # capacity 1: EVERY draw overflows -> the dynamic-shape fallback with the same draw
+    ("gcn", "gpw", 2, 96, -50.0)])
+def test_static_shape_sampled_criteria_match_the_oracle(gnn, mode, world, max_samples, sigmas):
+    """G-CRD / GSP on shards in the draw-independent layout (dist.StaticSample: fixed-capacity row blocks + per-step permutation,
+    G-CRD as even row blocks of the gathered S x S problem) reproduce the single-process oracle like the dynamic layout does --
+    same np.random draws, 3 optimisation steps.  With a negative sigma the capacity is 1 row and every step takes the overflow
+    fallback."""
+    hp = dict(max_samples=max_samples, static_sigmas=sigmas)
+    if max_samples < 0:
+        hp.update(max_samples=64, train_ids_below=-max_samples)
+    if mode == "gpw":
+        hp.update(kernel="cosine", beta=100.0)
+    losses, logits, accs, n_halo = _spawn(_worker, world, gnn, mode, hp)
+    ref_losses, ref_logits, ref_accs = _reference_run(gnn, mode, hp=hp)
+    np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("gnn,mode,world,max_samples", [("gcn", "nce", 3, 40), ("gcn", "gpw", 2, 40), ("gcn", "nce", 3, -300)])
+def test_static_shape_steps_issue_one_consistent_collective_program(gnn, mode, world, max_samples):
+    """Same property as test_every_rank_issues_the_same_collective_sequence for the static layout, plus what makes it capturable:
+    the sequence AND the sizes are identical from step to step (the dynamic layout's all-gather / all-reduce sizes move with the draw)."""
+    import efficient_gnns_amd.dist as DD
+    hp = dict(max_samples=max_samples, static_sigmas=6.0)
+    if max_samples < 0:
+        hp.update(max_samples=64, train_ids_below=-max_samples)
+    if mode == "gpw":
+        hp.update(kernel="cosine", beta=100.0)
+    everyone = _spawn(_trace_worker, world, gnn, mode, hp)
+    for step in range(3):
+        bad = DD.consistent_collectives([everyone[r][step] for r in range(world)])
+        assert bad is None, f"step {step}: {bad}"
+    for r in range(world):
+        sig = [[(rec[0], rec[1], rec[2]) for rec in everyone[r][step]] for step in range(3)]
+        assert sig[0] == sig[1] == sig[2], f"rank {r}: the collective program changes between steps"
+
+
+def test_static_sample_layout():
+    """StaticSample.fill: the permutation addresses each sampled row at (owner, index within the owner's block) in draw order, the
+    padded id list holds the owned sampled rows first and DISTINCT unsampled rows after them, an oversized draw is refused."""
+    import types
+    import efficient_gnns_amd.dist as DD
+    g = torch.Generator().manual_seed(0)
+    n, world, ntr, S = 1000, 3, 420, 100
+    tr = torch.randperm(n, generator=g)[:ntr]
+    per = (n + world - 1) // world
+    owner = torch.div(tr, per, rounding_mode="floor")
+    samples = []
+    for rank in range(world):
+        mine = owner == rank
+        localpos = torch.zeros_like(tr)
+        localpos[mine] = torch.arange(int(mine.sum()))
+        prob = types.SimpleNamespace(n_train_global=ntr, world=world, rank=rank, train_owner=owner, train_localpos=localpos, device="cpu")
+        samples.append(DD.StaticSample(prob, S))
+    cap = samples[0].cap
+    assert all(s.cap == cap for s in samples) and cap < S
+    np.random.seed(4)
+    pick = samples[0].draw()
+    assert all(s.fill(pick) for s in samples)
+    perm = samples[0].perm_host.numpy()
+    assert all(np.array_equal(s.perm_host.numpy(), perm) for s in samples)
+    assert len(set(perm.tolist())) == S and perm.min() >= 0 and perm.max() < world * cap
+    own = owner.numpy()[pick]
+    for rank, s in enumerate(samples):
+        k = perm[own == rank] - rank * cap
+        assert np.array_equal(k, np.arange(k.size)), "draw order inside the owner's block"
+        idx = s.idx_host.numpy()
+        cnt = int((own == rank).sum())
+        assert s.counts[rank] == cnt and idx.size == s.m
+        assert np.array_equal(idx[:cnt], s._localpos[pick[own == rank]])
+        assert len(set(idx.tolist())) == idx.size and idx.max() < s.n_mine
+    tiny = DD.StaticSample(types.SimpleNamespace(n_train_global=ntr, world=world, rank=0, train_owner=owner,
+                                                 train_localpos=torch.from_numpy(samples[0]._localpos), device="cpu"), S, sigmas=-50.0)
+    assert tiny.cap == 1 and not tiny.fill(pick)

@@ -1410,7 +1410,7 @@ def test_sharded_path_with_one_rank_over_rccl_matches_single_gpu_path(gnn, mode)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("gnn,mode", [("gcn", "nce"), ("sage", "kd"), ("sage", "lpw")])
+@pytest.mark.parametrize("gnn,mode", [("gcn", "nce"), ("sage", "kd"), ("sage", "lpw"), ("gcn", "nce+static"), ("gcn", "gpw+static")])
 def test_sharded_epoch_captured_as_a_graph_replays_the_eager_steps(gnn, mode):
     """dist.ShardedGraphedEpoch (one rank over RCCL): the captured epoch -- collectives included -- reproduces the eager sharded
     steps (same host draw, dropout 0).  Runs in its own interpreter (tools/checks/sharded_graph_check.py), as bench.py does: a
@@ -1419,7 +1419,10 @@ def test_sharded_epoch_captured_as_a_graph_replays_the_eager_steps(gnn, mode):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    p = subprocess.run([sys.executable, os.path.join(root, "tools", "checks", "sharded_graph_check.py"), "--gnn", gnn, "--mode", mode],
+    # "+static": the fixed-capacity sample layout the multi-rank runs capture (dist.StaticSample), exercised on this one rank
+    extra = ["--static"] if mode.endswith("+static") else []
+    mode = mode.split("+")[0]
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "checks", "sharded_graph_check.py"), "--gnn", gnn, "--mode", mode] + extra,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
     assert "SHARDED-GRAPH-OK" in p.stdout

@@ -23,9 +23,11 @@ import efficient_gnns_amd.models as PM  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--gnn", default="gcn")
 ap.add_argument("--mode", default="nce")
+ap.add_argument("--static", action="store_true", help="the fixed-capacity sample layout of the multi-rank runs (dist.StaticSample) on this one rank")
+ap.add_argument("--port", type=int, default=29578)
 a = ap.parse_args()
 gnn, mode, DEV = a.gnn, a.mode, "cuda"
-dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29578", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{a.port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 d = D.arxiv_like(scale=0.02, seed=5)
 hp = dict(alpha=0.9, kd_T=4.0, beta=0.1 if mode == "nce" else 100.0, nce_T=0.075, max_samples=512, kernel="cosine")
 prob = DD.ShardedProblem(d, 1, 0, torch.device(DEV, 0), None, need_gcn=(gnn == "gcn"))
@@ -36,7 +38,7 @@ def build():
     m = DD.swap_batchnorm((PM.GCN if gnn == "gcn" else PM.SAGE)(d.num_features, 64, d.num_classes, 3, 0.0).to(DEV))
     sp = tp = None
     params = list(m.parameters())
-    if mode == "nce":
+    if mode in ("nce", "gpw"):
         sp = DD.swap_batchnorm(PM.make_projection(64, 32).to(DEV))
         tp = DD.swap_batchnorm(PM.make_projection(750, 32).to(DEV))
         params += list(sp.parameters()) + list(tp.parameters())
@@ -53,7 +55,7 @@ for _ in range(3):
     eager.append((l, acc))
 # the graph's constructor runs `warmup` untimed steps on the model: restore the initial state afterwards
 state = [copy.deepcopy(x.state_dict()) if x is not None else None for x in (m2, sp2, tp2)]
-ge = DD.ShardedGraphedEpoch(m2, prob, o2, mode, hp, sp2, tp2, warmup=2)
+ge = DD.ShardedGraphedEpoch(m2, prob, o2, mode, hp, sp2, tp2, warmup=2, static_sample=True if a.static else None)
 for x, st in zip((m2, sp2, tp2), state):
     if x is not None:
         x.load_state_dict(st)
