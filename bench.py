@@ -332,7 +332,7 @@ def parity_check(args, data, d, device, hp, PM):
     ok = bool(loss_ok and logit_err <= PARITY_BARS["logits"] and gworst <= 1.0
               and all(abs(a - b) <= 1e-4 for a, b in zip(accs_p, accs_o)))
     traj = None
-    if args.parity_trajectory_steps > 0:
+    if getattr(args, "parity_trajectory_steps", 0) > 0:
         traj = trajectory_dropout(args, data, d, device, hp, PM)
         ok = bool(ok and traj["ok"])
     return dict(ok=ok, trajectory_dropout=traj,
