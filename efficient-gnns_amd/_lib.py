@@ -90,6 +90,11 @@ SIGNATURES = {
     "egnn_skinny_dx_bn_ws_floats": (_sz, [_i64, _i64]),
     "egnn_skinny_dx_bn_bwd_f32": (_i32, [_p, _i64, _p, _i64, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _f32,
                                          _p, _p, _i32, _f32, _u64, _p, _i32, _p, _p, _p, _i64, _p, _p, _sz, _p]),
+    "egnn_skinny_dx_bn_bwd_reduce_f32": (_i32, [_p, _i64, _p, _i64, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _f32,
+                                                _p, _p, _i32, _f32, _u64, _p, _p, _p, _p, _i64, _p, _sz, _p]),
+    "egnn_bn_bwd_apply_stored_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _p, _f32, _p, _i64, _p, _p,
+                                            _sz, _p]),
+    "egnn_bn_running_update_dev_f32": (_i32, [_p, _p, _i64, _p, _f32, _p, _p, _p, _p]),
     "egnn_bn_running_update_f32": (_i32, [_p, _p, _i64, _i64, _f32, _p, _p, _p, _p]),
     "egnn_split_accuracy_ws_ints": (_sz, []),
     "egnn_split_accuracy_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _sz, _p]),

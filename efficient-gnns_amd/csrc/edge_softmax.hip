@@ -234,39 +234,57 @@ __global__ __launch_bounds__(256) void lsp_loss_bwd_kernel(const int64_t* __rest
   }
 }
 
-// Column sums of a [n, C] matrix: fixed row stripes per block, fixed-order finalize (bias gradients; no torch reduction, see above)
-constexpr int kColsumBlocks = 256;
+// Column sums of a [n, C] matrix: fixed row stripes per block, fixed-order finalize (bias gradients; no torch reduction, see above).
+// HBM-bound streaming read: 256 threads = RPB row lanes x CW column lanes (CW = the power of two >= C, <= 256; wider matrices walk
+// column chunks), four independent row streams per thread, one partial row per block; the finalize gives one wave per column.
+constexpr int kColsumBlocks = 1024;
 
+template <int CW>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int64_t ld, int64_t n, int64_t C,
                                                              float* __restrict__ partials) {
-  // thread -> (row lane r, column c): 256 threads cover rpb rows x cw columns per step
-  const int cw = C >= 256 ? 256 : (C >= 128 ? 128 : (C >= 64 ? 64 : 32));
-  const int rpb = 256 / cw;
-  const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
+  constexpr int RPB = 256 / CW;
+  const int tc = threadIdx.x % CW, tr = threadIdx.x / CW;
   __shared__ float s[256];
-  for (int64_t c0 = 0; c0 < C; c0 += cw) {
+  const int64_t step = (int64_t)gridDim.x * RPB;
+  for (int64_t c0 = 0; c0 < C; c0 += CW) {
     const int64_t c = c0 + tc;
-    float acc = 0.f;
-    if (c < C)
-      for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < n; r += (int64_t)gridDim.x * rpb) acc += x[r * ld + c];
-    s[threadIdx.x] = acc;
-    __syncthreads();
-    if (tr == 0 && c < C) {
-      float t = s[tc];
-      for (int k = 1; k < rpb; ++k) t += s[k * cw + tc];
-      partials[(int64_t)blockIdx.x * C + c] = t;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < C) {
+      const float* col = x + c;
+      int64_t r = (int64_t)blockIdx.x * RPB + tr;
+      for (; r + 3 * step < n; r += 4 * step) {
+        a0 += col[r * ld];
+        a1 += col[(r + step) * ld];
+        a2 += col[(r + 2 * step) * ld];
+        a3 += col[(r + 3 * step) * ld];
+      }
+      for (; r < n; r += step) a0 += col[r * ld];
     }
-    __syncthreads();
+    if constexpr (RPB > 1) {
+      s[threadIdx.x] = (a0 + a1) + (a2 + a3);
+      __syncthreads();
+      if (tr == 0 && c < C) {
+        float t = s[tc];
+#pragma unroll
+        for (int k = 1; k < RPB; ++k) t += s[k * CW + tc];
+        partials[(int64_t)blockIdx.x * C + c] = t;
+      }
+      __syncthreads();
+    } else {
+      if (c < C) partials[(int64_t)blockIdx.x * C + c] = (a0 + a1) + (a2 + a3);
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partials, int nblocks, int64_t C,
-                                                           float* __restrict__ out) {
-  const int64_t c = blockIdx.x * 256LL + threadIdx.x;
+__global__ __launch_bounds__(256) void colsum_wave_final_kernel(const float* __restrict__ partials, int nblocks, int64_t C,
+                                                                float* __restrict__ out) {
+  const int lane = egnn_lane();
+  const int64_t c = (int64_t)blockIdx.x * 4 + egnn_wave_id();
   if (c >= C) return;
   float t = 0.f;
-  for (int b = 0; b < nblocks; ++b) t += partials[(int64_t)b * C + c];
-  out[c] = t;
+  for (int b = lane; b < nblocks; b += 64) t += partials[(int64_t)b * C + c];
+  t = egnn_wave_sum(t);
+  if (lane == 0) out[c] = t;
 }
 
 inline unsigned wave_grid(int64_t n) {
@@ -399,9 +417,16 @@ extern "C" size_t egnn_colsum_ws_floats(int64_t C) { return (size_t)kColsumBlock
 extern "C" int egnn_colsum_f32(const float* x, int64_t ld, int64_t n, int64_t C, float* out, float* ws, void* stream) {
   EGNN_CHECK_ARG(n > 0 && C > 0 && ld >= C && x && out && ws);
   hipStream_t st = (hipStream_t)stream;
-  const int64_t want = (n + 7) / 8;
-  const int nb = (int)(want < kColsumBlocks ? want : kColsumBlocks);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, x, ld, n, C, ws);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, ws, nb, C, out);
+  const int cw = C > 128 ? 256 : (C > 64 ? 128 : (C > 32 ? 64 : 32));
+  const int rpb = 256 / cw;
+  const int64_t want = (n + 4 * rpb - 1) / (4 * rpb);   // >= 4 rows per row lane before another block is worth its partial row
+  const int nb = (int)(want < 1 ? 1 : (want < kColsumBlocks ? want : kColsumBlocks));
+  switch (cw) {
+    case 256: hipLaunchKernelGGL(colsum_partial_kernel<256>, dim3(nb), dim3(256), 0, st, x, ld, n, C, ws); break;
+    case 128: hipLaunchKernelGGL(colsum_partial_kernel<128>, dim3(nb), dim3(256), 0, st, x, ld, n, C, ws); break;
+    case 64: hipLaunchKernelGGL(colsum_partial_kernel<64>, dim3(nb), dim3(256), 0, st, x, ld, n, C, ws); break;
+    default: hipLaunchKernelGGL(colsum_partial_kernel<32>, dim3(nb), dim3(256), 0, st, x, ld, n, C, ws); break;
+  }
+  hipLaunchKernelGGL(colsum_wave_final_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, st, ws, nb, C, out);
   return egnn_launch_status();
 }

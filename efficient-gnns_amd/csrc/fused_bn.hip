@@ -337,6 +337,22 @@ __global__ __launch_bounds__(256) void bn_running_update_kernel(const float* __r
   if (threadIdx.x == 0 && tracked) tracked[0] = t;
 }
 
+// the same update with the row count read from the device (all-rank total of a node-range sharded run: no host read)
+__global__ __launch_bounds__(256) void bn_running_update_dev_kernel(const float* __restrict__ mean, const float* __restrict__ var, int64_t C,
+                                                                    const float* __restrict__ total, float momentum, float* __restrict__ rmean,
+                                                                    float* __restrict__ rvar, long long* __restrict__ tracked) {
+  const long long t = tracked ? tracked[0] + 1 : 1;
+  const float m = momentum < 0.f ? 1.f / (float)t : momentum;
+  const float n = total[0];
+  const float unbias = n > 1.f ? n / (n - 1.f) : 1.f;
+  for (int64_t c = threadIdx.x; c < C; c += 256) {
+    rmean[c] = (1.f - m) * rmean[c] + m * mean[c];
+    rvar[c] = (1.f - m) * rvar[c] + (m * unbias) * var[c];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && tracked) tracked[0] = t;
+}
+
 bool shape_ok(const void* p, int64_t ld, int64_t C) { return C > 0 && C % 4 == 0 && C <= kMaxChunks * 256 && ld % 4 == 0 && egnn_aligned16(p); }
 
 int row_blocks(int64_t n) {
@@ -519,6 +535,14 @@ extern "C" int egnn_bn_running_update_f32(const float* mean, const float* var, i
   EGNN_CHECK_ARG(C > 0 && n > 0 && mean && var && running_mean && running_var);
   const float unbias = n > 1 ? (float)n / (float)(n - 1) : 1.f;
   hipLaunchKernelGGL(bn_running_update_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mean, var, C, unbias, momentum, running_mean,
+                     running_var, (long long*)num_batches_tracked);
+  return egnn_launch_status();
+}
+
+extern "C" int egnn_bn_running_update_dev_f32(const float* mean, const float* var, int64_t C, const float* total_rows, float momentum,
+                                              float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream) {
+  EGNN_CHECK_ARG(C > 0 && mean && var && total_rows && running_mean && running_var);
+  hipLaunchKernelGGL(bn_running_update_dev_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, mean, var, C, total_rows, momentum, running_mean,
                      running_var, (long long*)num_batches_tracked);
   return egnn_launch_status();
 }
@@ -959,12 +983,15 @@ extern "C" size_t egnn_skinny_dx_bn_ws_floats(int64_t M, int64_t C) {
   return a > b ? a : b;
 }
 
-extern "C" int egnn_skinny_dx_bn_bwd_f32(const float* G, int64_t ldg, const float* W, int64_t ldw, int w_kmajor, int64_t M, int64_t C,
-                                         int64_t Ks, float alpha, const float* addend, int64_t ld_addend, const float* add_rows,
-                                         int64_t ld_add_rows, const int32_t* add_inv, const float* x, int64_t ldx, const float* mean,
-                                         const float* var, float eps, const float* gamma, const float* beta, int relu, float p,
-                                         uint64_t seed, const uint64_t* seed_dev, int batch_stats, float* dgamma, float* dbeta, float* dx,
-                                         int64_t ld_dx, float* dx_colsum, float* ws, size_t ws_floats, void* stream) {
+// The tail backward in its two halves, so that a node-range shard can put the all-rank sum of (sum d, sum d xhat) between them
+// (SyncBN, dist.py): `reduce` leaves d = dh * gate in dx and this shard's column sums in dbeta / dgamma; `apply` turns the stored d
+// into dx with whatever sums / 1/count it is handed.  egnn_skinny_dx_bn_bwd_f32 = reduce + apply with the local sums and 1/M.
+extern "C" int egnn_skinny_dx_bn_bwd_reduce_f32(const float* G, int64_t ldg, const float* W, int64_t ldw, int w_kmajor, int64_t M, int64_t C,
+                                                int64_t Ks, float alpha, const float* addend, int64_t ld_addend, const float* add_rows,
+                                                int64_t ld_add_rows, const int32_t* add_inv, const float* x, int64_t ldx, const float* mean,
+                                                const float* var, float eps, const float* gamma, const float* beta, int relu, float p,
+                                                uint64_t seed, const uint64_t* seed_dev, float* dgamma, float* dbeta, float* dx,
+                                                int64_t ld_dx, float* ws, size_t ws_floats, void* stream) {
   EGNN_CHECK_ARG(M > 0 && G && W && x && mean && var && dgamma && dbeta && dx && ws && ldg >= Ks && ldx >= C && ld_dx >= C);
   EGNN_CHECK_ARG((add_inv == nullptr) == (add_rows == nullptr));
   if (Ks > 64 || Ks < 1 || C % 64 != 0 || C < 64 || C > 1024) return EGNN_EALIGN;
@@ -1003,21 +1030,46 @@ extern "C" int egnn_skinny_dx_bn_bwd_f32(const float* G, int64_t ldg, const floa
 #undef EGNN_DX_BN
   }
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)((C + kMergeCols - 1) / kMergeCols)), dim3(256), 0, st, ws, (int)sbs, C, dbeta, dgamma);
-  // dx <- gamma rstd (d - (sum d + xhat sum d xhat) / n), in place over the d the kernel above left in dx
-  const float inv_count = batch_stats ? 1.f / (float)M : 0.f;
+  return egnn_launch_status();
+}
+
+// dx <- gamma rstd (d - (sum_dbeta + xhat sum_dgamma) * inv_count), in place over the d that the reduce half left in dx
+extern "C" int egnn_bn_bwd_apply_stored_f32(const float* x, int64_t ldx, int64_t M, int64_t C, const float* mean, const float* var, float eps,
+                                            const float* gamma, const float* beta, int relu, float p, uint64_t seed, const uint64_t* seed_dev,
+                                            const float* sum_dbeta, const float* sum_dgamma, float inv_count, float* dx, int64_t ld_dx,
+                                            float* dx_colsum, float* ws, size_t ws_floats, void* stream) {
+  EGNN_CHECK_ARG(M > 0 && x && mean && var && sum_dbeta && sum_dgamma && dx && ldx >= C && ld_dx >= C);
+  if (!shape_ok(x, ldx, C) || !shape_ok(dx, ld_dx, C)) return EGNN_EALIGN;
+  if (dx_colsum && (!ws || ws_floats < egnn_bn_ws_floats(C))) return EGNN_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const BnParams q{x, ldx, M, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed, (const unsigned long long*)seed_dev, nullptr};
   int nb = row_blocks(M);
   if (dx_colsum) {
     if (nb > 2 * kStatBlocks) nb = 2 * kStatBlocks;
     nb = (nb + 1) & ~1;
-    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<true, 3>), dim3(nb), dim3(256), 0, st, q, (const float*)dx, ld_dx, dbeta, dgamma, inv_count, dx,
-                       ld_dx, ws);
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<true, 3>), dim3(nb), dim3(256), 0, st, q, (const float*)dx, ld_dx, sum_dbeta, sum_dgamma, inv_count,
+                       dx, ld_dx, ws);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((C + kMergeCols - 1) / kMergeCols)), dim3(256), 0, st, ws, nb / 2, C, dx_colsum,
                        (const float*)nullptr, (const float*)nullptr, 0.f, (const float*)nullptr);
   } else {
-    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<false, 3>), dim3(nb), dim3(256), 0, st, q, (const float*)dx, ld_dx, dbeta, dgamma, inv_count, dx,
-                       ld_dx, (float*)nullptr);
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<false, 3>), dim3(nb), dim3(256), 0, st, q, (const float*)dx, ld_dx, sum_dbeta, sum_dgamma, inv_count,
+                       dx, ld_dx, (float*)nullptr);
   }
   return egnn_launch_status();
+}
+
+extern "C" int egnn_skinny_dx_bn_bwd_f32(const float* G, int64_t ldg, const float* W, int64_t ldw, int w_kmajor, int64_t M, int64_t C,
+                                         int64_t Ks, float alpha, const float* addend, int64_t ld_addend, const float* add_rows,
+                                         int64_t ld_add_rows, const int32_t* add_inv, const float* x, int64_t ldx, const float* mean,
+                                         const float* var, float eps, const float* gamma, const float* beta, int relu, float p,
+                                         uint64_t seed, const uint64_t* seed_dev, int batch_stats, float* dgamma, float* dbeta, float* dx,
+                                         int64_t ld_dx, float* dx_colsum, float* ws, size_t ws_floats, void* stream) {
+  const int rc = egnn_skinny_dx_bn_bwd_reduce_f32(G, ldg, W, ldw, w_kmajor, M, C, Ks, alpha, addend, ld_addend, add_rows, ld_add_rows, add_inv, x,
+                                                  ldx, mean, var, eps, gamma, beta, relu, p, seed, seed_dev, dgamma, dbeta, dx, ld_dx, ws,
+                                                  ws_floats, stream);
+  if (rc != EGNN_OK) return rc;
+  return egnn_bn_bwd_apply_stored_f32(x, ldx, M, C, mean, var, eps, gamma, beta, relu, p, seed, seed_dev, dbeta, dgamma,
+                                      batch_stats ? 1.f / (float)M : 0.f, dx, ld_dx, dx_colsum, ws, ws_floats, stream);
 }
 
 namespace {

@@ -142,9 +142,12 @@ def node_range(n: int, world: int, rank: int):
 _OVERLAP = os.environ.get("EGNN_DIST_OVERLAP", "1") != "0"
 
 
-def _agg(adj, x, addend=None):
-    """Local sum-aggregation of a shard piece (the single-GPU kernels; tests swap in the oracle through ``ops.spmm``)."""
-    return ops.spmm(adj, x, "sum", addend=addend)
+def _agg(adj, x, addend=None, bias=None, relu=False):
+    """Local sum-aggregation of a shard piece (the single-GPU kernels; tests swap in the oracle through ``ops.spmm``).
+    ``bias`` / ``relu``: added / applied in the kernel's store (the LAST piece of a row's sum only); ``relu`` is inference only."""
+    if relu:
+        return ops.spmm_raw(adj, x, "sum", bias=bias, addend=addend, relu=True)[0]
+    return ops.spmm(adj, x, "sum", bias=bias, addend=addend)
 
 
 class ShardPlan:
@@ -273,7 +276,7 @@ class _OverlapAggregate(torch.autograd.Function):
     depend on the graph having interior rows (on a graph without locality there are none)."""
 
     @staticmethod
-    def forward(ctx, x_local, sadj, a_own, a_halo, static_halo):
+    def forward(ctx, x_local, sadj, a_own, a_halo, static_halo, bias=None, relu=False):
         plan, group = sadj.plan, sadj.group
         K = x_local.shape[1]
         work = None
@@ -287,7 +290,8 @@ class _OverlapAggregate(torch.autograd.Function):
         if probe:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
-        y = _agg(a_own, x_local)                                    # runs while the halo rows travel
+        last_is_own = not plan.n_halo                              # bias (+ ReLU) go into the store of the row sums' LAST piece
+        y = _agg(a_own, x_local, bias=bias if last_is_own else None, relu=relu and last_is_own)   # runs while the halo rows travel
         if probe:
             ev[1].record()
         if work is not None:
@@ -296,8 +300,8 @@ class _OverlapAggregate(torch.autograd.Function):
             ev[2].record()
             CommTrace.active.overlap.append(tuple(ev))
         if plan.n_halo:
-            y = _agg(a_halo, x_halo, addend=y)
-        ctx.sadj, ctx.pieces = sadj, (a_own, a_halo)
+            y = _agg(a_halo, x_halo, addend=y, bias=bias, relu=relu)
+        ctx.sadj, ctx.pieces, ctx.has_bias = sadj, (a_own, a_halo), bias is not None
         return y
 
     @staticmethod
@@ -315,7 +319,8 @@ class _OverlapAggregate(torch.autograd.Function):
         work.wait()
         if back.shape[0]:
             g_x = _agg(sadj.scatter, back, addend=g_x)
-        return g_x, None, None, None, None
+        g_b = ops.colsum(g_y) if (ctx.has_bias and ctx.needs_input_grad[5]) else None
+        return g_x, None, None, None, None, g_b, None
 
 
 class ShardedAdj:
@@ -418,17 +423,21 @@ class ShardedAdj:
             self._pieces[key] = (own, halo)
         return self._pieces[key]
 
-    def aggregate(self, x_local: Tensor, reduce: str, valueless: bool = False) -> Tensor:
+    def aggregate(self, x_local: Tensor, reduce: str, valueless: bool = False, bias: Tensor | None = None, relu: bool = False) -> Tensor:
+        """``bias`` [K]: added to every row in the aggregation's store (GCNConv's bias: no separate pass over [n, K]); ``relu``
+        (inference only): clamp in the same store (the eval-mode BatchNorm fold of GCNConv)."""
         if reduce not in ("sum", "add", "mean"):
             raise NotImplementedError(f"sharded aggregation supports sum / mean, not '{reduce}'")
         st = self._static
         static = st is not None and st[0] is x_local and not x_local.requires_grad and x_local._version == st[2]   # version AT registration
         if _OVERLAP:
             own, halo = self._split(reduce == "mean", valueless)
-            return _OverlapAggregate.apply(x_local, self, own, halo, st[1][self.plan.n_local:] if static else None)
+            return _OverlapAggregate.apply(x_local, self, own, halo, st[1][self.plan.n_local:] if static else None, bias, relu)
         x_ext = st[1] if static else _HaloExchange.apply(x_local, self)
         adj = self.raw.set_value(None) if valueless and self.raw.has_value() else self.raw
-        return ops.spmm(adj, x_ext, reduce)
+        if relu:
+            return ops.spmm_raw(adj, x_ext, reduce, bias=bias, relu=True)[0]
+        return ops.spmm(adj, x_ext, reduce, bias=bias)
 
     def halo_fraction(self) -> float:
         return self.plan.n_halo / max(1, self.plan.n - self.plan.n_local)
@@ -490,6 +499,13 @@ class SyncBatchNorm1d(nn.Module):
 
     def _update_running(self, mean, var, n):
         with torch.no_grad():
+            if mean.is_cuda and self.running_mean.dtype == torch.float32 and self.num_batches_tracked.dtype == torch.int64:
+                # one launch (the row count stays on the device) instead of nine element-wise ones
+                lib = _lib.load()
+                _lib.check(lib.egnn_bn_running_update_dev_f32(_lib.ptr(mean), _lib.ptr(var), mean.numel(), _lib.ptr(n), float(self.momentum),
+                                                              _lib.ptr(self.running_mean), _lib.ptr(self.running_var),
+                                                              _lib.ptr(self.num_batches_tracked), _lib.stream()), "egnn_bn_running_update_dev_f32")
+                return
             m = self.momentum
             self.running_mean.mul_(1 - m).add_(mean.detach(), alpha=m)
             self.running_var.mul_(1 - m).add_(var.detach() * (n / (n - 1).clamp(min=1)), alpha=m)
@@ -514,6 +530,18 @@ class SyncBatchNorm1d(nn.Module):
         y, mean, var, n = ops.sync_bn_act(x, self, relu, p, training, self.group)
         self._update_running(mean, var, n)
         return y
+
+    def fused_act_linear(self, x: Tensor, w: Tensor, relu: bool, p: float, training: bool):
+        """(h, h @ w) for h = dropout(relu(self(x)), p) and a narrow ``w`` (the output conv's weight): the students' last hidden layer
+        in one forward pass and a two-half backward around ONE all-reduce (ops.sync_bn_act_linear).  None when not taken."""
+        if not (training and _lib.on_gpu(x)):
+            return None
+        both = ops.sync_bn_act_linear(x, self, w, relu, p, training, self.group)
+        if both is None:
+            return None
+        h, xw, mean, var, n = both
+        self._update_running(mean, var, n)
+        return h, xw
 
 
 # ------------------------------------------------------------------------------------------------

@@ -51,8 +51,10 @@ class _Student(nn.Module):
     def forward(self, x, adj_t):
         n_hidden = len(self.bns)
         for li, (conv, bn) in enumerate(zip(self.convs[:-1], self.bns)):
-            if (_EVAL_BN_FOLD and not self.training and not torch.is_grad_enabled() and isinstance(conv, GCNConv) and type(bn) is nn.BatchNorm1d
-                    and bn.track_running_stats and x.is_cuda and isinstance(adj_t, SparseTensor) and not conv._uses_memoised_input(x)):
+            sharded = hasattr(adj_t, "gcn_normalized") and hasattr(bn, "fused_act")       # node-range shard + dist.SyncBatchNorm1d
+            if (_EVAL_BN_FOLD and not self.training and not torch.is_grad_enabled() and isinstance(conv, GCNConv) and x.is_cuda
+                    and ((type(bn) is nn.BatchNorm1d and bn.track_running_stats and isinstance(adj_t, SparseTensor)) or sharded)
+                    and not conv._uses_memoised_input(x)):
                 # test(): BatchNorm on running statistics folded into the conv's weights, ReLU in the last kernel's store
                 x = self.out_feat = conv(x, adj_t, eval_bn=bn)
                 continue
@@ -66,6 +68,14 @@ class _Student(nn.Module):
                 # last hidden layer: BatchNorm + ReLU + dropout, the gradient tap and the output conv's x @ W as one op, whose
                 # backward is one pass over the [N, hidden] tensors (ops._BnActLinear)
                 both = ops.bn_act_linear(x, bn, self.convs[-1].weight, relu=True, p=self.dropout, training=True)
+                if both is not None:
+                    self.out_feat, xw = both
+                    return self.convs[-1](self.out_feat, adj_t, xw=xw)
+            if (li == n_hidden - 1 and _FUSED_TAIL and self.training and torch.is_grad_enabled() and hasattr(bn, "fused_act_linear")
+                    and isinstance(self.convs[-1], GCNConv) and hasattr(adj_t, "gcn_normalized")
+                    and self.convs[-1].in_channels >= self.convs[-1].out_channels):
+                # the same fused tail on node-range shards: all-rank statistics (dist.SyncBatchNorm1d), one all-reduce in its backward
+                both = bn.fused_act_linear(x, self.convs[-1].weight, True, self.dropout, True)
                 if both is not None:
                     self.out_feat, xw = both
                     return self.convs[-1](self.out_feat, adj_t, xw=xw)

@@ -110,8 +110,14 @@ class GCNConv(nn.Module):
             raise NotImplementedError("GCNConv with edge_weight is not used by the reference")
         agg_first = self.in_channels < self.out_channels
         if eval_bn is not None:
-            if torch.is_grad_enabled() or eval_bn.training or not isinstance(edge_index, SparseTensor) or not x.is_cuda:
-                raise ValueError("eval_bn: inference only (no_grad, BatchNorm in eval mode, SparseTensor adjacency on the GPU)")
+            sharded = hasattr(edge_index, "gcn_normalized")
+            if torch.is_grad_enabled() or eval_bn.training or not (isinstance(edge_index, SparseTensor) or sharded) or not x.is_cuda:
+                raise ValueError("eval_bn: inference only (no_grad, BatchNorm in eval mode, SparseTensor / sharded adjacency on the GPU)")
+            if sharded:   # node-range shard: the same fold, bias + ReLU in the store of the aggregation's last piece
+                w, b = ops.bn_fold(self.weight, self.bias, eval_bn)
+                if agg_first:
+                    return ops.gemm_raw(edge_index.gcn_normalized().aggregate(x, "sum"), w, False, False, b, relu=True)
+                return edge_index.gcn_normalized().aggregate(ops.gemm_raw(x, w), "sum", bias=b, relu=True)
             norm = self._cached_adj_t
             if norm is None:
                 norm = gcn_norm(edge_index)
@@ -124,8 +130,7 @@ class GCNConv(nn.Module):
         if hasattr(edge_index, "gcn_normalized"):  # node-range shard (dist.ShardedAdj): halo exchange + local rows of A^
             if agg_first:
                 return ops.matmul(edge_index.gcn_normalized().aggregate(x, "sum"), self.weight, self.bias)
-            out = edge_index.gcn_normalized().aggregate(ops.matmul(x, self.weight), "sum")
-            return ops.add_bias(out, self.bias)
+            return edge_index.gcn_normalized().aggregate(ops.matmul(x, self.weight) if xw is None else xw, "sum", bias=self.bias)
         norm = self._cached_adj_t
         if norm is None:
             if isinstance(edge_index, SparseTensor):

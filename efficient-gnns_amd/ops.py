@@ -1023,7 +1023,7 @@ class _BnActLinear(torch.autograd.Function):
             xw = gemm_raw(h, w, False, False)
         ctx.save_for_backward(x, gamma, beta, mean, var, h, w)
         ctx.cfg = (float(eps), int(relu), float(p), int(seed), int(batch_stats))
-        ctx.seed_dev, ctx.box = seed_dev, box
+        ctx.seed_dev, ctx.box, ctx.w_index = seed_dev, box, 10
         ctx.set_materialize_grads(False)
         return h, xw
 
@@ -1031,46 +1031,76 @@ class _BnActLinear(torch.autograd.Function):
     def backward(ctx, g_h, g_xw):
         x, gamma, beta, mean, var, h, w = ctx.saved_tensors
         eps, relu, p, seed, batch_stats = ctx.cfg
-        pend = []
-        if ctx.box is not None:
-            pend, ctx.box.pending = ctx.box.pending, []
-        n, C = x.shape
-        Ks = w.shape[1]
-        lib, dev = _lib.load(), x.device
-        gw = None
-        if g_xw is not None:
-            g_xw = _rowmajor(g_xw)
-            if ctx.needs_input_grad[10]:
-                gw = gemm_raw(h, g_xw, True, False)                       # dW = h^T G
-        if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None, None, None, None, None, None, gw, None
-        dx = torch.empty_like(x)
-        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
-        cs = torch.empty(C, dtype=torch.float32, device=dev) if batch_stats else None
-        if g_h is not None:
-            g_h = _rowmajor(g_h.to_dense() if g_h.is_sparse else g_h)
-        fused = (g_xw is not None and len(pend) <= 1 and C % 64 == 0 and Ks <= 64 and x.stride(0) % 4 == 0
-                 and (g_h is None or (g_h.stride(0) % 4 == 0 and g_h.data_ptr() % 16 == 0)))
-        rows = inv = None
-        if fused and pend:
-            idx, rows = pend[0]
-            rows = _rowmajor(rows)
-            fused = rows.stride(0) % 4 == 0 and rows.data_ptr() % 16 == 0 and rows.shape[1] == C
-            if fused:
-                inv = _inverse_rows(idx, n)
+        dx, dgamma, dbeta, gw = _tail_backward(ctx, g_h, g_xw, x, gamma, beta, mean, var, h, w, eps, relu, p, seed, batch_stats, None)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, gw, None
+
+
+def _tail_backward(ctx, g_h, g_xw, x, gamma, beta, mean, var, h, w, eps, relu, p, seed, batch_stats, sync):
+    """Backward of (h, h @ w) = tail(x): dW = h^T G; dh = G w^T (+ tap rows, + dense g_h) through the BatchNorm backward.
+    ``sync`` = None: statistics of this tensor alone (1 / n).  ``sync`` = (total rows [1] on the device, group): the column sums
+    (sum d, sum d xhat) are all-reduced between the reduce half and the apply half (SyncBN on node-range shards); the returned
+    dgamma / dbeta are then this shard's LOCAL sums (the flat gradient all-reduce adds the shards)."""
+    pend = []
+    if ctx.box is not None:
+        pend, ctx.box.pending = ctx.box.pending, []
+    n, C = x.shape
+    Ks = w.shape[1]
+    lib, dev = _lib.load(), x.device
+    gw = None
+    if g_xw is not None:
+        g_xw = _rowmajor(g_xw)
+        if ctx.needs_input_grad[ctx.w_index]:
+            gw = gemm_raw(h, g_xw, True, False) if n > 0 else torch.zeros_like(w)     # dW = h^T G
+    if not ctx.needs_input_grad[0]:
+        return None, None, None, gw
+    dx = torch.empty_like(x)
+    sums = torch.zeros(2 * C, dtype=torch.float32, device=dev)       # [dbeta | dgamma]
+    dbeta, dgamma = sums[:C], sums[C:]
+    cs = torch.empty(C, dtype=torch.float32, device=dev) if (batch_stats and n > 0) else None
+    if g_h is not None:
+        g_h = _rowmajor(g_h.to_dense() if g_h.is_sparse else g_h)
+    fused = (n > 0 and g_xw is not None and len(pend) <= 1 and C % 64 == 0 and Ks <= 64 and x.stride(0) % 4 == 0
+             and (g_h is None or (g_h.stride(0) % 4 == 0 and g_h.data_ptr() % 16 == 0)))
+    rows = inv = None
+    if fused and pend:
+        idx, rows = pend[0]
+        rows = _rowmajor(rows)
+        fused = rows.stride(0) % 4 == 0 and rows.data_ptr() % 16 == 0 and rows.shape[1] == C
         if fused:
-            nws = lib.egnn_skinny_dx_bn_ws_floats(n, C)
-            ws = torch.empty(nws, dtype=torch.float32, device=dev)
-            rc = lib.egnn_skinny_dx_bn_bwd_f32(_lib.ptr(g_xw), g_xw.stride(0), _lib.ptr(w), w.stride(0), 0, n, C, Ks, 1.0,
-                                               _lib.ptr(g_h), 0 if g_h is None else g_h.stride(0), _lib.ptr(rows),
-                                               0 if rows is None else rows.stride(0), _lib.ptr(inv), _lib.ptr(x), x.stride(0), _lib.ptr(mean),
-                                               _lib.ptr(var), eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev),
-                                               batch_stats, _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dx), dx.stride(0), _lib.ptr(cs),
-                                               _lib.ptr(ws), nws, _lib.stream())
-            _lib.check(rc, "egnn_skinny_dx_bn_bwd_f32")
-        else:
-            # the separate passes: dense dh, the tap rows added into it, the BatchNorm backward
+            inv = _inverse_rows(idx, n)
+
+    def apply_sums():
+        """(sum_dbeta, sum_dgamma, inv_count) the apply half uses; the all-rank sum on shards."""
+        if sync is None:
+            return dbeta, dgamma, (1.0 / n if batch_stats else 0.0)
+        import torch.distributed as dist
+        total, group = sync
+        red = sums.clone()
+        dist.all_reduce(red, group=group)
+        red = red / total                                          # scaled on the device (no host read of the row count)
+        return red[:C], red[C:], 1.0
+
+    done = False
+    if fused:
+        nws = lib.egnn_skinny_dx_bn_ws_floats(n, C)
+        ws = torch.empty(nws, dtype=torch.float32, device=dev)
+        rc = lib.egnn_skinny_dx_bn_bwd_reduce_f32(_lib.ptr(g_xw), g_xw.stride(0), _lib.ptr(w), w.stride(0), 0, n, C, Ks, 1.0,
+                                                  _lib.ptr(g_h), 0 if g_h is None else g_h.stride(0), _lib.ptr(rows),
+                                                  0 if rows is None else rows.stride(0), _lib.ptr(inv), _lib.ptr(x), x.stride(0), _lib.ptr(mean),
+                                                  _lib.ptr(var), eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev),
+                                                  _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dx), dx.stride(0), _lib.ptr(ws), nws, _lib.stream())
+        if rc != _lib.EGNN_EALIGN:     # EGNN_EALIGN: beyond the kernel's 32-bit element offsets (n * ld >= 2^31) -> the separate passes below
+            _lib.check(rc, "egnn_skinny_dx_bn_bwd_reduce_f32")
+            sb, sg, inv_count = apply_sums()
+            _lib.check(lib.egnn_bn_bwd_apply_stored_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), eps, _lib.ptr(gamma),
+                                                        _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), _lib.ptr(sb), _lib.ptr(sg),
+                                                        inv_count, _lib.ptr(dx), dx.stride(0), _lib.ptr(cs), _lib.ptr(ws), nws, _lib.stream()),
+                       "egnn_bn_bwd_apply_stored_f32")
+            done = True
+    if not done:
+        # the separate passes: dense dh, the tap rows added into it, the BatchNorm backward (reduce, [all-reduce,] apply)
+        dh = None
+        if n > 0:
             dh = gemm_raw(g_xw, w, False, True) if g_xw is not None else None
             if dh is None:
                 dh = g_h.clone() if g_h is not None else torch.zeros_like(x)
@@ -1082,14 +1112,18 @@ class _BnActLinear(torch.autograd.Function):
                                                  rows.shape[1], _lib.stream()), "egnn_rows_add_f32")
             nws = lib.egnn_bn_ws_floats(C)
             ws = torch.empty(nws, dtype=torch.float32, device=dev)
-            rc = lib.egnn_bn_act_bwd_colsum_f32(_lib.ptr(x), x.stride(0), _lib.ptr(dh), dh.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), eps,
-                                                _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), batch_stats,
-                                                _lib.ptr(dgamma), _lib.ptr(dbeta), _lib.ptr(dx), dx.stride(0), _lib.ptr(cs), _lib.ptr(ws), nws,
-                                                _lib.stream())
-            _lib.check(rc, "egnn_bn_act_bwd_colsum_f32")
-        if cs is not None:
-            dx._egnn_colsum = (cs, dx._version)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, gw, None
+            _lib.check(lib.egnn_bn_act_bwd_reduce_f32(_lib.ptr(x), x.stride(0), _lib.ptr(dh), dh.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var),
+                                                      eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), _lib.ptr(dgamma),
+                                                      _lib.ptr(dbeta), _lib.ptr(ws), nws, _lib.stream()), "egnn_bn_act_bwd_reduce_f32")
+        sb, sg, inv_count = apply_sums()
+        if n > 0:
+            _lib.check(lib.egnn_bn_act_bwd_apply_f32(_lib.ptr(x), x.stride(0), _lib.ptr(dh), dh.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var),
+                                                     eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), _lib.ptr(sb),
+                                                     _lib.ptr(sg), inv_count, _lib.ptr(dx), dx.stride(0), _lib.stream()), "egnn_bn_act_bwd_apply_f32")
+            cs = None            # this route forms no column sums of dx: ops.colsum computes them when a bias gradient asks
+    if cs is not None:
+        dx._egnn_colsum = (cs, dx._version)
+    return dx, dgamma, dbeta, gw
 
 
 def bn_act_linear(x: Tensor, bn: "torch.nn.BatchNorm1d", w: Tensor, relu: bool = True, p: float = 0.0, training: bool | None = None):
@@ -1113,37 +1147,50 @@ def bn_act_linear(x: Tensor, bn: "torch.nn.BatchNorm1d", w: Tensor, relu: bool =
 # ------------------------------------------------------------------------------------------------
 # the same fused BatchNorm + ReLU + dropout with batch statistics that span all ranks (node-range shards)
 # ------------------------------------------------------------------------------------------------
+def _sync_stats(x: Tensor, group):
+    """(mean, biased var, total rows [1]) of the rows of ALL ranks: the per-shard (mean, var, n) triples are all-gathered and merged in
+    rank order (Chan's parallel-variance formula, identical on every rank).  An empty shard contributes n = 0."""
+    import torch.distributed as dist
+    n, C = x.shape
+    lib, dev = _lib.load(), x.device
+    world = dist.get_world_size(group)
+    stats = torch.zeros(2 * C + 1, dtype=torch.float32, device=dev)  # [mean | var | n]
+    if n > 0:
+        nws = lib.egnn_bn_ws_floats(C)
+        ws = torch.empty(nws, dtype=torch.float32, device=dev)
+        _lib.check(lib.egnn_bn_stats_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(stats), _lib.ptr(stats[C:]), _lib.ptr(ws), nws,
+                                         _lib.stream()), "egnn_bn_stats_f32")
+        stats[2 * C:].fill_(float(n))     # a fill kernel, not a host->device copy
+    if world == 1:
+        return stats[:C], stats[C:2 * C], stats[2 * C:]
+    allst = torch.empty(world, 2 * C + 1, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(allst, stats, group=group)
+    merged = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
+    mean, var, total = merged[:C], merged[C:2 * C], merged[2 * C:]
+    _lib.check(lib.egnn_bn_merge_shards_f32(_lib.ptr(allst), world, C, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(total), _lib.stream()),
+               "egnn_bn_merge_shards_f32")
+    return mean, var, total
+
+
 class _SyncBnAct(torch.autograd.Function):
-    """Two small collectives per direction: the per-shard (n, mean, var) triples are all-gathered and merged in rank
-    order (Chan's parallel-variance formula, identical on every rank); the backward all-reduces [sum d, sum d*xhat]."""
+    """Two small collectives per direction: the per-shard (n, mean, var) triples are all-gathered and merged (``_sync_stats``); the
+    backward all-reduces [sum d, sum d*xhat]."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, relu, p, seed, group):
-        import torch.distributed as dist
         x = _rowmajor(x)
         n, C = x.shape
         lib, dev = _lib.load(), x.device
-        world = dist.get_world_size(group)
-        stats = torch.zeros(2 * C + 1, dtype=torch.float32, device=dev)  # [mean | var | n]; an empty shard contributes n = 0
-        if n > 0:
-            nws = lib.egnn_bn_ws_floats(C)
-            ws = torch.empty(nws, dtype=torch.float32, device=dev)
-            _lib.check(lib.egnn_bn_stats_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(stats), _lib.ptr(stats[C:]), _lib.ptr(ws), nws,
-                                             _lib.stream()), "egnn_bn_stats_f32")
-            stats[2 * C:].fill_(float(n))     # a fill kernel, not a host->device copy
-        allst = torch.empty(world, 2 * C + 1, dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(allst, stats, group=group)
-        merged = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
-        mean, var, total = merged[:C], merged[C:2 * C], merged[2 * C:]
-        _lib.check(lib.egnn_bn_merge_shards_f32(_lib.ptr(allst), world, C, _lib.ptr(mean), _lib.ptr(var), _lib.ptr(total), _lib.stream()),
-                   "egnn_bn_merge_shards_f32")
+        mean, var, total = _sync_stats(x, group)
+        seed_dev = _DROPOUT_SEED_DEV if p > 0 else None     # the per-step seed of a replayed graph (fresh masks in every replay)
         y = torch.empty(n, C, dtype=torch.float32, device=dev)
         if n > 0:
             rc = lib.egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
-                                         _lib.ptr(beta), int(relu), float(p), int(seed), None, _lib.ptr(y), y.stride(0), _lib.stream())
+                                         _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(seed_dev), _lib.ptr(y), y.stride(0), _lib.stream())
             _lib.check(rc, "egnn_bn_act_fwd_f32")
         ctx.save_for_backward(x, gamma, beta, mean, var, total)
         ctx.cfg = (float(eps), int(relu), float(p), int(seed), group)
+        ctx.seed_dev = seed_dev
         ctx.mark_non_differentiable(mean, var, total)
         return y, mean, var, total
 
@@ -1160,8 +1207,8 @@ class _SyncBnAct(torch.autograd.Function):
             nws = lib.egnn_bn_ws_floats(C)
             ws = torch.empty(nws, dtype=torch.float32, device=dev)
             rc = lib.egnn_bn_act_bwd_reduce_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var),
-                                                eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, None, _lib.ptr(sums[C:]), _lib.ptr(sums),
-                                                _lib.ptr(ws), nws, _lib.stream())
+                                                eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), _lib.ptr(sums[C:]),
+                                                _lib.ptr(sums), _lib.ptr(ws), nws, _lib.stream())
             _lib.check(rc, "egnn_bn_act_bwd_reduce_f32")
         local = sums.clone()                                          # parameter grads stay local (the flat all-reduce sums them)
         dist.all_reduce(sums, group=group)
@@ -1169,8 +1216,8 @@ class _SyncBnAct(torch.autograd.Function):
         dx = torch.empty_like(x)
         if n > 0:
             rc = lib.egnn_bn_act_bwd_apply_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var),
-                                               eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, None, _lib.ptr(sums), _lib.ptr(sums[C:]),
-                                               1.0, _lib.ptr(dx), dx.stride(0), _lib.stream())
+                                               eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), _lib.ptr(sums),
+                                               _lib.ptr(sums[C:]), 1.0, _lib.ptr(dx), dx.stride(0), _lib.stream())
             _lib.check(rc, "egnn_bn_act_bwd_apply_f32")
         return dx, local[C:], local[:C], None, None, None, None, None
 
@@ -1181,6 +1228,63 @@ def sync_bn_act(x: Tensor, bn, relu: bool, p: float, training: bool, group=None)
     drop = p if (training and p > 0) else 0.0
     seed = _draw_dropout_seed() if drop > 0 else 0
     return _SyncBnAct.apply(x, bn.weight, bn.bias, bn.eps, relu, drop, seed, group)
+
+
+class _SyncBnActLinear(torch.autograd.Function):
+    """``_BnActLinear`` with all-rank batch statistics: (h, h @ w, mean, var, total) for h = drop(relu(bn(x))) on a node-range shard.
+    Forward: statistics all-gather, then the one-pass tail kernel; backward: the tail's reduce half, ONE all-reduce of
+    [sum d | sum d xhat], the apply half (egnn_skinny_dx_bn_bwd_reduce_f32 / egnn_bn_bwd_apply_stored_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu, p, seed, w, box, group):
+        x = _rowmajor(x)
+        n, C = x.shape
+        lib, dev = _lib.load(), x.device
+        mean, var, total = _sync_stats(x, group)
+        seed_dev = _DROPOUT_SEED_DEV if p > 0 else None
+        w = _rowmajor(w)
+        h = torch.empty(n, C, dtype=torch.float32, device=dev)
+        xw = torch.empty(n, w.shape[1], dtype=torch.float32, device=dev)
+        if n > 0:
+            rc = _lib.EGNN_EALIGN
+            if w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0:
+                rc = lib.egnn_bn_act_linear_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
+                                                    _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(seed_dev), _lib.ptr(w), w.stride(0), 0,
+                                                    w.shape[1], _lib.ptr(h), h.stride(0), _lib.ptr(xw), xw.stride(0), _lib.stream())
+                if rc != _lib.EGNN_EALIGN:
+                    _lib.check(rc, "egnn_bn_act_linear_fwd_f32")
+            if rc == _lib.EGNN_EALIGN:
+                _lib.check(lib.egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
+                                                   _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(seed_dev), _lib.ptr(h), h.stride(0),
+                                                   _lib.stream()), "egnn_bn_act_fwd_f32")
+                xw = gemm_raw(h, w, False, False)
+        ctx.save_for_backward(x, gamma, beta, mean, var, h, w, total)
+        ctx.cfg = (float(eps), int(relu), float(p), int(seed), group)
+        ctx.seed_dev, ctx.box, ctx.w_index = seed_dev, box, 7
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(mean, var, total)
+        return h, xw, mean, var, total
+
+    @staticmethod
+    def backward(ctx, g_h, g_xw, _gm, _gv, _gt):
+        x, gamma, beta, mean, var, h, w, total = ctx.saved_tensors
+        eps, relu, p, seed, group = ctx.cfg
+        dx, dgamma, dbeta, gw = _tail_backward(ctx, g_h, g_xw, x, gamma, beta, mean, var, h, w, eps, relu, p, seed, 1, (total, group))
+        return dx, dgamma, dbeta, None, None, None, None, gw, None, None
+
+
+def sync_bn_act_linear(x: Tensor, bn, w: Tensor, relu: bool, p: float, training: bool, group=None):
+    """(h, h @ w, mean, var, total) -- ``bn_act_linear`` with all-rank statistics (dist.SyncBatchNorm1d.fused_act_linear); None when
+    the fused kernels do not take the shape."""
+    if not (training and torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and w.dim() == 2 and w.shape[0] == x.shape[1]
+            and w.shape[1] <= 64 and x.shape[1] % 64 == 0 and _bn_shape_ok(_rowmajor(x))):
+        return None
+    drop = p if p > 0 else 0.0
+    seed = _draw_dropout_seed() if drop > 0 else 0
+    box = _TapBox()
+    h, xw, mean, var, total = _SyncBnActLinear.apply(x, bn.weight, bn.bias, bn.eps, relu, drop, seed, w, box, group)
+    h._egnn_tap = box
+    return h, xw, mean, var, total
 
 
 def bn_shape_ok(x: Tensor) -> bool:

@@ -473,12 +473,30 @@ int egnn_skinny_dx_bn_bwd_f32(const float* G, int64_t ldg, const float* W, int64
                               const float* gamma, const float* beta, int relu, float p, uint64_t seed, const uint64_t* seed_dev,
                               int batch_stats, float* dgamma, float* dbeta, float* dx, int64_t ld_dx, float* dx_colsum, float* ws,
                               size_t ws_floats, void* stream);
+/* The same backward in its two halves, for BatchNorm statistics that span several node-range shards (SyncBN semantics):
+ * `reduce` leaves d = dh * gate in dx and THIS shard's (sum d, sum d xhat) in dbeta / dgamma; the caller all-reduces them; `apply` then
+ * turns the stored d into dx = gamma rstd (d - (sum_dbeta + xhat sum_dgamma) inv_count) in place (dx_colsum nullable: column sums of dx,
+ * ws of egnn_bn_ws_floats(C) floats then).  egnn_skinny_dx_bn_bwd_f32 = reduce + apply with the local sums and inv_count = 1 / M. */
+int egnn_skinny_dx_bn_bwd_reduce_f32(const float* G, int64_t ldg, const float* W, int64_t ldw, int w_kmajor, int64_t M, int64_t C,
+                                     int64_t Ks, float alpha, const float* addend, int64_t ld_addend, const float* add_rows,
+                                     int64_t ld_add_rows, const int32_t* add_inv, const float* x, int64_t ldx, const float* mean,
+                                     const float* var, float eps, const float* gamma, const float* beta, int relu, float p, uint64_t seed,
+                                     const uint64_t* seed_dev, float* dgamma, float* dbeta, float* dx, int64_t ld_dx, float* ws,
+                                     size_t ws_floats, void* stream);
+int egnn_bn_bwd_apply_stored_f32(const float* x, int64_t ldx, int64_t M, int64_t C, const float* mean, const float* var, float eps,
+                                 const float* gamma, const float* beta, int relu, float p, uint64_t seed, const uint64_t* seed_dev,
+                                 const float* sum_dbeta, const float* sum_dgamma, float inv_count, float* dx, int64_t ld_dx,
+                                 float* dx_colsum, float* ws, size_t ws_floats, void* stream);
 
 /* nn.BatchNorm1d's training-step state update in one launch (torch/nn/modules/batchnorm.py: num_batches_tracked += 1,
  * running = (1 - m) running + m stat with the unbiased variance n/(n-1) var):  mean / var [C] = this batch's statistics,
  * momentum < 0 = cumulative average (momentum=None); num_batches_tracked: nullable device int64. */
 int egnn_bn_running_update_f32(const float* mean, const float* var, int64_t C, int64_t n, float momentum, float* running_mean,
                                float* running_var, int64_t* num_batches_tracked, void* stream);
+/* The same update with the row count read from device memory (total_rows [1], float): the all-rank row total of a node-range
+ * sharded run (SyncBN) never visits the host. */
+int egnn_bn_running_update_dev_f32(const float* mean, const float* var, int64_t C, const float* total_rows, float momentum,
+                                   float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream);
 
 /* Eval-mode BatchNorm1d folded into the layer in front of it (model.eval(): y = (x W + b - running_mean) * gamma /
  * sqrt(running_var + eps) + beta, gnn.py:47-49,198-201):  W_out[i,c] = W[i,c] * s_c,  bias_out[c] = (bias[c] - mean[c]) * s_c
