@@ -94,6 +94,8 @@ SIGNATURES = {
                                                 _p, _p, _i32, _f32, _u64, _p, _p, _p, _p, _i64, _p, _sz, _p]),
     "egnn_bn_bwd_apply_stored_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _p, _f32, _p, _i64, _p, _p,
                                             _sz, _p]),
+    "egnn_bn_act_bwd_apply_colsum_f32": (_i32, [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _p, _f32, _p, _i64,
+                                                _p, _p, _sz, _p]),
     "egnn_bn_running_update_dev_f32": (_i32, [_p, _p, _i64, _p, _f32, _p, _p, _p, _p]),
     "egnn_bn_running_update_f32": (_i32, [_p, _p, _i64, _i64, _f32, _p, _p, _p, _p]),
     "egnn_split_accuracy_ws_ints": (_sz, []),

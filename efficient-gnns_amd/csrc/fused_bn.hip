@@ -446,6 +446,27 @@ extern "C" int egnn_bn_act_bwd_apply_f32(const float* x, int64_t ld, const float
   return egnn_launch_status();
 }
 
+// the apply half with the column sums of dx formed on the way (the bias gradient of the layer in front), for callers that put an
+// all-rank reduction of the sums between the halves (SyncBN): ws of egnn_bn_ws_floats(C) floats
+extern "C" int egnn_bn_act_bwd_apply_colsum_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
+                                                const float* mean, const float* var, float eps, const float* gamma, const float* beta,
+                                                int relu, float p, uint64_t seed, const uint64_t* seed_dev, const float* sum_dbeta,
+                                                const float* sum_dgamma, float inv_count, float* dx, int64_t ld_dx, float* dx_colsum,
+                                                float* ws, size_t ws_floats, void* stream) {
+  EGNN_CHECK_ARG(n > 0 && x && dy && mean && var && sum_dbeta && sum_dgamma && dx && dx_colsum && ws && ld >= C && ld_dy >= C && ld_dx >= C);
+  if (!shape_ok(x, ld, C) || !shape_ok(dy, ld_dy, C) || !shape_ok(dx, ld_dx, C)) return EGNN_EALIGN;
+  if (ws_floats < egnn_bn_ws_floats(C)) return EGNN_EWORKSPACE;
+  const BnParams q{x, ld, n, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed, (const unsigned long long*)seed_dev, nullptr};
+  int nb = row_blocks(n);
+  if (nb > 2 * kStatBlocks) nb = 2 * kStatBlocks;
+  nb = (nb + 1) & ~1;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_act_bwd_apply_kernel<true>, dim3(nb), dim3(256), 0, st, q, dy, ld_dy, sum_dbeta, sum_dgamma, inv_count, dx, ld_dx, ws);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((C + kMergeCols - 1) / kMergeCols)), dim3(256), 0, st, ws, nb / 2, C, dx_colsum,
+                     (const float*)nullptr, (const float*)nullptr, 0.f, (const float*)nullptr);
+  return egnn_launch_status();
+}
+
 extern "C" int egnn_bn_act_bwd_colsum_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
                                           const float* mean, const float* var, float eps, const float* gamma, const float* beta, int relu,
                                           float p, uint64_t seed, const uint64_t* seed_dev, int batch_stats, float* dgamma, float* dbeta,

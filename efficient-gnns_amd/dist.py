@@ -887,28 +887,40 @@ def allreduce_grads(params, group=None):
 
 
 class FlatGrads:
-    """All parameter gradients as views of ONE buffer: the per-step gradient exchange is a single all-reduce with no
-    concatenation / scatter copies (about forty small launches per step otherwise -- the 8-rank step is launch-bound), and
-    zeroing the gradients is one fill.  Autograd accumulates in place into the views."""
+    """All parameter gradients in ONE buffer: the per-step gradient exchange is a single all-reduce.  ``loss.backward()`` runs with
+    the parameters' ``.grad`` unset (each gradient is then assigned, not accumulated: no zero fill, no add per parameter);
+    ``gather`` copies them into the buffer with one batched copy, and after the all-reduce ``.grad`` are views of the buffer
+    (what the optimizer reads)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else "cpu"
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        off = 0
+        self.views, off = [], 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
     def intact(self) -> bool:
-        return all(p.grad is not None and p.grad.data_ptr() >= self.flat.data_ptr()
-                   and p.grad.data_ptr() < self.flat.data_ptr() + max(self.flat.numel(), 1) * 4 for p in self.params)
+        return True
 
     def zero(self):
-        self.flat.zero_()
+        """Before ``backward``: unset the gradients (no kernel)."""
+        for p in self.params:
+            p.grad = None
+
+    def gather(self):
+        """After ``backward``: one batched copy of all gradients into the flat buffer (a parameter without gradient counts as 0)."""
+        if not self.params:
+            return
+        pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        torch.cat(pieces, out=self.flat)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def all_reduce(self, group=None):
+        self.gather()
         dist.all_reduce(self.flat, group=group)
 
 

@@ -1054,7 +1054,9 @@ def _tail_backward(ctx, g_h, g_xw, x, gamma, beta, mean, var, h, w, eps, relu, p
     if not ctx.needs_input_grad[0]:
         return None, None, None, gw
     dx = torch.empty_like(x)
-    sums = torch.zeros(2 * C, dtype=torch.float32, device=dev)       # [dbeta | dgamma]
+    sums = torch.empty(2 * C, dtype=torch.float32, device=dev)       # [dbeta | dgamma]; written by the reduce half (zeroed on an empty shard)
+    if n == 0:
+        sums.zero_()
     dbeta, dgamma = sums[:C], sums[C:]
     cs = torch.empty(C, dtype=torch.float32, device=dev) if (batch_stats and n > 0) else None
     if g_h is not None:
@@ -1075,8 +1077,10 @@ def _tail_backward(ctx, g_h, g_xw, x, gamma, beta, mean, var, h, w, eps, relu, p
             return dbeta, dgamma, (1.0 / n if batch_stats else 0.0)
         import torch.distributed as dist
         total, group = sync
-        red = sums.clone()
-        dist.all_reduce(red, group=group)
+        red = sums
+        if dist.get_world_size(group) > 1:
+            red = sums.clone()
+            dist.all_reduce(red, group=group)
         red = red / total                                          # scaled on the device (no host read of the row count)
         return red[:C], red[C:], 1.0
 
@@ -1154,8 +1158,10 @@ def _sync_stats(x: Tensor, group):
     n, C = x.shape
     lib, dev = _lib.load(), x.device
     world = dist.get_world_size(group)
-    stats = torch.zeros(2 * C + 1, dtype=torch.float32, device=dev)  # [mean | var | n]
-    if n > 0:
+    stats = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)  # [mean | var | n]
+    if n == 0:
+        stats.zero_()
+    else:
         nws = lib.egnn_bn_ws_floats(C)
         ws = torch.empty(nws, dtype=torch.float32, device=dev)
         _lib.check(lib.egnn_bn_stats_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(stats), _lib.ptr(stats[C:]), _lib.ptr(ws), nws,
@@ -1202,7 +1208,8 @@ class _SyncBnAct(torch.autograd.Function):
         gy = _rowmajor(gy)
         n, C = x.shape
         lib, dev = _lib.load(), x.device
-        sums = torch.zeros(2 * C, dtype=torch.float32, device=dev)   # [dbeta | dgamma] of this shard
+        sums = torch.empty(2 * C, dtype=torch.float32, device=dev)   # [dbeta | dgamma] of this shard
+        ws = None
         if n > 0:
             nws = lib.egnn_bn_ws_floats(C)
             ws = torch.empty(nws, dtype=torch.float32, device=dev)
@@ -1210,15 +1217,23 @@ class _SyncBnAct(torch.autograd.Function):
                                                 eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), _lib.ptr(sums[C:]),
                                                 _lib.ptr(sums), _lib.ptr(ws), nws, _lib.stream())
             _lib.check(rc, "egnn_bn_act_bwd_reduce_f32")
-        local = sums.clone()                                          # parameter grads stay local (the flat all-reduce sums them)
-        dist.all_reduce(sums, group=group)
-        sums = sums / total                                          # scaled on the device (no host read of the row count)
+        else:
+            sums.zero_()
+        local = sums                                                 # parameter grads stay local (the flat all-reduce sums them)
+        if dist.get_world_size(group) > 1:
+            sums = sums.clone()
+            dist.all_reduce(sums, group=group)
+        scaled = sums / total                                        # scaled on the device (no host read of the row count)
         dx = torch.empty_like(x)
         if n > 0:
-            rc = lib.egnn_bn_act_bwd_apply_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var),
-                                               eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), _lib.ptr(sums),
-                                               _lib.ptr(sums[C:]), 1.0, _lib.ptr(dx), dx.stride(0), _lib.stream())
-            _lib.check(rc, "egnn_bn_act_bwd_apply_f32")
+            # the column sums of dx (bias gradient of the conv / Linear in front) come out of the same pass (ops.colsum picks the tag up)
+            cs = torch.empty(C, dtype=torch.float32, device=dev)
+            rc = lib.egnn_bn_act_bwd_apply_colsum_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var),
+                                                      eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), _lib.ptr(scaled),
+                                                      _lib.ptr(scaled[C:]), 1.0, _lib.ptr(dx), dx.stride(0), _lib.ptr(cs), _lib.ptr(ws), nws,
+                                                      _lib.stream())
+            _lib.check(rc, "egnn_bn_act_bwd_apply_colsum_f32")
+            dx._egnn_colsum = (cs, dx._version)
         return dx, local[C:], local[:C], None, None, None, None, None
 
 

@@ -429,6 +429,12 @@ int egnn_bn_act_bwd_apply_f32(const float* x, int64_t ld, const float* dy, int64
                               const float* mean, const float* var, float eps, const float* gamma, const float* beta, int relu,
                               float p, uint64_t seed, const uint64_t* seed_dev, const float* sum_dbeta, const float* sum_dgamma,
                               float inv_count, float* dx, int64_t ld_dx, void* stream);
+/* The apply half that also returns the column sums of dx (dx_colsum [C]: the bias gradient of the layer in front of the BatchNorm);
+ * ws: egnn_bn_ws_floats(C) floats. */
+int egnn_bn_act_bwd_apply_colsum_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,
+                                     const float* mean, const float* var, float eps, const float* gamma, const float* beta, int relu,
+                                     float p, uint64_t seed, const uint64_t* seed_dev, const float* sum_dbeta, const float* sum_dgamma,
+                                     float inv_count, float* dx, int64_t ld_dx, float* dx_colsum, float* ws, size_t ws_floats, void* stream);
 
 /* egnn_bn_act_bwd_f32 that also leaves dx_colsum[c] = sum over rows of dx[:,c] (nullable): the gradient of a bias added in
  * front of the BatchNorm (GCNConv / nn.Linear bias, /root/reference/arxiv_pyg/gnn.py:47-48,296-306), formed while dx is
