@@ -583,11 +583,11 @@ class _DistNCE(torch.autograd.Function):
         saved = ctx.saved_tensors
         fhat, t_all = saved[0], saved[1]
         Sr, P = fhat.shape
-        dt_all = torch.zeros_like(t_all)
-        df = torch.zeros_like(fhat)
         if Sr > 0:
             Z, lse = saved[2], saved[3]
             df, dt_all = ops.nce_block_bwd(fhat, t_all, off, 1.0 / (S * tau), Z, lse, g.contiguous().to(torch.float32), tau)
+        else:   # no row block here: zeros that still take part in the collective
+            dt_all, df = torch.zeros_like(t_all), torch.zeros_like(fhat)
         dist.all_reduce(dt_all, group=group)  # every row block contributes to every teacher row
         return df, dt_all[off:off + Sr].contiguous(), None, None, None, None
 
@@ -740,10 +740,11 @@ class _BalancedNCE(torch.autograd.Function):
         saved = ctx.saved_tensors
         fhat_all, t_all = saved[0], saved[1]
         df_all = torch.zeros_like(fhat_all)
-        dt_all = torch.zeros_like(t_all)
         if r1 > r0:
             df, dt_all = ops.nce_block_bwd(fhat_all[r0:r1], t_all, r0, 1.0 / (S * tau), saved[2], saved[3], g.contiguous().to(torch.float32), tau)
             df_all[r0:r1].copy_(df)
+        else:
+            dt_all = torch.zeros_like(t_all)
         return df_all, dt_all, None, None, None, None
 
 
