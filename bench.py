@@ -73,6 +73,10 @@ def parse():
     ap.add_argument("--workload", default="arxiv", choices=["arxiv", "mag"],
                     help="arxiv: BASELINE.json configs[1] (the headline); mag: configs[4], the MAG-shaped SAGE-mean + KD run on "
                          "node-range shards (sharded code path; with --gpus 1 use --force-sharded)")
+    ap.add_argument("--partition", default="auto", choices=["auto", "range"],
+                    help="sharded runs: auto = cut the node ranges from the community order when that lowers the halo; range = node ids as given")
+    ap.add_argument("--graph-kind", default="chunglu", choices=["chunglu", "local", "local-sorted"],
+                    help="synthetic graph of the sharded runs: chunglu (headline: no locality) | local (community structure, ids shuffled)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the node-range sharded (multi-GPU) code path even with one rank: RCCL init, halo plan, "
                          "SyncBN, row-block G-CRD -- a 1-GPU check of the path the N>1 runs take")

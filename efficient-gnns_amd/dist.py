@@ -150,6 +150,58 @@ def _agg(adj, x, addend=None, bias=None, relu=False):
     return ops.spmm(adj, x, "sum", bias=bias, addend=addend)
 
 
+def halo_rows_per_rank(rowptr: Tensor, col: Tensor, n: int, world: int) -> list:
+    """Distinct remote source rows every rank needs per halo exchange (= rows it receives per layer and direction) when the nodes
+    are cut into ``world`` contiguous ranges.  Integer, host or device; what locality-aware node orders reduce."""
+    out = []
+    for r in range(world):
+        lo, hi, _ = node_range(n, world, r)
+        c = col[int(rowptr[lo]):int(rowptr[hi])]
+        out.append(int(torch.unique(c[(c < lo) | (c >= hi)]).numel()))
+    return out
+
+
+def reorder_nodes(data, perm: Tensor):
+    """The same problem with its nodes relabelled: new node i is old node ``perm[i]`` -- adjacency (rows and columns), features,
+    labels, teacher artefacts and the split index lists (which keep their ORDER: position k of the train list still names the same
+    node, so the sampled criteria draw the same rows).  Every loss is invariant under the relabelling (up to summation order)."""
+    import types
+    n = data.num_nodes
+    perm = perm.to("cpu", torch.int64)
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(n, dtype=torch.int64)
+    d = types.SimpleNamespace(**vars(data))
+    d.adj_t = data.adj_t.permute(perm.to(data.adj_t.device))
+    for k in ("x", "y", "teacher_out_feat", "teacher_logits"):
+        v = getattr(data, k, None)
+        if v is not None:
+            setattr(d, k, v[perm])
+    d.split_idx = {k: inv[v] for k, v in data.split_idx.items()}
+    if getattr(data, "community", None) is not None:
+        d.community = data.community[perm]
+    d.node_perm = perm
+    return d
+
+
+def locality_order(data, world: int, device=None, **kw):
+    """``sparse.community_order`` of the problem's graph (size-capped label propagation, communities contiguous) as the node order
+    to cut the ranges from, when it pays: returns (perm | None, halo rows per rank in the given order, ... in the community order).
+    perm is None when the community order does not lower the total halo (a graph without locality: the Chung-Lu headline workload).
+    Deterministic (seeded), identical on every rank; integer work on ``device`` when given."""
+    from .sparse import community_order
+    adj = data.adj_t if device is None else data.adj_t.to(device)
+    rowptr, col, _ = adj.csr()
+    n = data.num_nodes
+    before = halo_rows_per_rank(rowptr, col, n, world)
+    # communities well below a rank's range, so that ranges hold whole communities
+    cap = kw.pop("max_community", max(64, min(4096, n // (4 * max(world, 1)))))
+    perm = community_order(adj, max_community=cap, **kw)
+    padj = adj.permute(perm)
+    prow, pcol, _ = padj.csr()
+    after = halo_rows_per_rank(prow, pcol, n, world)
+    return (perm.cpu() if sum(after) < sum(before) else None), before, after
+
+
 class ShardPlan:
     """Local view of one rank's rows of a global CSR: remapped columns + halo send / receive lists.
 
@@ -1277,7 +1329,16 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
         data = mag_problem(args.scale, args.seed)
         args.gnn, args.training = "sage", "kd"
     else:
-        data = D.arxiv_like(args.scale, seed=args.seed)        # same seeded graph on every rank (host-side, one-off)
+        data = D.arxiv_like(args.scale, seed=args.seed, graph=getattr(args, "graph_kind", "chunglu"))   # same seeded graph on every rank (host-side, one-off)
+    # locality-aware node order before the ranges are cut (SURVEY 8(e) "optional: locality reordering"): kept when it lowers the halo
+    partition = dict(order="node ids as given")
+    if world > 1 and getattr(args, "partition", "auto") != "range":
+        perm, halo_before, halo_after = locality_order(data, world, device if on_gpu else None)
+        partition = dict(order="community order (sparse.community_order)" if perm is not None else "node ids as given (the community order did not lower the halo)",
+                         halo_rows_per_rank_as_given=halo_before, halo_rows_per_rank_community_order=halo_after,
+                         halo_rows_change=round(sum(halo_after) / max(sum(halo_before), 1) - 1.0, 4))
+        if perm is not None:
+            data = reorder_nodes(data, perm)
     prob = ShardedProblem(data, world, rank, device, None, need_gcn=(args.gnn == "gcn"))
     Net = PM.GCN if args.gnn == "gcn" else PM.SAGE
     model = Net(data.num_features, model_cfg["hidden"], data.num_classes, model_cfg["layers"], model_cfg["dropout"]).to(device)
@@ -1389,7 +1450,7 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
             config=dict(workload=wl,
                         partitioning=f"node-range shards x{world}: halo all_to_all {'overlapped with the own-column aggregation' if _OVERLAP else '(blocking)'}"
                                      f" + SyncBN all-reduce + flat grad all-reduce over RCCL",
-                        mean_halo_rows_per_rank=int(float(halo) / world)),
+                        mean_halo_rows_per_rank=int(float(halo) / world), node_order=partition),
             launch=graph_note,
             comm_per_epoch=dict(what="one epoch (train step + eval) traced after the timed region: payload bytes per rank and kind; "
                                      "overlap_window_us = own-column aggregation time the halo exchanges run under, exposed_comm_us = what the "

@@ -531,3 +531,39 @@ def test_static_sample_layout():
     tiny = DD.StaticSample(types.SimpleNamespace(n_train_global=ntr, world=world, rank=0, train_owner=owner,
                                                  train_localpos=torch.from_numpy(samples[0]._localpos), device="cpu"), S, sigmas=-50.0)
     assert tiny.cap == 1 and not tiny.fill(pick)
+
+
+def test_community_order_lowers_the_halo_and_keeps_the_problem():
+    """dist.locality_order / reorder_nodes on the synthetic community graph (ids shuffled, as datasets come): cutting the 8 node
+    ranges from the community order lowers the halo rows by >= 40 %; the relabelled problem is the same problem (oracle loss and
+    gradients of one GCN + KD step agree); the Chung-Lu graph (no locality) keeps its given order."""
+    import efficient_gnns_amd.data as D
+    import efficient_gnns_amd.dist as DD
+    import oracle.models as OM
+    import oracle.sparse as OS
+    d = D.arxiv_like(scale=0.1, seed=1, graph="local")
+    perm, before, after = DD.locality_order(d, 8)
+    assert perm is not None and sum(after) <= 0.6 * sum(before), (before, after)
+    assert sorted(perm.tolist()) == list(range(d.num_nodes))
+    d2 = DD.reorder_nodes(d, perm)
+    assert all(torch.equal(d.y[d.split_idx[k]], d2.y[d2.split_idx[k]]) for k in d.split_idx), "split lists keep their order"
+    rowptr, col, _ = d2.adj_t.csr()
+    assert DD.halo_rows_per_rank(rowptr, col, d.num_nodes, 8) == after
+
+    def step(data):
+        rp, c, _ = data.adj_t.csr()
+        adj = OS.SparseTensor(rowptr=rp, col=c, sparse_sizes=data.adj_t.sparse_sizes())
+        torch.manual_seed(0)
+        m = OM.GCN(data.num_features, 32, data.num_classes, 3, 0.0)
+        opt = torch.optim.Adam(m.parameters(), lr=0.01)
+        hp = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=64, kernel="cosine")
+        losses = OM.train_step(m, data.x, adj, data.y, data.split_idx["train"], opt, "kd", hp, data.teacher_out_feat, data.teacher_logits)
+        return losses, [p.grad.clone() for p in m.parameters()]
+    (l1, g1), (l2, g2) = step(d), step(d2)
+    np.testing.assert_allclose(l1, l2, rtol=1e-5)
+    scale = max(float(a.abs().max()) for a in g1)     # biases in front of a BatchNorm carry rounding noise only: one absolute bar
+    for a, b in zip(g1, g2):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-3, atol=1e-5 * scale)
+    flat = D.arxiv_like(scale=0.05, seed=1)
+    perm_f, bf, af = DD.locality_order(flat, 8)
+    assert perm_f is None or sum(af) < sum(bf)
