@@ -8,7 +8,8 @@ drop-in one whatever PYTHONPATH says.  This launcher builds the path explicitly:
 matches the script's flavour -- ``dropin/`` (class-index CE/KL losses: arxiv_pyg, mag_pyg) or ``dropin/ppi_pyg/`` +
 ``dropin/`` (multi-label BCE ``kd_criterion``: any script directory whose own criterion.py is BCE based) -- and only
 then the script's directory (its logger.py etc. still resolve).  Use ``--keep-criterion`` to shim the operators
-(GCNConv, SparseTensor, ...) but keep the script's own criterion.py.
+(GCNConv, SparseTensor, ...) but keep the script's own criterion.py, ``--plain-torch-modules`` to leave torch.nn.BatchNorm1d /
+torch.nn.Linear of the script's own model code on PyTorch's kernels (default: the package's, see accel.py).
 """
 import os
 import runpy
@@ -36,10 +37,19 @@ def main(argv=None):
     keep = "--keep-criterion" in argv
     if keep:
         argv.remove("--keep-criterion")
+    plain = "--plain-torch-modules" in argv
+    if plain:
+        argv.remove("--plain-torch-modules")
     if not argv:
         raise SystemExit(__doc__)
     script = argv[0]
     sys.path[:0] = shim_path(script, keep)
+    if not plain:   # torch.nn.BatchNorm1d / torch.nn.Linear of the script's own model code on the package's kernels (dropin/accel.py)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("egnn_dropin_accel", os.path.join(HERE, "accel.py"))
+        accel = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(accel)
+        accel.enable()
     sys.argv = argv
     runpy.run_path(script, run_name="__main__")
 

@@ -198,3 +198,45 @@ def test_lsp_debug_invariants_hold_and_catch_a_broken_distribution(monkeypatch):
     p = torch.full((plan.E,), 0.5, device=DEV)
     with pytest.raises(AssertionError):
         ops_edge._check_lsp_invariants(p, p, plan.ptr_b, loss, p, p, 0)
+
+
+def test_dropin_accel_modules_match_torch():
+    """dropin/accel.py: torch.nn.BatchNorm1d / torch.nn.Linear re-pointed at the package's kernels give torch's values, gradients and
+    running statistics (fp32 tolerances of the package's parity tests); other inputs (3-D, CPU) keep torch's path; disable() restores."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("egnn_dropin_accel_t", os.path.join(ROOT, "efficient-gnns_amd", "dropin", "accel.py"))
+    accel = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(accel)
+    g = torch.Generator().manual_seed(0)
+    n, C, P = 5000, 256, 64
+    x0 = torch.randn(n, C, generator=g) * 2 + 0.5
+    gy = torch.randn(n, P, generator=g)
+
+    def run():
+        torch.manual_seed(1)
+        net = torch.nn.Sequential(torch.nn.BatchNorm1d(C), torch.nn.ReLU(), torch.nn.Linear(C, P)).to(DEV)
+        x = x0.to(DEV).requires_grad_(True)
+        y = net(x)
+        y.backward(gy.to(DEV))
+        net.eval()
+        with torch.no_grad():
+            ye = net(x0.to(DEV))
+        return [y, x.grad, net[0].weight.grad, net[0].bias.grad, net[2].weight.grad, net[2].bias.grad, net[0].running_mean, net[0].running_var,
+                net[0].num_batches_tracked.float(), ye]
+    ref = run()
+    orig_bn, orig_lin = torch.nn.BatchNorm1d.forward, torch.nn.Linear.forward
+    accel.enable()
+    try:
+        assert accel.enabled() and torch.nn.BatchNorm1d.forward is not orig_bn
+        got = run()
+        bn3 = torch.nn.BatchNorm1d(4).to(DEV)
+        assert bn3(torch.randn(2, 4, 5, device=DEV)).shape == (2, 4, 5)          # 3-D input: torch's own path
+        assert torch.nn.Linear(3, 2)(torch.randn(4, 3)).shape == (4, 2)         # CPU input: torch's own path
+    finally:
+        accel.disable()
+    assert torch.nn.BatchNorm1d.forward is orig_bn and torch.nn.Linear.forward is orig_lin
+    for a, b in zip(got, ref):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-6, (a.shape, float((a - b).abs().max()), scale)
