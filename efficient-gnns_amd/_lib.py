@@ -42,6 +42,7 @@ SIGNATURES = {
     "egnn_gemm_ws_floats": (_sz, [_i32, _i32, _i64, _i64, _i64, _i32]),
     "egnn_gemm_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _p]),
     "egnn_gemm_ex_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _i64, _p, _p, _i64, _i32, _p, _sz, _i32, _p]),
+    "egnn_gemm_add_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _i32, _p, _sz, _p]),
     "egnn_bn_fold_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _f32, _p, _i64, _p, _p]),
     "egnn_gemm_rows_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _p, _i64, _p, _p, _p, _i64, _i32, _p, _sz, _p]),
     "egnn_ce_kd_ws_floats": (_sz, [_i64]),

@@ -24,7 +24,15 @@ __global__ __launch_bounds__(256) void edge_sim_kernel(const float* __restrict__
     const float* b = F + ib[e] * ld;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     if constexpr (VEC4) {
-      for (int64_t d = lane * 4; d < D; d += 256) {
+      // 16-byte aligned rows (ld % 4 == 0): whole float4 chunks first, then the D % 4 trailing columns one lane each (the teacher's
+      // 750 columns behind a 752 pitch: the scalar walk of the whole row was 511 us of the LSP step)
+      const int64_t Dv = D & ~(int64_t)3;
+      if (lane < D - Dv) {
+        const float x = a[Dv + lane], y = b[Dv + lane];
+        if (kernel <= K_POLY) { s0 = x * y; s1 = x * x; s2 = y * y; }
+        else { const float t = x - y; s0 = t * t; }
+      }
+      for (int64_t d = lane * 4; d < Dv; d += 256) {
         const float4 x = *reinterpret_cast<const float4*>(a + d);
         const float4 y = *reinterpret_cast<const float4*>(b + d);
         if (kernel <= K_POLY) {
@@ -346,7 +354,7 @@ extern "C" int egnn_edge_sim_f32(const float* F, int64_t ld, int64_t D, const in
   EGNN_CHECK_ARG(E >= 0 && D > 0 && ld >= D && kernel >= 0 && kernel <= 3);
   if (E == 0) return EGNN_OK;
   EGNN_CHECK_ARG(F && idx_a && idx_b && sim && aux3);
-  const bool vec4 = (D % 4 == 0) && (ld % 4 == 0) && egnn_aligned16(F);
+  const bool vec4 = (ld % 4 == 0) && egnn_aligned16(F) && D >= 4;
   hipStream_t st = (hipStream_t)stream;
   if (vec4) hipLaunchKernelGGL(edge_sim_kernel<true>, dim3(wave_grid(E)), dim3(256), 0, st, F, ld, D, idx_a, idx_b, E, kernel, sim, aux3);
   else hipLaunchKernelGGL(edge_sim_kernel<false>, dim3(wave_grid(E)), dim3(256), 0, st, F, ld, D, idx_a, idx_b, E, kernel, sim, aux3);

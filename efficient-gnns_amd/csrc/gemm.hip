@@ -51,6 +51,8 @@ struct GemmArgs {
   int split_pipe;          // 1: products on the bf16 pipe (three-way operand split, gemm_split.h); 0: f32-input MFMA
   const u32x4* planes;     // pre-split B (gemm_split.h, "planes" form) or null
   int relu;                // C = max(alpha A B + bias, 0)
+  const float* addend;     // optional [M,N] matrix added in the store: C = alpha A B + bias + addend (never together with relu)
+  int64_t ld_add;
 };
 
 // epilogue of one output tile (or of one split-K partial)
@@ -73,7 +75,8 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TM_][TN_], const 
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wm * WM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < g.M) {
-          const float v = alpha * acc[tm][tn][r] + bv;
+          float v = alpha * acc[tm][tn][r] + bv;
+          if (g.addend && !partial) v += g.addend[row * g.ld_add + c];
           out[row * ldo + c] = (g.relu && !partial) ? fmaxf(v, 0.f) : v;
         }
       }
@@ -117,8 +120,20 @@ __device__ __forceinline__ void store_tile_wide(const f32x16 (&acc)[TM_][TN_], c
       const int rin = it * RPI + lane / F4, c4 = (lane % F4) * 4;
       const int64_t row = m0 + wm * WM + tm * 32 + rin;
       const int64_t col = n0 + wn * WN + c4;
-      const float4 v = *reinterpret_cast<const float4*>(sm + rin * LD + c4);
+      float4 v = *reinterpret_cast<const float4*>(sm + rin * LD + c4);
       float* o = out + row * ldo + col;
+      if (g.addend && !partial && row < g.M) {   // the wide form is only taken with a 16-byte addressable addend (gemm_impl)
+        const float* ad = g.addend + row * g.ld_add + col;
+        if (cols_full) {
+          const float4 a4 = *reinterpret_cast<const float4*>(ad);
+          v.x += a4.x; v.y += a4.y; v.z += a4.z; v.w += a4.w;
+        } else {
+          if (col < g.N) v.x += ad[0];
+          if (col + 1 < g.N) v.y += ad[1];
+          if (col + 2 < g.N) v.z += ad[2];
+          if (col + 3 < g.N) v.w += ad[3];
+        }
+      }
       if (cols_full) {               // block-uniform: the whole tile's columns are in range -> one 16-byte store per lane
         if (row < g.M) *reinterpret_cast<float4*>(o) = v;
       } else if (row < g.M) {
@@ -215,7 +230,8 @@ __global__ __launch_bounds__(256, 2) void gemm_pb_kernel(const GemmArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < g.M) {
-          const float v = alpha * acc[tm][r] + bv;
+          float v = alpha * acc[tm][r] + bv;
+          if (g.addend && !partial) v += g.addend[row * g.ld_add + c];
           out[row * ldo + c] = (g.relu && !partial) ? fmaxf(v, 0.f) : v;
         }
       }
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
     float s = 0.f;
     for (int k = 0; k < g.split_k; ++k) s += g.ws[(int64_t)k * total + t];  // fixed order
     const int64_t row = t / g.N, c = t % g.N;
-    const float v = alpha * s + (g.bias ? g.bias[c] : 0.f);
+    const float v = alpha * s + (g.bias ? g.bias[c] : 0.f) + (g.addend ? g.addend[row * g.ld_add + c] : 0.f);
     g.C[row * g.ldc + c] = g.relu ? fmaxf(v, 0.f) : v;
   }
 }
@@ -333,15 +349,17 @@ int launch_major(const GemmArgs& g, bool vec4, hipStream_t st) {
 
 static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
                      const int64_t* a_rows, const float* B, int64_t ldb, const int64_t* b_rows, const float* bias, float* C,
-                     int64_t ldc, int split_k, float* ws, size_t ws_bytes, void* stream, int flags = 0) {
+                     int64_t ldc, int split_k, float* ws, size_t ws_bytes, void* stream, int flags = 0, const float* addend = nullptr,
+                     int64_t ld_add = 0) {
   EGNN_CHECK_ARG(M >= 0 && N >= 0 && K >= 0);
   if (M == 0 || N == 0) return EGNN_OK;
   EGNN_CHECK_ARG(A && B && C && ldc >= N);
+  EGNN_CHECK_ARG(addend == nullptr || (ld_add >= N && !(flags & 1)));
   EGNN_CHECK_ARG(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N));
   // fused row gathers: rows of an [M,K]-stored A (the operand of x[idx] @ W^T) or of a [K,N]-stored B (dW = dY^T x[idx])
   EGNN_CHECK_ARG(!(a_rows && b_rows) && !(a_rows && trans_a) && !(b_rows && trans_b));
   hipStream_t st0 = (hipStream_t)stream;
-  if (!a_rows && !b_rows && flags == 0) {   // class-count-wide shapes: dedicated HBM-bound kernels (gemm_skinny.hip); rc 1 = shape not taken
+  if (!a_rows && !b_rows && flags == 0 && !addend) {   // class-count-wide shapes: dedicated HBM-bound kernels (gemm_skinny.hip); rc 1 = shape not taken
     const int kind = skinny_kind(trans_a, trans_b, M, N, K, bias != nullptr);
     int rc = 1;
     if (kind == 1) {
@@ -359,12 +377,13 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   if (split_k > 1) {
     if (!ws || ws_bytes < (size_t)split_k * M * N * sizeof(float)) return EGNN_EWORKSPACE;
   }
-  const bool wide = split_k > 1 ? (N % 4 == 0 && egnn_aligned16(ws)) : (ldc % 4 == 0 && egnn_aligned16(C));
+  const bool wide = split_k > 1 ? (N % 4 == 0 && egnn_aligned16(ws))
+                                : (ldc % 4 == 0 && egnn_aligned16(C) && (!addend || (ld_add % 4 == 0 && egnn_aligned16(addend))));
   static const bool narrow_forced = getenv("EGNN_GEMM_NARROW_STORE") != nullptr;   // A/B switch for the epilogue form
   GemmArgs g{M, N, K, A, lda, B, ldb, bias, C, ldc, alpha, nullptr, split_k,
              ((ksteps + split_k - 1) / split_k) * BK, ws, a_rows ? a_rows : b_rows, (wide && !narrow_forced) ? 1 : 0,
              gemm_split_pipe() ? 1 : 0,
-             nullptr, (flags & 1) ? 1 : 0};
+             nullptr, (flags & 1) ? 1 : 0, addend, ld_add};
   hipStream_t st = (hipStream_t)stream;
   const bool vec4 = (lda % 4 == 0) && (ldb % 4 == 0) && egnn_aligned16(A) && egnn_aligned16(B);
   const int amaj = trans_a ? MNMAJOR : KMAJOR;   // A stored [K,M] when transposed
@@ -432,6 +451,13 @@ extern "C" int egnn_gemm_ex_f32(int trans_a, int trans_b, int64_t M, int64_t N, 
                                 const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc, int split_k, float* ws,
                                 size_t ws_bytes, int flags, void* stream) {
   return gemm_impl(trans_a, trans_b, M, N, K, alpha, A, lda, nullptr, B, ldb, nullptr, bias, C, ldc, split_k, ws, ws_bytes, stream, flags);
+}
+
+extern "C" int egnn_gemm_add_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                                 const float* B, int64_t ldb, const float* bias, const float* addend, int64_t ld_addend, float* C,
+                                 int64_t ldc, int split_k, float* ws, size_t ws_bytes, void* stream) {
+  return gemm_impl(trans_a, trans_b, M, N, K, alpha, A, lda, nullptr, B, ldb, nullptr, bias, C, ldc, split_k, ws, ws_bytes, stream, 0, addend,
+                   ld_addend);
 }
 
 extern "C" int egnn_gemm_rows_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A,

@@ -19,6 +19,7 @@ from .sparse import SparseTensor, _ind2ptr, csr_from_coo, gcn_norm
 
 # opt-in: the headline bench keeps the reference's per-step work (aggregate every layer every step)
 _MEMOISE_AX = os.environ.get("EGNN_GCN_MEMOISE_AX", "0") == "1"
+_SAGE_FUSED = os.environ.get("EGNN_SAGE_FUSED", "1") == "1"   # A/B switch: SAGEConv as one autograd node with accumulating stores (ops._SageLayer)
 _SAGE_NARROW_FIRST = os.environ.get("EGNN_SAGE_NARROW_FIRST", "1") == "1"   # A/B switch: SAGEConv aggregates lin_l(x) when out < in
 
 
@@ -189,6 +190,11 @@ class SAGEConv(nn.Module):
             agg = edge_index.aggregate(x, self.aggr, valueless=True)
             return ops.linear(agg, self.lin_l.weight, self.lin_l.bias) + ops.linear(x, self.lin_r.weight, None)
         adj = edge_index if isinstance(edge_index, SparseTensor) else _adj_from_edge_index(edge_index, x.shape[0])
+        if (_SAGE_FUSED and self.aggr in ("mean", "sum") and x.is_cuda and x.dim() == 2 and self.lin_r.bias is None
+                and adj.nnz() > 0 and adj.sparse_size(0) == adj.sparse_size(1)):
+            # lin_l(aggr(x)) + lin_r(x) with both sums formed in kernel stores (ops._SageLayer): no element-wise pass forward or backward
+            narrow = _SAGE_NARROW_FIRST and self.out_channels < self.in_channels
+            return ops.sage_layer(x, adj.set_value(None), self.lin_l, self.lin_r, self.aggr, narrow)
         if _SAGE_NARROW_FIRST and self.out_channels < self.in_channels and self.aggr in ("mean", "sum") and x.is_cuda:
             # mean / sum are linear: aggr_j(x_j) W^T == aggr_j(x_j W^T).  On the output layer (256 -> 40 classes, gnn.py:84) the HBM-bound
             # gather then moves `out` instead of `in` floats per neighbour, forward and backward -- the re-association GCNConv makes.

@@ -368,8 +368,8 @@ def pad_pitch(t: Tensor) -> Tensor:
 
 def gemm_raw(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False, bias: Tensor | None = None,
              alpha: float = 1.0, split_k: int | None = None, a_rows: Tensor | None = None, b_rows: Tensor | None = None,
-             relu: bool = False) -> Tensor:
-    """C = alpha * op(a) @ op(b) (+ bias) via egnn_gemm_f32 / egnn_gemm_rows_f32.
+             relu: bool = False, addend: Tensor | None = None) -> Tensor:
+    """C = alpha * op(a) @ op(b) (+ bias) (+ addend [M,N], added in the kernel's store) via egnn_gemm_f32 / egnn_gemm_rows_f32.
 
     a_rows [M] (trans_a False): op(a) = a[a_rows];  b_rows [K] (trans_b False): b = b[b_rows] -- the gather is fused
     into the operand load."""
@@ -398,7 +398,15 @@ def gemm_raw(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False,
         nws = max(nws, split_k * M * N if split_k > 1 else 0)
     if nws > 0:
         ws = torch.empty(nws, dtype=torch.float32, device=a.device)
-    if a_rows is None and b_rows is None:
+    if addend is not None:
+        if a_rows is not None or b_rows is not None or relu or tuple(addend.shape) != (M, N):
+            raise ValueError("gemm_raw: `addend` is an [M, N] matrix (no fused gather, no ReLU)")
+        addend = _rowmajor(addend)
+        rc = lib.egnn_gemm_add_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0),
+                                   _lib.ptr(bias), _lib.ptr(addend), addend.stride(0), _lib.ptr(c), c.stride(0), split_k, _lib.ptr(ws),
+                                   0 if ws is None else ws.numel() * 4, _lib.stream())
+        _lib.check(rc, "egnn_gemm_add_f32")
+    elif a_rows is None and b_rows is None:
         rc = lib.egnn_gemm_ex_f32(int(trans_a), int(trans_b), M, N, K, float(alpha), _lib.ptr(a), a.stride(0), _lib.ptr(b),
                                   b.stride(0), _lib.ptr(bias), _lib.ptr(c), c.stride(0), split_k, _lib.ptr(ws),
                                   0 if ws is None else ws.numel() * 4, 1 if relu else 0, _lib.stream())
@@ -456,6 +464,60 @@ class _MatMul(torch.autograd.Function):
 def matmul(x: Tensor, w: Tensor, bias: Tensor | None = None) -> Tensor:
     """x [M,K] @ w [K,N] (+ bias [N], added in the GEMM's store)."""
     return _MatMul.apply(x, w, bias, False)
+
+
+class _SageLayer(torch.autograd.Function):
+    """SAGEConv (PyG <= 1.7: ``lin_l(aggr_j x_j) + lin_r(x_i)``; gnn.py:79-84) as ONE node of the autograd graph, so that
+    neither ``lin_l(..) + lin_r(..)`` nor the two-path sum of the input gradient is an element-wise pass over [N, C]: the second
+    product of each pair is added in the store of the kernel that forms it (GEMM ``addend`` / SpMM ``addend``).
+    ``narrow``: aggregate ``x W_l^T`` instead of x (mean / sum are linear; taken when out < in: the gather moves `out` floats)."""
+
+    @staticmethod
+    def forward(ctx, x, adj, wl, bl, wr, reduce, narrow):
+        x = _rowmajor(x)
+        r = gemm_raw(x, wr, False, True)                                   # lin_r(x)
+        if narrow:
+            t = gemm_raw(x, wl, False, True)                               # x W_l^T, then aggregated with bias + lin_r(x) in the store
+            out = spmm_raw(adj, t, reduce, bias=bl, addend=r)[0]
+            agg = None
+        else:
+            agg = spmm_raw(adj, x, reduce)[0]
+            out = gemm_raw(agg, wl, False, True, bias=bl, addend=r)        # lin_l(agg) + lin_r(x) in one store
+        ctx.save_for_backward(x, wl, wr, *([] if agg is None else [agg]))
+        ctx.adj, ctx.reduce, ctx.narrow, ctx.has_bias = adj, reduce, narrow, bl is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wl, wr = ctx.saved_tensors[:3]
+        agg = ctx.saved_tensors[3] if len(ctx.saved_tensors) > 3 else None
+        adj, reduce = ctx.adj, ctx.reduce
+        g = _rowmajor(g)
+        need_x = ctx.needs_input_grad[0]
+        scale = adj._inv_rowcount() if reduce == "mean" else None          # dX = A^T (dY / cnt) for the mean
+        gx = gwl = gbl = gwr = None
+        if ctx.needs_input_grad[4]:
+            gwr = gemm_raw(g, x, True, False)                              # dW_r = g^T x
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            gbl = colsum(g)
+        if ctx.narrow:
+            need_t = need_x or ctx.needs_input_grad[2]
+            dt = spmm_raw(adj.t(), g, "sum", src_scale=scale)[0] if need_t else None
+            if ctx.needs_input_grad[2]:
+                gwl = gemm_raw(dt, x, True, False)                         # dW_l = dt^T x
+            if need_x:
+                gx = gemm_raw(dt, wl, False, False, addend=gemm_raw(g, wr, False, False))     # dt W_l + g W_r
+        else:
+            if ctx.needs_input_grad[2]:
+                gwl = gemm_raw(g, agg, True, False)                        # dW_l = g^T agg
+            if need_x:
+                d_agg = gemm_raw(g, wl, False, False)
+                gx = spmm_raw(adj.t(), d_agg, "sum", src_scale=scale, addend=gemm_raw(g, wr, False, False))[0]   # A^T d_agg + g W_r
+        return _fresh(gx), None, gwl, gbl, gwr, None, None
+
+
+def sage_layer(x: Tensor, adj, lin_l, lin_r, reduce: str, narrow: bool) -> Tensor:
+    return _SageLayer.apply(x, adj, lin_l.weight, lin_l.bias, lin_r.weight, reduce, narrow)
 
 
 class _TapBox:

@@ -225,6 +225,12 @@ int egnn_gemm_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, flo
 int egnn_gemm_ex_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
                      const float* B, int64_t ldb, const float* bias, float* C, int64_t ldc, int split_k, float* ws,
                      size_t ws_bytes, int flags, void* stream);
+/* egnn_gemm_f32 with an accumulating store: C = alpha op(A) op(B) + bias + addend (addend [M,N], ld_addend >= N, nullable; may be C
+ * itself only if nothing else reads it).  SAGEConv's lin_l(agg) + lin_r(x) (/root/reference/arxiv_pyg/gnn.py:79-84 via PyG SAGEConv.forward,
+ * SURVEY 9.5) and the two-path input gradient of its backward become one store each instead of a GEMM + an element-wise pass. */
+int egnn_gemm_add_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda,
+                      const float* B, int64_t ldb, const float* bias, const float* addend, int64_t ld_addend, float* C, int64_t ldc,
+                      int split_k, float* ws, size_t ws_bytes, void* stream);
 /* The same GEMM with a row gather fused into one operand's load, for the `feat[train_idx]` gathers in front of the
  * projection heads (/root/reference/arxiv_pyg/gnn.py:150-156: `out_feat[train_idx]`, `teacher_out_feat[train_idx]`,
  * the latter 273 MB read + written per step in the reference):

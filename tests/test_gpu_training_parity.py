@@ -240,3 +240,66 @@ def test_dropin_accel_modules_match_torch():
     for a, b in zip(got, ref):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-6, (a.shape, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,pad,split_k", [(5000, 256, 128, False, True, 0, None), (5000, 256, 256, False, False, 0, None),
+                                                       (300, 72, 50, False, True, 3, None), (4096, 128, 64, False, False, 0, None),
+                                                       (64, 40, 9000, True, False, 0, 8), (1000, 256, 96, False, True, 0, 1)])
+def test_gemm_accumulating_store_vs_float64(M, N, K, ta, tb, pad, split_k):
+    """egnn_gemm_add_f32: C = op(A) op(B) + bias + addend for the DMA form, the register-staged forms (odd pitches: narrow stores),
+    split-K; the addend lives behind a pitch (a column block of a wider matrix)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g) * 0.1
+    bias = torch.randn(N, generator=g)
+    add = torch.randn(M, N + pad, generator=g)[:, :N]
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double()) + bias.double() + add.double()
+    out = ops.gemm_raw(a.to(DEV), b.to(DEV), ta, tb, bias.to(DEV), split_k=split_k, addend=add.to(DEV))
+    scale = float(ref.abs().max())
+    assert float((out.double().cpu() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (K / 256) ** 0.5)
+
+
+@pytest.mark.parametrize("reduce", ["mean", "sum"])
+@pytest.mark.parametrize("cin,cout", [(128, 256), (256, 256), (256, 40)])
+def test_sage_layer_as_one_node_equals_the_composed_operators(reduce, cin, cout):
+    """ops._SageLayer (accumulating stores, one autograd node) against lin_l(spmm(x)) + lin_r(x) built from the separate operators:
+    output and all five gradients."""
+    d = D.arxiv_like(scale=0.05, seed=9)
+    adj = d.adj_t.to(DEV)
+    g = torch.Generator().manual_seed(cin + cout)
+    n = d.num_nodes
+    x0 = torch.randn(n, cin, generator=g)
+    lin_l, lin_r = torch.nn.Linear(cin, cout).to(DEV), torch.nn.Linear(cin, cout, bias=False).to(DEV)
+    gy = torch.randn(n, cout, generator=g).to(DEV)
+
+    def run(fused):
+        for p in list(lin_l.parameters()) + list(lin_r.parameters()):
+            p.grad = None
+        x = x0.to(DEV).requires_grad_(True)
+        if fused:
+            out = ops.sage_layer(x, adj.set_value(None), lin_l, lin_r, reduce, narrow=cout < cin)
+        else:
+            out = ops.linear(ops.spmm(adj.set_value(None), x, reduce), lin_l.weight, lin_l.bias) + ops.linear(x, lin_r.weight, None)
+        out.backward(gy)
+        return [out.detach(), x.grad, lin_l.weight.grad.clone(), lin_l.bias.grad.clone(), lin_r.weight.grad.clone()]
+    got, ref = run(True), run(False)
+    for name, a, b in zip(("out", "dx", "dWl", "dbl", "dWr"), got, ref):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 3e-5 * scale, (name, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("kernel", ["cosine", "rbf"])
+def test_edge_similarity_behind_a_padded_pitch(kernel):
+    """egnn_edge_sim_f32 on rows of 750 columns behind a 752 pitch (the teacher features after ops.pad_pitch): the float4 walk
+    + trailing columns equals the unpadded tensor's result (scalar walk) and float64."""
+    g = torch.Generator().manual_seed(3)
+    n, Dm, E_ = 3000, 750, 40000
+    F_ = torch.relu(torch.randn(n, Dm, generator=g)) * (0.06 if kernel == "rbf" else 1.0)
+    ei = torch.randint(0, n, (2, E_), generator=g)
+    plan = ops_edge.EdgePlan(ei.to(DEV), n)
+    dense = ops_edge._EdgeSim.apply(F_.to(DEV), plan, kernel)
+    padded = ops_edge._EdgeSim.apply(ops.pad_pitch(F_.to(DEV)), plan, kernel)
+    a, b = F_.double()[plan.a_in_b.cpu()], F_.double()[plan.b_in_b.cpu()]
+    ref = torch.exp(-0.5 * ((a - b) ** 2).sum(1)) if kernel == "rbf" else torch.nn.functional.cosine_similarity(a, b)
+    assert float((padded.double().cpu() - ref).abs().max()) <= 2e-6
+    assert float((padded - dense).abs().max()) <= 1e-6
