@@ -131,13 +131,28 @@ __global__ __launch_bounds__(256) void seg_softmax_bwd_kernel(const int64_t* __r
 
 __global__ __launch_bounds__(256) void seg_sum_kernel(const int64_t* __restrict__ ptr, const float* __restrict__ x,
                                                       int64_t n_seg, float* __restrict__ out) {
+  // four segments per wave (16-lane groups); a segment longer than 256 entries is walked by the whole wave afterwards
   const int lane = egnn_lane();
-  for (int64_t s = blockIdx.x * 4LL + egnn_wave_id(); s < n_seg; s += (int64_t)gridDim.x * 4) {
-    const int64_t b = ptr[s], e = ptr[s + 1];
+  const int grp = lane >> 4, sl = lane & 15;
+  for (int64_t s0 = (blockIdx.x * 4LL + egnn_wave_id()) * 4; s0 < n_seg; s0 += (int64_t)gridDim.x * 16) {
+    const int64_t s = s0 + grp;
+    const int64_t b = s < n_seg ? ptr[s] : 0, e = s < n_seg ? ptr[s + 1] : 0;
+    const bool small = e - b <= 256;
     float d = 0.f;
-    for (int64_t i = b + lane; i < e; i += 64) d += x[i];
-    d = egnn_wave_sum(d);
-    if (lane == 0) out[s] = d;
+    if (small) for (int64_t i = b + sl; i < e; i += 16) d += x[i];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    if (small && sl == 0 && s < n_seg) out[s] = d;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t bg = __shfl(b, k * 16), eg = __shfl(e, k * 16);
+      if (eg - bg > 256) {
+        float w = 0.f;
+        for (int64_t i = bg + lane; i < eg; i += 64) w += x[i];
+        w = egnn_wave_sum(w);
+        if (lane == 0) out[s0 + k] = w;
+      }
+    }
   }
 }
 
@@ -150,13 +165,48 @@ __global__ __launch_bounds__(256) void seg_sum_kernel(const int64_t* __restrict_
 // semaphores with a memset node that was seen NOT to take effect in hipGraph replays on this stack, profiles/r04_lsp_trace.txt).
 constexpr int kLspBlocks = 1024;
 
-__device__ __forceinline__ void seg_softmax_stats(const float* __restrict__ x, int64_t b, int64_t e, int lane, float& m, float& den) {
+// Segments are short on average (7.5 edges per train node) with a few hubs: a wave takes FOUR consecutive segments, one per 16-lane
+// group (strided walk, 16-lane butterflies); a segment longer than kSubMax is then walked by the whole wave.  Fixed assignment and
+// fixed reduction order: deterministic.
+constexpr int kSubMax = 256;
+
+__device__ __forceinline__ float sub16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float sub16_max(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// (max, sum exp + 1e-16) of x[b, e) walked by lanes first, first + step, ... and reduced over the walking group
+template <bool WAVE>
+__device__ __forceinline__ void seg_softmax_stats(const float* __restrict__ x, int64_t b, int64_t e, int first, int step, float& m, float& den) {
   m = -INFINITY;
-  for (int64_t i = b + lane; i < e; i += 64) m = fmaxf(m, x[i]);
-  m = egnn_wave_max(m);
+  for (int64_t i = b + first; i < e; i += step) m = fmaxf(m, x[i]);
+  m = WAVE ? egnn_wave_max(m) : sub16_max(m);
   float z = 0.f;
-  for (int64_t i = b + lane; i < e; i += 64) z += expf(x[i] - m);
-  den = egnn_wave_sum(z) + 1e-16f;
+  for (int64_t i = b + first; i < e; i += step) z += expf(x[i] - m);
+  den = (WAVE ? egnn_wave_sum(z) : sub16_sum(z)) + 1e-16f;
+}
+
+template <bool WAVE>
+__device__ __forceinline__ float lsp_fwd_segment(const float* __restrict__ xs, const float* __restrict__ xt, int64_t b, int64_t e, int first,
+                                                 int step, int mse, float* __restrict__ ps, float* __restrict__ pt) {
+  float ms, ds, mt, dt, acc = 0.f;
+  seg_softmax_stats<WAVE>(xs, b, e, first, step, ms, ds);
+  seg_softmax_stats<WAVE>(xt, b, e, first, step, mt, dt);
+  for (int64_t i = b + first; i < e; i += step) {
+    const float a = expf(xs[i] - ms) / ds;   // a DIVISION per entry as in the reference (see seg_softmax_fwd_kernel)
+    const float t = expf(xt[i] - mt) / dt;
+    ps[i] = a;
+    pt[i] = t;
+    if (mse) { const float d = a - t; acc = fmaf(d, d, acc); }
+    else acc += t > 0.f ? t * (logf(t) - logf(a)) : 0.f;
+  }
+  return acc;
 }
 
 __global__ __launch_bounds__(256) void lsp_loss_fwd_kernel(const int64_t* __restrict__ ptr, const float* __restrict__ xs,
@@ -166,20 +216,16 @@ __global__ __launch_bounds__(256) void lsp_loss_fwd_kernel(const int64_t* __rest
   __shared__ float s_part[4];
   const int lane = egnn_lane();
   const int wave = egnn_wave_id();
+  const int grp = lane >> 4, sl = lane & 15;
   float acc = 0.f;
-  for (int64_t s = blockIdx.x * 4LL + wave; s < n_seg; s += (int64_t)gridDim.x * 4) {
-    const int64_t b = ptr[s], e = ptr[s + 1];
-    if (b == e) continue;
-    float ms, ds, mt, dt;
-    seg_softmax_stats(xs, b, e, lane, ms, ds);
-    seg_softmax_stats(xt, b, e, lane, mt, dt);
-    for (int64_t i = b + lane; i < e; i += 64) {
-      const float a = expf(xs[i] - ms) / ds;   // a DIVISION per entry as in the reference (see seg_softmax_fwd_kernel)
-      const float t = expf(xt[i] - mt) / dt;
-      ps[i] = a;
-      pt[i] = t;
-      if (mse) { const float d = a - t; acc = fmaf(d, d, acc); }
-      else acc += t > 0.f ? t * (logf(t) - logf(a)) : 0.f;
+  for (int64_t s0 = (blockIdx.x * 4LL + wave) * 4; s0 < n_seg; s0 += (int64_t)gridDim.x * 16) {
+    const int64_t s = s0 + grp;
+    const int64_t b = s < n_seg ? ptr[s] : 0, e = s < n_seg ? ptr[s + 1] : 0;
+    if (e - b <= kSubMax) acc += lsp_fwd_segment<false>(xs, xt, b, e, sl, 16, mse, ps, pt);   // (an empty range walks nothing)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {   // the hubs among the four: wave-uniform bounds, the whole wave walks
+      const int64_t bg = __shfl(b, g * 16), eg = __shfl(e, g * 16);
+      if (eg - bg > kSubMax) acc += lsp_fwd_segment<true>(xs, xt, bg, eg, lane, 64, mse, ps, pt);
     }
   }
   acc = egnn_wave_sum(acc);
@@ -205,39 +251,51 @@ __global__ __launch_bounds__(256) void lsp_loss_final_kernel(const float* __rest
 // d loss / d sim_s (and, when asked for, d loss / d sim_t) through the two softmaxes: gx = p * (gp - sum_seg p * gp) with
 //   KLD: gp_s = -g p_t / (E p_s)          gp_t = g (log p_t - log p_s + 1) / E   (0 where p_t == 0)
 //   MSE: gp_s = 2 g (p_s - p_t) / E       gp_t = -gp_s
+template <bool WAVE>
+__device__ __forceinline__ void lsp_bwd_segment(const float* __restrict__ ps, const float* __restrict__ pt, int64_t b, int64_t e, int first,
+                                                int step, int mse, float gs, float* __restrict__ gxs, float* __restrict__ gxt) {
+  float d_s = 0.f, d_t = 0.f;   // sum_seg p * gp for the student / teacher side
+  for (int64_t i = b + first; i < e; i += step) {
+    const float a = ps[i], t = pt[i];
+    if (mse) {
+      const float gp = 2.f * gs * (a - t);
+      d_s = fmaf(a, gp, d_s);
+      d_t = fmaf(t, -gp, d_t);
+    } else {
+      d_s -= gs * t;                                       // p_s * (-g p_t / (E p_s))
+      if (gxt != nullptr && t > 0.f) d_t = fmaf(t, gs * (logf(t) - logf(a) + 1.f), d_t);
+    }
+  }
+  d_s = WAVE ? egnn_wave_sum(d_s) : sub16_sum(d_s);
+  if (gxt != nullptr) d_t = WAVE ? egnn_wave_sum(d_t) : sub16_sum(d_t);
+  for (int64_t i = b + first; i < e; i += step) {
+    const float a = ps[i], t = pt[i];
+    if (mse) {
+      const float gp = 2.f * gs * (a - t);
+      gxs[i] = a * (gp - d_s);
+      if (gxt != nullptr) gxt[i] = t * (-gp - d_t);
+    } else {
+      gxs[i] = -gs * t - a * d_s;
+      if (gxt != nullptr) gxt[i] = t > 0.f ? t * (gs * (logf(t) - logf(a) + 1.f) - d_t) : 0.f;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void lsp_loss_bwd_kernel(const int64_t* __restrict__ ptr, const float* __restrict__ ps,
                                                            const float* __restrict__ pt, int64_t n_seg, int mse,
                                                            const float* __restrict__ g, float inv_count,
                                                            float* __restrict__ gxs, float* __restrict__ gxt) {
   const int lane = egnn_lane();
+  const int grp = lane >> 4, sl = lane & 15;
   const float gs = g[0] * inv_count;
-  for (int64_t s = blockIdx.x * 4LL + egnn_wave_id(); s < n_seg; s += (int64_t)gridDim.x * 4) {
-    const int64_t b = ptr[s], e = ptr[s + 1];
-    if (b == e) continue;
-    float d_s = 0.f, d_t = 0.f;   // sum_seg p * gp for the student / teacher side
-    for (int64_t i = b + lane; i < e; i += 64) {
-      const float a = ps[i], t = pt[i];
-      if (mse) {
-        const float gp = 2.f * gs * (a - t);
-        d_s = fmaf(a, gp, d_s);
-        d_t = fmaf(t, -gp, d_t);
-      } else {
-        d_s -= gs * t;                                       // p_s * (-g p_t / (E p_s))
-        if (gxt != nullptr && t > 0.f) d_t = fmaf(t, gs * (logf(t) - logf(a) + 1.f), d_t);
-      }
-    }
-    d_s = egnn_wave_sum(d_s);
-    if (gxt != nullptr) d_t = egnn_wave_sum(d_t);
-    for (int64_t i = b + lane; i < e; i += 64) {
-      const float a = ps[i], t = pt[i];
-      if (mse) {
-        const float gp = 2.f * gs * (a - t);
-        gxs[i] = a * (gp - d_s);
-        if (gxt != nullptr) gxt[i] = t * (-gp - d_t);
-      } else {
-        gxs[i] = -gs * t - a * d_s;
-        if (gxt != nullptr) gxt[i] = t > 0.f ? t * (gs * (logf(t) - logf(a) + 1.f) - d_t) : 0.f;
-      }
+  for (int64_t s0 = (blockIdx.x * 4LL + egnn_wave_id()) * 4; s0 < n_seg; s0 += (int64_t)gridDim.x * 16) {
+    const int64_t s = s0 + grp;
+    const int64_t b = s < n_seg ? ptr[s] : 0, e = s < n_seg ? ptr[s + 1] : 0;
+    if (e - b <= kSubMax) lsp_bwd_segment<false>(ps, pt, b, e, sl, 16, mse, gs, gxs, gxt);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t bg = __shfl(b, k * 16), eg = __shfl(e, k * 16);
+      if (eg - bg > kSubMax) lsp_bwd_segment<true>(ps, pt, bg, eg, lane, 64, mse, gs, gxs, gxt);
     }
   }
 }
@@ -393,7 +451,7 @@ extern "C" int egnn_segment_sum_f32(const int64_t* seg_ptr, const float* x, int6
   EGNN_CHECK_ARG(n_seg >= 0);
   if (n_seg == 0) return EGNN_OK;
   EGNN_CHECK_ARG(seg_ptr && x && out);
-  hipLaunchKernelGGL(seg_sum_kernel, dim3(wave_grid(n_seg)), dim3(256), 0, (hipStream_t)stream, seg_ptr, x, n_seg, out);
+  hipLaunchKernelGGL(seg_sum_kernel, dim3(wave_grid((n_seg + 3) / 4)), dim3(256), 0, (hipStream_t)stream, seg_ptr, x, n_seg, out);
   return egnn_launch_status();
 }
 
@@ -404,7 +462,7 @@ extern "C" int egnn_lsp_loss_fwd_f32(const int64_t* seg_ptr, const float* sim_s,
   EGNN_CHECK_ARG(n_seg >= 0 && E > 0 && (criterion == 0 || criterion == 1));
   EGNN_CHECK_ARG(seg_ptr && sim_s && sim_t && p_s && p_t && loss && ws && n_seg > 0);
   hipStream_t st = (hipStream_t)stream;
-  const int64_t want = (n_seg + 3) / 4;
+  const int64_t want = (n_seg + 15) / 16;   // 16 segments per workgroup pass
   const int nb = (int)(want < kLspBlocks ? want : kLspBlocks);
   hipLaunchKernelGGL(lsp_loss_fwd_kernel, dim3(nb), dim3(256), 0, st, seg_ptr, sim_s, sim_t, n_seg, criterion, p_s, p_t, ws);
   hipLaunchKernelGGL(lsp_loss_final_kernel, dim3(1), dim3(256), 0, st, ws, nb, 1.f / (float)E, loss);
@@ -415,7 +473,7 @@ extern "C" int egnn_lsp_loss_bwd_f32(const int64_t* seg_ptr, const float* p_s, c
                                      int criterion, const float* g, float* gsim_s, float* gsim_t, void* stream) {
   EGNN_CHECK_ARG(n_seg > 0 && E > 0 && (criterion == 0 || criterion == 1));
   EGNN_CHECK_ARG(seg_ptr && p_s && p_t && g && gsim_s);
-  hipLaunchKernelGGL(lsp_loss_bwd_kernel, dim3(wave_grid(n_seg)), dim3(256), 0, (hipStream_t)stream, seg_ptr, p_s, p_t, n_seg,
+  hipLaunchKernelGGL(lsp_loss_bwd_kernel, dim3(wave_grid((n_seg + 3) / 4)), dim3(256), 0, (hipStream_t)stream, seg_ptr, p_s, p_t, n_seg,
                      criterion, g, 1.f / (float)E, gsim_s, gsim_t);
   return egnn_launch_status();
 }

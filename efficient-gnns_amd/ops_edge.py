@@ -68,6 +68,14 @@ class EdgePlan:
         self.perm_a = perm_a
         self.ptr_a = _ind2ptr(self.a_in_b[perm_a].contiguous(), n)
         self.by_a = SparseTensor(rowptr=self.ptr_a, col=self.b_in_b[perm_a].contiguous(), sparse_sizes=(n, n))  # row a gathers b
+        # "row b gathers a" PLUS one diagonal entry per node: the backward's  sum_e alpha_e F[a_e] + d_i F[i]  is then ONE aggregation
+        # (values = the step's alpha followed by the step's diagonal, brought into CSR order by ``perm_bd``) instead of an
+        # aggregation + a scale pass + an add pass over [n, D]
+        ids = torch.arange(n, dtype=torch.int64, device=a.device)
+        rows_bd = torch.cat([self.b_in_b, ids])
+        self.perm_bd = torch.argsort(rows_bd, stable=True)
+        self.by_bd = SparseTensor(rowptr=_ind2ptr(rows_bd[self.perm_bd].contiguous(), n), col=torch.cat([self.a_in_b, ids])[self.perm_bd].contiguous(),
+                                  sparse_sizes=(n, n))
 
 
 _PLANS: dict = {}
@@ -109,18 +117,18 @@ class _EdgeSim(torch.autograd.Function):
         alpha, beta_a, beta_b = (torch.empty(E, dtype=torch.float32, device=dev) for _ in range(3))
         _lib.check(lib.egnn_edge_sim_coef_f32(_lib.ptr(g), _lib.ptr(sim), _lib.ptr(aux), E, _KERNELS[ctx.kernel], _lib.ptr(alpha),
                                               _lib.ptr(beta_a), _lib.ptr(beta_b), st), "egnn_edge_sim_coef_f32")
-        # dF[b] += sum_e alpha_e F[a_e]   and   dF[a] += sum_e alpha_e F[b_e]  : two aggregations with edge values
-        gF, _ = ops.spmm_raw(plan.by_b.set_value(alpha), F, "sum")
+        # dF[b] += sum_e alpha_e F[a_e],  dF[a] += sum_e alpha_e F[b_e],  dF[i] += (sum_{e: b_e = i} beta_b + sum_{e: a_e = i} beta_a) F[i]:
+        # two aggregations with edge values -- the second carries the diagonal as extra entries and adds the first in its store
         alpha_a = alpha[plan.perm_a].contiguous()
         gF2, _ = ops.spmm_raw(plan.by_a.set_value(alpha_a), F, "sum")
-        # diagonal part: (sum_{e: b_e = i} beta_b + sum_{e: a_e = i} beta_a) * F[i]
         sb = torch.empty(plan.n, dtype=torch.float32, device=dev)
         sa = torch.empty(plan.n, dtype=torch.float32, device=dev)
         _lib.check(lib.egnn_segment_sum_f32(_lib.ptr(plan.ptr_b), _lib.ptr(beta_b), plan.n, _lib.ptr(sb), st), "egnn_segment_sum_f32")
         beta_a_a = beta_a[plan.perm_a].contiguous()
         _lib.check(lib.egnn_segment_sum_f32(_lib.ptr(plan.ptr_a), _lib.ptr(beta_a_a), plan.n, _lib.ptr(sa), st), "egnn_segment_sum_f32")
-        gF = gF + gF2 + (sa + sb).unsqueeze(1) * F
-        return gF, None, None
+        vals = torch.cat([alpha, sa + sb])[plan.perm_bd]
+        gF, _ = ops.spmm_raw(plan.by_bd.set_value(vals), F, "sum", addend=gF2)
+        return ops._fresh(gF), None, None
 
 
 class _LspLoss(torch.autograd.Function):
