@@ -205,6 +205,46 @@ class NceProbe:
         return dict(calls=len(self.records), flops=flops, secs=secs)
 
 
+class EdgeProbe:
+    """Brackets the LSP forward entry points (egnn_edge_sim_f32 x 2 + egnn_lsp_loss_fwd_f32: per-edge similarities of gathered rows and the
+    segment-softmax criterion, HBM / L2-bound gather work) with HIP events on the launch stream, for the `roofline_edges` object."""
+    NAMES = ("egnn_edge_sim_f32", "egnn_lsp_loss_fwd_f32")
+
+    def __init__(self, lib):
+        self.lib, self.records, self.active = lib, [], False
+        self._orig = {n: getattr(lib, n) for n in self.NAMES}
+
+    def __enter__(self):
+        def wrap(name):
+            orig = self._orig[name]
+
+            def wrapped(*a):
+                if not self.active:
+                    return orig(*a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = orig(*a)
+                e1.record()
+                self.records.append((name, int(a[2]) if name == "egnn_edge_sim_f32" else 0, e0, e1))
+                return rc
+            return wrapped
+        for n in self.NAMES:
+            setattr(self.lib, n, wrap(n))
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self._orig.items():
+            setattr(self.lib, n, f)
+
+    def summary(self):
+        if not self.records:
+            return None
+        secs = sum(a.elapsed_time(b) * 1e-3 for _, _, a, b in self.records)
+        steps = sum(1 for r in self.records if r[0] == "egnn_lsp_loss_fwd_f32")
+        widths = sorted({r[1] for r in self.records if r[0] == "egnn_edge_sim_f32"})
+        return dict(secs=secs, steps=max(steps, 1), widths=widths)
+
+
 def cpu_baseline(args, data, hp):
     """The CPU oracle on the host cores: same inputs, same epoch definition, bounded number of epochs."""
     import oracle.models as OM
@@ -560,8 +600,11 @@ def lib_sha16() -> str:
 
 
 def measured_traffic(name):
-    """HBM-side bytes per aggregation call from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in their own rocprofv3 runs
-    over the lab driver by tools/evidence.sh, calibrated on a copy of known size; profiles/<name>).  The file records the
+    """L2-miss FABRIC bytes per aggregation call from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in their own rocprofv3 runs
+    over the lab driver by tools/evidence.sh, calibrated on a copy of known size; profiles/<name>).  FETCH_SIZE counts the requests
+    that leave L2 -- served by the 256 MiB Infinity Cache or by HBM alike (MI355X_MICROARCH.md, HBM section): for the arxiv-sized
+    source matrix (173 MB, inside the cache) this is fabric traffic, not HBM traffic; for the MAG-sized one (993 MB) it is HBM
+    (profiles/r04_gather_footprint.txt has the split).  The file records the
     stamp of the kernel sources it was measured on (lib_sha16): a file from other kernels is STALE and is not reported
     (traffic = null) -- the counters cannot be collected inside this process (rocprofv3 wraps the process it profiles)."""
     tj = os.path.join(ROOT, "profiles", name)
@@ -575,8 +618,9 @@ def measured_traffic(name):
     have = lib_sha16()
     if j.get("lib_sha16") != have:
         return None, f"profiles/{name} was measured on another build (lib_sha16 {j.get('lib_sha16')}, this run {have}): stale, not reported"
-    return float(j["hbm_bytes_per_call"]), (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same entry points on this very build (lib_sha16 {have}), separate "
-                                            f"passes, calibrated on a 256 MiB copy (profiles/{name}; measured off-line by tools/evidence.sh, not in this run)")
+    return float(j["hbm_bytes_per_call"]), (f"L2-miss fabric bytes (Infinity-Cache hits included; the 173 MB source matrix fits the 256 MiB cache): rocprofv3 --pmc "
+                                            f"FETCH_SIZE / WRITE_SIZE of the same entry points on this very build (lib_sha16 {have}), separate passes, calibrated "
+                                            f"on a 256 MiB copy (profiles/{name}; measured off-line by tools/evidence.sh, not in this run)")
 
 
 def cap_cpu_threads(local_world: int = 1) -> int:
@@ -697,9 +741,10 @@ def main():
     # per-kernel events, so the roofline objects are measured on `probe_epochs` eager epochs of the same problem right after
     # it; without a graph they are measured over the timed region itself
     n_probe = args.probe_epochs if graphed is not None else args.steps
-    with SpmmProbe(ops) as probe, NceProbe(_egnn_lib.load()) as nce_probe:
+    with SpmmProbe(ops) as probe, NceProbe(_egnn_lib.load()) as nce_probe, EdgeProbe(_egnn_lib.load()) as edge_probe:
         probe.active = True
         nce_probe.active = True
+        edge_probe.active = args.training == "lpw"
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(n_probe):
@@ -716,6 +761,7 @@ def main():
         eager_elapsed = time.perf_counter() - t1
         probe.active = False
         nce_probe.active = False
+        edge_probe.active = False
     if graphed is None:
         elapsed, losses, accs = eager_elapsed, l2, a2
     K = MODEL["hidden"]
@@ -764,6 +810,24 @@ def main():
                              mfma_tflops_issued=round(tf * (6.0 if split else 1.0), 1),
                              flops_per_step=int(nsum["flops"] / max(1, n_probe)),
                              ms_per_step=round(1e3 * nsum["secs"] / max(1, n_probe), 3), calls_timed=nsum["calls"])
+    roofline_edges = None
+    esum = edge_probe.summary()
+    if esum and edge_index is not None:
+        # SURVEY 8(d) row "LSP lpw fwd": compulsory bytes = E_tr (8 index bytes) + 4 N_tr (Ds + Dt) -- every train row of both feature
+        # matrices once; the gathered figure E_tr * 4 * 2 * (Ds + Dt) is what the kernels actually request (mostly L2 / Infinity-Cache hits)
+        E_tr, n_tr = int(edge_index.shape[1]), int(d.split_idx["train"].numel())
+        Ds, Dt = MODEL["hidden"], int(d.teacher_out_feat.shape[1])
+        alg = E_tr * 8 + 4 * n_tr * (Ds + Dt)
+        gathered = E_tr * 4 * 2 * (Ds + Dt)
+        per_step = esum["secs"] / esum["steps"]
+        roofline_edges = dict(bound="hbm", kernel="edge_sim_kernel x 2 (student [N,256], teacher [N,750]) + lsp_loss_fwd_kernel "
+                                                  "(egnn_edge_sim_f32, egnn_lsp_loss_fwd_f32): the LSP forward of one step",
+                              achieved=round(alg / per_step / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(alg / per_step / 1e9 / HBM_PEAK_GBS, 4),
+                              algorithmic_bytes_per_step=alg, us_per_step=round(per_step * 1e6, 1), steps_timed=esum["steps"],
+                              gathered_bytes_per_step=gathered, gather_GBs=round(gathered / per_step / 1e9, 1),
+                              note="E_tr = %d train-subgraph edges, N_tr = %d; rows are gathered 7.5 times each on average, so the request "
+                                   "stream (gather_GBs) is what the memory system serves, from L2 / Infinity Cache for the most part" % (E_tr, n_tr),
+                              traffic=None)
     roofline_local = None
     if not args.no_local_roofline:
         try:
@@ -794,7 +858,7 @@ def main():
                     adam=os.environ.get("EGNN_ADAM", "fused"),
                     memoise_first_layer_aggregation=os.environ.get("EGNN_GCN_MEMOISE_AX", "0") == "1",
                     cache_constant_row_gathers=os.environ.get("EGNN_CACHE_CONST_ROWS", "0") == "1"),
-        roofline=roofline, roofline_local=roofline_local, roofline_mfma=roofline_mfma, cpu_baseline=cpu, parity=parity,
+        roofline=roofline, roofline_local=roofline_local, roofline_mfma=roofline_mfma, roofline_edges=roofline_edges, cpu_baseline=cpu, parity=parity,
         launch=graph_note,
         eager=dict(epochs_per_s=round(n_probe / eager_elapsed, 3), epochs=n_probe,
                    note="eager launches with per-kernel event brackets (where the roofline objects are measured)"),
