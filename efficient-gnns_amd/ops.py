@@ -209,6 +209,7 @@ class _SpMM(torch.autograd.Function):
         else:
             y, arg = spmm_raw(adj, x, reduce, bias=b)
         ctx.adj, ctx.reduce, ctx.has_bias = adj, reduce, bias is not None
+        ctx.tap_box = getattr(x, "_egnn_tap", None)     # x is a tapped tensor (grad_tap): its gradient may be completed in place, see _fresh
         if arg is not None:
             ctx.save_for_backward(arg)
         if stats is None:
@@ -237,14 +238,16 @@ class _SpMM(torch.autograd.Function):
                                                        _lib.ptr(gy), gy.stride(0), _lib.ptr(gx), gx.stride(0), _lib.stream())
             _lib.check(rc, "egnn_spmm_csr_max_bwd_f32")
         gb = colsum(gy) if ctx.has_bias and ctx.needs_input_grad[3] else None
-        return _fresh(gx), None, None, gb, None, None
+        return _fresh(gx, ctx.tap_box), None, None, gb, None, None
 
 
-def _fresh(g):
-    """Marks a gradient this package has just allocated in a backward: nobody else holds it yet, so ``_GradTap`` may add
-    its row-compact pieces into it in place (a gradient without the mark is copied first)."""
-    if g is not None:
-        g._egnn_fresh = True
+def _fresh(g, tap_box):
+    """Marks a gradient this package has just allocated in a backward FOR the tapped tensor whose box is ``tap_box``: nobody else
+    holds it yet, so that tensor's ``_GradTap`` may add its row-compact pieces into it in place.  The mark names the box: a gradient
+    that reaches a tap through a pass-through node (an add, a view: the same tensor object can then also be a sibling input's
+    gradient) was produced for some OTHER tensor, carries no mark for this box, and is copied first."""
+    if g is not None and tap_box is not None:
+        g._egnn_fresh_for = tap_box
     return g
 
 
@@ -445,6 +448,7 @@ class _MatMul(torch.autograd.Function):
     def forward(ctx, x, w, bias, transposed):
         ctx.save_for_backward(x, w)
         ctx.transposed, ctx.has_bias = transposed, bias is not None
+        ctx.tap_box = getattr(x, "_egnn_tap", None)
         return gemm_raw(x, w, False, transposed, bias)
 
     @staticmethod
@@ -458,7 +462,7 @@ class _MatMul(torch.autograd.Function):
             gw = gemm_raw(gy, x, True, False) if ctx.transposed else gemm_raw(x, gy, True, False)  # dW = dY^T X | X^T dY
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = colsum(gy)
-        return _fresh(gx), gw, gb, None
+        return _fresh(gx, ctx.tap_box), gw, gb, None
 
 
 def matmul(x: Tensor, w: Tensor, bias: Tensor | None = None) -> Tensor:
@@ -474,6 +478,7 @@ class _SageLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, adj, wl, bl, wr, reduce, narrow):
+        ctx.tap_box = getattr(x, "_egnn_tap", None)
         x = _rowmajor(x)
         r = gemm_raw(x, wr, False, True)                                   # lin_r(x)
         if narrow:
@@ -513,7 +518,7 @@ class _SageLayer(torch.autograd.Function):
             if need_x:
                 d_agg = gemm_raw(g, wl, False, False)
                 gx = spmm_raw(adj.t(), d_agg, "sum", src_scale=scale, addend=gemm_raw(g, wr, False, False))[0]   # A^T d_agg + g W_r
-        return _fresh(gx), None, gwl, gbl, gwr, None, None
+        return _fresh(gx, ctx.tap_box), None, gwl, gbl, gwr, None, None
 
 
 def sage_layer(x: Tensor, adj, lin_l, lin_r, reduce: str, narrow: bool) -> Tensor:
@@ -551,10 +556,10 @@ class _GradTap(torch.autograd.Function):
             g = torch.zeros(shape, dtype=dtype, device=dev)
         elif g.is_sparse or not g.is_contiguous():
             g = g.to_dense().contiguous() if g.is_sparse else g.contiguous()
-        elif not getattr(g, "_egnn_fresh", False):
+        elif getattr(g, "_egnn_fresh_for", None) is not ctx.box:
             # autograd forbids changing a grad_output in place: a consumer whose backward hands its own grad_output through
             # (add, a view, identity) or a caller-supplied gradient would be corrupted.  Only a tensor one of this package's
-            # backward functions has just allocated (``_fresh``) is added into directly.
+            # backward functions has just allocated FOR THIS tapped tensor (``_fresh`` names the box) is added into directly.
             g = g.clone()
         for idx, rows in pend:   # unique ids: a plain read-modify-write of those rows, deterministic
             rows = _rowmajor(rows)

@@ -97,6 +97,7 @@ class _EdgeSim(torch.autograd.Function):
     @staticmethod
     def forward(ctx, F, plan: EdgePlan, kernel: str):
         _lib.require_gpu(F)
+        ctx.tap_box = getattr(F, "_egnn_tap", None)
         F = ops._rowmajor(F)
         E = plan.E
         sim = torch.empty(E, dtype=torch.float32, device=F.device)
@@ -128,7 +129,7 @@ class _EdgeSim(torch.autograd.Function):
         _lib.check(lib.egnn_segment_sum_f32(_lib.ptr(plan.ptr_a), _lib.ptr(beta_a_a), plan.n, _lib.ptr(sa), st), "egnn_segment_sum_f32")
         vals = torch.cat([alpha, sa + sb])[plan.perm_bd]
         gF, _ = ops.spmm_raw(plan.by_bd.set_value(vals), F, "sum", addend=gF2)
-        return ops._fresh(gF), None, None
+        return ops._fresh(gF, ctx.tap_box), None, None
 
 
 class _LspLoss(torch.autograd.Function):

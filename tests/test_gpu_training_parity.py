@@ -303,3 +303,33 @@ def test_edge_similarity_behind_a_padded_pitch(kernel):
     ref = torch.exp(-0.5 * ((a - b) ** 2).sum(1)) if kernel == "rbf" else torch.nn.functional.cosine_similarity(a, b)
     assert float((padded.double().cpu() - ref).abs().max()) <= 2e-6
     assert float((padded - dense).abs().max()) <= 1e-6
+
+
+def test_grad_tap_does_not_edit_a_gradient_produced_for_another_tensor():
+    """a gradient tagged "fresh" by a package backward that reaches the tap through a pass-through node (``tap(h) + c``
+    fed to ops.matmul: AddBackward hands the SAME tensor to h and to c) must not be completed in place -- the sibling c would receive
+    the projection head's rows as well.  The tag names the tap it was produced for (ops._fresh)."""
+    gen = torch.Generator().manual_seed(4)
+    n, C = 3000, 64
+    h0 = torch.randn(n, C, generator=gen).to(DEV).requires_grad_()
+    c0 = torch.randn(n, C, generator=gen).to(DEV).requires_grad_()
+    W = torch.randn(C, 32, generator=gen).to(DEV)
+    w2 = torch.randn(16, C, generator=gen).to(DEV)
+    idx = torch.randperm(n, generator=gen)[:1000].to(DEV)
+    gy = torch.randn(n, 32, generator=gen).to(DEV)
+    h = ops.grad_tap(h0 * 1.0)
+    z = ops.linear_rows(h, idx, w2)
+    y = ops.matmul(h + c0, W)
+    torch.autograd.backward([y, z], [gy, torch.ones_like(z)])
+    dense = gy @ W.t()
+    want_h = dense.clone()
+    want_h[idx] += torch.ones(1000, 16, device=DEV) @ w2
+    assert float((c0.grad - dense).abs().max()) <= 1e-4 * float(dense.abs().max()), "the sibling's gradient received the tap rows"
+    assert float((h0.grad - want_h).abs().max()) <= 1e-4 * float(want_h.abs().max())
+    # and the direct consumer still completes its own fresh gradient in place (no clone): same values
+    h0.grad = None
+    h = ops.grad_tap(h0 * 1.0)
+    z = ops.linear_rows(h, idx, w2)
+    y = ops.matmul(h, W)
+    torch.autograd.backward([y, z], [gy, torch.ones_like(z)])
+    assert float((h0.grad - want_h).abs().max()) <= 1e-4 * float(want_h.abs().max())
