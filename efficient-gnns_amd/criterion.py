@@ -48,13 +48,9 @@ def _bce_term(logits, labels, rows=None):
     return bce_with_logits_pair(logits, labels, logits.detach())[0]
 
 
-# The classification term the criteria below use: class-index cross entropy (arxiv / MAG scripts); ``ppi_criteria()`` evaluates them
-# with the multi-label BCE term instead.  A module-level switch rather than a parameter: the public signatures stay the reference's.
-_CLS = _ce_term
-
-
 # The public criteria keep the reference's signatures exactly.  Each has a ``rows_*`` twin (an extension; the reference has no
-# such thing) that takes the FULL [N, .] ``logits`` / ``labels`` (/ ``teacher_logits``) plus the row ids: the classification / KD
+# such thing) that takes the FULL [N, .] ``logits`` / ``labels`` (/ ``teacher_logits``) plus the row ids (and, keyword-only, the
+# classification term ``_cls``: class-index cross entropy for the arxiv / MAG scripts, multi-label BCE for the PPI ones): the classification / KD
 # terms are evaluated on those rows inside the kernels -- the ``[train_idx]`` gathers of gnn.py:109-110,121 and the zero-fill +
 # scatter of their backward never exist.  ``models.train_step`` uses the twins.
 
@@ -81,9 +77,9 @@ def fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000):
     return rows_fitnet_criterion(logits, labels, feat, teacher_feat, beta, rows=None)
 
 
-def rows_fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=None):
+def rows_fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=None, *, _cls=None):
     """``fitnet_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
-    loss_cls = _CLS(logits, labels, rows)
+    loss_cls = (_cls or _ce_term)(logits, labels, rows)
     loss_aux = ops.fitnet_loss(feat, teacher_feat)
     return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 
@@ -93,9 +89,9 @@ def at_criterion(logits, labels, feat, teacher_feat, beta=1000):
     return rows_at_criterion(logits, labels, feat, teacher_feat, beta, rows=None)
 
 
-def rows_at_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=None):
+def rows_at_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=None, *, _cls=None):
     """``at_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
-    loss_cls = _CLS(logits, labels, rows)
+    loss_cls = (_cls or _ce_term)(logits, labels, rows)
     loss_aux = ops.at_loss(feat, teacher_feat)
     return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 
@@ -105,13 +101,13 @@ def gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, m
     return rows_gpw_criterion(logits, labels, feat, teacher_feat, kernel, beta, max_samples, rows=None)
 
 
-def rows_gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, max_samples=8192, rows=None, presampled=False):
+def rows_gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, max_samples=8192, rows=None, presampled=False, *, _cls=None):
     """``gpw_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call).
     ``presampled``: ``feat`` / ``teacher_feat`` already are the sampled rows (the caller made the draw with ``_sample_rows``)."""
     from .ops_pairwise import gsp_loss
     if kernel not in ("cosine", "poly", "l2", "rbf"):
         raise NotImplementedError
-    loss_cls = _CLS(logits, labels, rows)
+    loss_cls = (_cls or _ce_term)(logits, labels, rows)
     idx = None if presampled else _sample_rows(feat.shape[0], max_samples, feat.device)
     loss_aux = gsp_loss(feat, teacher_feat, idx, kernel)
     return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
@@ -122,12 +118,12 @@ def lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="cosine
     return rows_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel, beta, criterion, rows=None)
 
 
-def rows_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="cosine", beta=100, criterion="kld", rows=None):
+def rows_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="cosine", beta=100, criterion="kld", rows=None, *, _cls=None):
     """``lpw_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
     from .ops_edge import lsp_loss
     if kernel not in ("cosine", "poly", "l2", "rbf") or criterion not in ("kld", "mse"):
         raise NotImplementedError
-    loss_cls = _CLS(logits, labels, rows)
+    loss_cls = (_cls or _ce_term)(logits, labels, rows)
     loss_aux = lsp_loss(feat, teacher_feat, edge_index, kernel, criterion)
     return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 
@@ -137,10 +133,10 @@ def nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max
     return rows_nce_criterion(logits, labels, feat, teacher_feat, beta, nce_T, max_samples, rows=None)
 
 
-def rows_nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max_samples=8192, rows=None, presampled=False):
+def rows_nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max_samples=8192, rows=None, presampled=False, *, _cls=None):
     """``nce_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call).
     ``presampled``: as in ``rows_gpw_criterion``."""
-    loss_cls = _CLS(logits, labels, rows)
+    loss_cls = (_cls or _ce_term)(logits, labels, rows)
     idx = None if presampled else _sample_rows(feat.shape[0], max_samples, feat.device)
     fhat = ops.gather_normalize(feat, idx)
     that = ops.gather_normalize(teacher_feat, idx)
@@ -148,46 +144,31 @@ def rows_nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075
     return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 
 
-class _PpiCriteria:
-    """The auxiliary criteria of /root/reference/ppi_pyg/criterion.py:21-146 -- the same feature losses as the arxiv scripts with
-    the multi-label BCE-with-logits classification term (the file differs from arxiv_pyg/criterion.py in that line only)."""
-
-    @staticmethod
-    def _with_bce(fn):
-        def wrapped(*a, **kw):
-            global _CLS
-            prev, _CLS = _CLS, _bce_term
-            try:
-                return fn(*a, **kw)
-            finally:
-                _CLS = prev
-        wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
-        return wrapped
-
-
+# The auxiliary criteria of /root/reference/ppi_pyg/criterion.py:21-146: the same feature losses as the arxiv scripts with the
+# multi-label BCE-with-logits classification term (the file differs from arxiv_pyg/criterion.py in that line only).
 def ppi_fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000):
     """ppi_pyg/criterion.py:21-36."""
-    return _PpiCriteria._with_bce(fitnet_criterion)(logits, labels, feat, teacher_feat, beta)
+    return rows_fitnet_criterion(logits, labels, feat, teacher_feat, beta, _cls=_bce_term)
 
 
 def ppi_at_criterion(logits, labels, feat, teacher_feat, beta=1000):
     """ppi_pyg/criterion.py:39-54."""
-    return _PpiCriteria._with_bce(at_criterion)(logits, labels, feat, teacher_feat, beta)
+    return rows_at_criterion(logits, labels, feat, teacher_feat, beta, _cls=_bce_term)
 
 
 def ppi_gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, max_samples=8192):
     """ppi_pyg/criterion.py:57-92."""
-    return _PpiCriteria._with_bce(gpw_criterion)(logits, labels, feat, teacher_feat, kernel, beta, max_samples)
+    return rows_gpw_criterion(logits, labels, feat, teacher_feat, kernel, beta, max_samples, _cls=_bce_term)
 
 
 def ppi_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="cosine", beta=100, criterion="kld"):
     """ppi_pyg/criterion.py:95-126."""
-    return _PpiCriteria._with_bce(lpw_criterion)(logits, labels, feat, teacher_feat, edge_index, kernel, beta, criterion)
+    return rows_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel, beta, criterion, _cls=_bce_term)
 
 
 def ppi_nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max_samples=8192):
     """ppi_pyg/criterion.py:129-149."""
-    return _PpiCriteria._with_bce(nce_criterion)(logits, labels, feat, teacher_feat, beta, nce_T, max_samples)
+    return rows_nce_criterion(logits, labels, feat, teacher_feat, beta, nce_T, max_samples, _cls=_bce_term)
 
 
 def ppi_kd_criterion(logits, labels, teacher_logits, alpha=0.5, T=1):

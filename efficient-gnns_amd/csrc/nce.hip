@@ -580,12 +580,11 @@ int launch_bwd3(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag
 }
 
 template <int AMAJ>
-void launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag_off, const float* lse, float shift, bool expz,
+int launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag_off, const float* lse, float shift, bool expz,
                 const float* Bm, int64_t P, int64_t ldb, const float* Im, int64_t ldi, float coef, const float* g, float* C,
                 int64_t ldc, bool vec4, float* ws, hipStream_t st) {
   if (nce3_takes<AMAJ>(M, Kd, P, ldz, Z, expz, vec4, ws)) {
-    launch_bwd3<AMAJ>(Z, ldz, M, Kd, diag_off, lse, shift, Bm, P, ldb, Im, ldi, coef, g, C, ldc, ws, st);
-    return;
+    return launch_bwd3<AMAJ>(Z, ldz, M, Kd, diag_off, lse, shift, Bm, P, ldb, Im, ldi, coef, g, C, ldc, ws, st);   // a refused big-LDS opt-in / failed launch is the caller's error
   }
   const int64_t tiles_n = (P + 127) / 128;
   const int64_t t128 = ((M + 127) / 128) * tiles_n;
@@ -608,15 +607,16 @@ void launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag
     hipLaunchKernelGGL(nce_row_weight_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, Bm, ldb, lse, shift, Kd, P, wx);
     if (split) rc = launch_dyn_lds<nce_bwd_kernel<128, AMAJ, true, true, false, true>>(grid, dim3(256), shm_split, st, EGNN_NCE_BWD_ARGS(wx, P));
     else rc = launch_dyn_lds<nce_bwd_kernel<128, AMAJ, true, true, false, false>>(grid, dim3(256), shm_f32, st, EGNN_NCE_BWD_ARGS(wx, P));
-    if (rc != EGNN_OK) return;
+    if (rc != EGNN_OK) return rc;
     if (nsplit > 1) {
       const int64_t rb = (M * P + 255) / 256;
       hipLaunchKernelGGL((nce_bwd_reduce_kernel<AMAJ, true>), dim3((unsigned)(rb < 4096 ? rb : 4096)), dim3(256), 0, st, ws, nsplit, M, P, Kd,
                          diag_off, lse, shift, Im, ldi, coef, g, C, ldc);
     }
-    return;
+    return EGNN_OK;
   }
-#define EGNN_NCE_BWD(BM_, V, E, S_) launch_dyn_lds<nce_bwd_kernel<BM_, AMAJ, V, E, true, S_>>(grid, dim3(256), S_ ? shm_split : (size_t)TileShape<BM_, 128>::SMEM_FLOATS * 4, st, EGNN_NCE_BWD_ARGS(Bm, ldb))
+#define EGNN_NCE_BWD(BM_, V, E, S_) rc_main = launch_dyn_lds<nce_bwd_kernel<BM_, AMAJ, V, E, true, S_>>(grid, dim3(256), S_ ? shm_split : (size_t)TileShape<BM_, 128>::SMEM_FLOATS * 4, st, EGNN_NCE_BWD_ARGS(Bm, ldb))
+  int rc_main = EGNN_OK;
   if (split) {
     if (vec4) { if (expz) EGNN_NCE_BWD(128, true, true, true); else EGNN_NCE_BWD(128, true, false, true); }
     else { if (expz) EGNN_NCE_BWD(128, false, true, true); else EGNN_NCE_BWD(128, false, false, true); }
@@ -629,12 +629,14 @@ void launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag
   }
 #undef EGNN_NCE_BWD
 #undef EGNN_NCE_BWD_ARGS
+  if (rc_main != EGNN_OK) return rc_main;
   if (nsplit > 1) {
     const int64_t blocks = (M * P + 255) / 256;
     const dim3 rgrid((unsigned)(blocks < 4096 ? blocks : 4096));
     if (expz) hipLaunchKernelGGL((nce_bwd_reduce_kernel<AMAJ, true>), rgrid, dim3(256), 0, st, ws, nsplit, M, P, Kd, diag_off, lse, shift, Im, ldi, coef, g, C, ldc);
     else hipLaunchKernelGGL((nce_bwd_reduce_kernel<AMAJ, false>), rgrid, dim3(256), 0, st, ws, nsplit, M, P, Kd, diag_off, lse, shift, Im, ldi, coef, g, C, ldc);
   }
+  return EGNN_OK;
 }
 
 }  // namespace
@@ -708,8 +710,10 @@ extern "C" int egnn_nce_block_bwd_f32(const float* fhat, int64_t ld_f, const flo
   const bool expz = nce_unit_form(tau, unit_rows);   // what the forward stored in Z
   const float shift = (1.f / tau) * 1.0001f;         // == nce_shift(inv_tau) of the forward
   // dfhat [Sr,P] = scale g (P - I) that ;  dthat [Sc,P] = scale g (P - I)^T fhat
-  if (dfhat) launch_bwd<KMAJOR>(Z, Sc, Sr, Sc, diag_off, lse, shift, expz, that, P, ld_t, that, ld_t, scale, g, dfhat, ld_df, vec4, ws, st);
-  if (dthat) launch_bwd<MNMAJOR>(Z, Sc, Sc, Sr, diag_off, lse, shift, expz, fhat, P, ld_f, fhat, ld_f, scale, g, dthat, ld_dt, vec4, ws, st);
+  int rc = EGNN_OK;
+  if (dfhat) rc = launch_bwd<KMAJOR>(Z, Sc, Sr, Sc, diag_off, lse, shift, expz, that, P, ld_t, that, ld_t, scale, g, dfhat, ld_df, vec4, ws, st);
+  if (rc == EGNN_OK && dthat) rc = launch_bwd<MNMAJOR>(Z, Sc, Sc, Sr, diag_off, lse, shift, expz, fhat, P, ld_f, fhat, ld_f, scale, g, dthat, ld_dt, vec4, ws, st);
+  if (rc != EGNN_OK) return rc;
   return egnn_launch_status();
 }
 

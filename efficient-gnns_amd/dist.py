@@ -1183,7 +1183,9 @@ class ShardedGraphedEpoch:
             _, correct = sharded_evaluate_tensors(model, prob)
             return rep, correct
         self._body = body
-        with self._installed():
+        from . import _cache
+        # cached structures the captured launches read through raw pointers stay alive with this object (_cache.pinning)
+        with self._installed(), _cache.pinning() as self._pinned:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):

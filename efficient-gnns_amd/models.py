@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import _lib
+from . import _cache, _lib
 from . import criterion as C
 from . import ops
 from .nn import DGLGATConv, GATConv, GCNConv, RGCNConv, SAGEConv
@@ -155,37 +155,25 @@ def make_projection(in_dim, proj_dim):
     return ProjectionHead(in_dim, proj_dim)
 
 
-_ROW_CACHE: dict = {}
+_ROW_CACHE = _cache.TensorKeyedCache(capacity=8)
 _CACHE_CONST_ROWS = os.environ.get("EGNN_CACHE_CONST_ROWS", "0") == "1"  # opt-in (the reference re-gathers every step)
 
 
 def _const_rows(t, idx):
     """``t[idx]`` for a constant tensor (teacher artefacts): the reference re-gathers 273 MB every step (gnn.py:155);
-    the rows do not change within a run, so the gather is done once per (tensor, index) identity + version."""
+    the rows do not change within a run, so (opt-in) the gather is done once per (tensor, index) identity + version."""
     if t.requires_grad or not _CACHE_CONST_ROWS:
         return t[idx]
-    key = (t.data_ptr(), t._version, tuple(t.shape), idx.data_ptr(), idx._version, idx.numel())
-    hit = _ROW_CACHE.get(key)
-    if hit is None:
-        if len(_ROW_CACHE) > 8:
-            _ROW_CACHE.clear()
-        hit = _ROW_CACHE[key] = (t[idx], t, idx)   # holds t / idx: their addresses cannot be reused while the entry lives
-    return hit[0]
+    return _ROW_CACHE.get((t, idx), (), lambda: t[idx])
 
 
-_GLOBAL_EDGES: dict = {}
+_GLOBAL_EDGES = _cache.TensorKeyedCache(capacity=8)
 
 
 def _global_edges(edge_index, train_idx):
     """``train_idx[edge_index]``: the edge list of the train-induced subgraph (relabelled, gnn.py:274) in node ids of the full graph.
-    Built once per (edge list, index) identity + version; the entry keeps both alive."""
-    key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape), train_idx.data_ptr(), train_idx._version, train_idx.numel())
-    hit = _GLOBAL_EDGES.get(key)
-    if hit is None:
-        if len(_GLOBAL_EDGES) > 4:
-            _GLOBAL_EDGES.clear()
-        hit = _GLOBAL_EDGES[key] = (train_idx[edge_index].contiguous(), edge_index, train_idx)
-    return hit[0]
+    Built once per (edge list, index) identity + version; the entry keeps both alive (_cache.py)."""
+    return _GLOBAL_EDGES.get((edge_index, train_idx), (), lambda: train_idx[edge_index].contiguous())
 
 
 def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_logits, hp,
@@ -338,6 +326,16 @@ class GraphedEpoch:
             out, accs = evaluate_tensors(model, x, adj_t, y, split_idx)
             return losses, out, accs
         self._body = body
+        # every cached structure the captured launches read through raw pointers (edge plans, composed edge lists, inverse row maps,
+        # normalised adjacencies) stays alive with this object, whatever the caches evict later (_cache.pinning)
+        self._pin_ctx = _cache.pinning()
+        self._pinned = self._pin_ctx.__enter__()
+        try:
+            self._capture(body, dev, warmup)
+        finally:
+            self._pin_ctx.__exit__(None, None, None)
+
+    def _capture(self, body, dev, warmup):
         # warm-up on a side stream (allocator, optimizer state, cached structures), as graph capture requires
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))

@@ -47,29 +47,10 @@ def _gcn_norm_edge_index(edge_index: Tensor, n: int) -> SparseTensor:
     return _adj_from_edge_index(torch.stack([src2, dst2]), n, val)
 
 
-class _TensorKeyedCache:
-    """Memo for integer preprocessing keyed on the identity of index tensors (storage address, version counter, shape).
-    Every entry keeps a reference to its key tensors: while an entry lives, the allocator cannot hand the same address
-    to a different tensor, so an address match really means the same data."""
-
-    def __init__(self, capacity: int = 64):
-        self.capacity, self.store = capacity, {}
-
-    @staticmethod
-    def _key(tensors, extra):
-        return tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) for t in tensors) + tuple(extra)
-
-    def get(self, tensors, extra, build):
-        key = self._key(tensors, extra)
-        hit = self.store.get(key)
-        if hit is None:
-            if len(self.store) >= self.capacity:
-                self.store.clear()
-            hit = self.store[key] = (tuple(tensors), build())
-        return hit[1]
+from ._cache import TensorKeyedCache as _TensorKeyedCache  # noqa: E402  (LRU, pins entries a captured graph reads: _cache.py)
 
 
-_GCN_NORM_CACHE = _TensorKeyedCache()
+_GCN_NORM_CACHE = _TensorKeyedCache(capacity=64)
 
 
 class GCNConv(nn.Module):
@@ -208,7 +189,7 @@ class SAGEConv(nn.Module):
         return f"SAGEConv({self.in_channels}, {self.out_channels}, aggr={self.aggr})"
 
 
-_GAT_STRUCT_CACHE = _TensorKeyedCache()
+_GAT_STRUCT_CACHE = _TensorKeyedCache(capacity=64)
 
 
 class GATConv(nn.Module):

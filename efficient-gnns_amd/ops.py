@@ -6,7 +6,7 @@ import os
 import torch
 from torch import Tensor
 
-from . import _lib
+from . import _cache, _lib
 
 _REDUCE = {"sum": 0, "add": 0, "mean": 1, "max": 2}
 _OVERLAP_HEAVY_ROWS = os.environ.get("EGNN_SPMM_OVERLAP", "1") != "0"
@@ -568,23 +568,20 @@ class _GradTap(torch.autograd.Function):
         return g, None
 
 
-_SPLIT_IDS: dict = {}
+_SPLIT_IDS = _cache.TensorKeyedCache(capacity=16)
 
 
 def split_ids(split_idx: dict, n: int, device) -> Tensor:
     """int8 [n]: 0 / 1 / 2 for the train / valid / test nodes of ``split_idx``, -1 elsewhere (a node listed twice keeps the
     later split); built once per split dict (keyed on the identity and version of its index tensors, which the entry keeps alive)."""
     names = ("train", "valid", "test")
-    key = (n, str(device)) + tuple((split_idx[k].data_ptr(), split_idx[k]._version, split_idx[k].numel()) for k in names)
-    hit = _SPLIT_IDS.get(key)
-    if hit is None:
-        if len(_SPLIT_IDS) > 8:
-            _SPLIT_IDS.clear()
+
+    def build():
         sid = torch.full((n,), -1, dtype=torch.int8, device=device)
         for i, k in enumerate(names):
             sid[split_idx[k].to(device)] = i
-        hit = _SPLIT_IDS[key] = (sid, tuple(split_idx[k] for k in names))
-    return hit[0]
+        return sid
+    return _SPLIT_IDS.get(tuple(split_idx[k] for k in names), (n, str(device)), build)
 
 
 def split_accuracy(logits: Tensor, y: Tensor, split_idx: dict, counts: bool = False) -> Tensor:
@@ -1042,21 +1039,17 @@ def bn_act(x: Tensor, bn: "torch.nn.BatchNorm1d", relu: bool = True, p: float = 
 
 
 _TAIL_ONE_PASS = os.environ.get("EGNN_TAIL_ONE_PASS", "1") == "1"   # A/B switch: _BnActLinear.forward as one kernel
-_INV_ROWS: dict = {}
+_INV_ROWS = _cache.TensorKeyedCache(capacity=16)
 
 
 def _inverse_rows(idx: Tensor, n: int) -> Tensor:
     """int32 [n]: position of row r in the unique id list ``idx``, -1 where r is not listed.  Built once per index tensor (identity +
-    version + length: the train split does not change between steps), the entry keeps ``idx`` alive."""
-    key = (idx.data_ptr(), idx._version, idx.numel(), n, str(idx.device))
-    hit = _INV_ROWS.get(key)
-    if hit is None:
-        if len(_INV_ROWS) > 8:
-            _INV_ROWS.clear()
+    version + length: the train split does not change between steps); the entry keeps ``idx`` alive (_cache.py)."""
+    def build():
         inv = torch.full((n,), -1, dtype=torch.int32, device=idx.device)
         inv[idx] = torch.arange(idx.numel(), dtype=torch.int32, device=idx.device)
-        hit = _INV_ROWS[key] = (inv, idx)
-    return hit[0]
+        return inv
+    return _INV_ROWS.get((idx,), (n,), build)
 
 
 class _BnActLinear(torch.autograd.Function):

@@ -6,7 +6,7 @@ import os
 import torch
 from torch import Tensor
 
-from . import _lib, ops
+from . import _cache, _lib, ops
 from .sparse import SparseTensor, _ind2ptr
 
 _KERNELS = {"cosine": 0, "poly": 1, "l2": 2, "rbf": 3}
@@ -78,17 +78,12 @@ class EdgePlan:
                                   sparse_sizes=(n, n))
 
 
-_PLANS: dict = {}
+_PLANS = _cache.TensorKeyedCache(capacity=16)
 
 
 def edge_plan(edge_index: Tensor, n: int) -> EdgePlan:
-    key = (edge_index.data_ptr(), edge_index.shape[1], n, edge_index._version)
-    plan = _PLANS.get(key)
-    if plan is None:
-        if len(_PLANS) > 8:
-            _PLANS.clear()
-        plan = _PLANS[key] = EdgePlan(edge_index, n)
-    return plan
+    """The plan of an edge list, built once per edge_index tensor (identity + version); the entry keeps the tensor alive (_cache.py)."""
+    return _PLANS.get((edge_index,), (n,), lambda: EdgePlan(edge_index, n))
 
 
 class _EdgeSim(torch.autograd.Function):
