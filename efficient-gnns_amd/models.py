@@ -20,7 +20,7 @@ from .nn import DGLGATConv, GATConv, GCNConv, RGCNConv, SAGEConv
 from .sparse import SparseTensor
 
 
-_EVAL_BN_FOLD = os.environ.get("EGNN_EVAL_BN_FOLD", "1") == "1"   # A/B switch of the eval-mode BatchNorm fold
+_EVAL_BN_FOLD = True   # (no environment switch any more; tests flip the attribute to compare the fold with the separate normalisation pass)
 _TRAIN_ROWS = os.environ.get("EGNN_TRAIN_ROWS", "1") == "1"       # A/B switch: [train_idx] row picks inside the CE / KD kernels
 _LSP_FULL_ROWS = os.environ.get("EGNN_LSP_FULL_ROWS", "1") == "1"    # A/B switch: LSP on the full tensors through composed edge ids
 _FUSED_TAIL = os.environ.get("EGNN_FUSED_TAIL", "1") == "1"        # A/B switch: ops.bn_act_linear for the last hidden layer of a GCN

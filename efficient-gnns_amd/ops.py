@@ -9,7 +9,7 @@ from torch import Tensor
 from . import _cache, _lib
 
 _REDUCE = {"sum": 0, "add": 0, "mean": 1, "max": 2}
-_OVERLAP_HEAVY_ROWS = os.environ.get("EGNN_SPMM_OVERLAP", "1") != "0"
+_OVERLAP_HEAVY_ROWS = True   # (no environment switch any more; tools/spmm_pmc.py clears the attribute to trace one stream)
 _SIDE_STREAMS: dict = {}
 
 
@@ -1038,7 +1038,6 @@ def bn_act(x: Tensor, bn: "torch.nn.BatchNorm1d", relu: bool = True, p: float = 
     return _BnAct.apply(x, bn.weight, bn.bias, mean, var, bn.eps, relu, drop, seed, use_batch, pick)
 
 
-_TAIL_ONE_PASS = os.environ.get("EGNN_TAIL_ONE_PASS", "1") == "1"   # A/B switch: _BnActLinear.forward as one kernel
 _INV_ROWS = _cache.TensorKeyedCache(capacity=16)
 
 
@@ -1067,7 +1066,7 @@ class _BnActLinear(torch.autograd.Function):
         w = _rowmajor(w)
         lib = _lib.load()
         rc = _lib.EGNN_EALIGN
-        if _TAIL_ONE_PASS and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0:
+        if w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0:
             # one pass over x: h is stored and multiplied by w while its pieces are in registers
             xw = torch.empty(n, w.shape[1], dtype=torch.float32, device=x.device)
             rc = lib.egnn_bn_act_linear_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),

@@ -333,3 +333,15 @@ def test_grad_tap_does_not_edit_a_gradient_produced_for_another_tensor():
     y = ops.matmul(h, W)
     torch.autograd.backward([y, z], [gy, torch.ones_like(z)])
     assert float((h0.grad - want_h).abs().max()) <= 1e-4 * float(want_h.abs().max())
+
+
+def test_locality_order_is_the_same_on_every_device():
+    """dist.locality_order (every rank computes it for itself before the ranges are cut): the GPU result equals the CPU result --
+    a rank-dependent order would shard different problems."""
+    import efficient_gnns_amd.dist as DD
+    d = D.arxiv_like(scale=0.05, seed=1, graph="local")
+    perm_c, before_c, after_c = DD.locality_order(d, 8)
+    perm_g, before_g, after_g = DD.locality_order(d, 8, device=torch.device(DEV))
+    assert before_c == before_g and after_c == after_g
+    assert perm_c is not None and torch.equal(perm_c, perm_g)
+    assert sum(after_c) <= 0.6 * sum(before_c)
