@@ -24,9 +24,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--gnn", default="gcn")
 ap.add_argument("--mode", default="nce")
 ap.add_argument("--static", action="store_true", help="the fixed-capacity sample layout of the multi-rank runs (dist.StaticSample) on this one rank")
-ap.add_argument("--port", type=int, default=29578)
+ap.add_argument("--port", type=int, default=0, help="rendezvous port (0 = any free port: back-to-back runs must not meet a lingering socket)")
 a = ap.parse_args()
 gnn, mode, DEV = a.gnn, a.mode, "cuda"
+if a.port == 0:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        a.port = sk.getsockname()[1]
 dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{a.port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 d = D.arxiv_like(scale=0.02, seed=5)
 hp = dict(alpha=0.9, kd_T=4.0, beta=0.1 if mode == "nce" else 100.0, nce_T=0.075, max_samples=512, kernel="cosine")
