@@ -169,7 +169,8 @@ class SAGEConv(nn.Module):
     def forward(self, x: Tensor, edge_index) -> Tensor:
         if hasattr(edge_index, "aggregate"):  # node-range shard (dist.ShardedAdj)
             agg = edge_index.aggregate(x, self.aggr, valueless=True)
-            return ops.linear(agg, self.lin_l.weight, self.lin_l.bias) + ops.linear(x, self.lin_r.weight, None)
+            # lin_l(agg) + lin_r(x): the second product is added in the first GEMM's store (ops.linear_add)
+            return ops.linear_add(agg, self.lin_l.weight, self.lin_l.bias, ops.linear(x, self.lin_r.weight, None))
         adj = edge_index if isinstance(edge_index, SparseTensor) else _adj_from_edge_index(edge_index, x.shape[0])
         if (_SAGE_FUSED and self.aggr in ("mean", "sum") and x.is_cuda and x.dim() == 2 and self.lin_r.bias is None
                 and adj.nnz() > 0 and adj.sparse_size(0) == adj.sparse_size(1)):

@@ -521,6 +521,35 @@ class _SageLayer(torch.autograd.Function):
         return _fresh(gx, ctx.tap_box), None, gwl, gbl, gwr, None, None
 
 
+class _LinearAdd(torch.autograd.Function):
+    """x @ w^T + bias + addend with the sum formed in the GEMM's store (egnn_gemm_add_f32): SAGEConv's ``lin_l(agg) + lin_r(x)`` on
+    node-range shards, where the aggregation is a collective operator of its own (dist._OverlapAggregate)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, addend):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        ctx.tap_box = getattr(x, "_egnn_tap", None)
+        return gemm_raw(x, w, False, True, bias, addend=addend)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _rowmajor(gy)
+        gx = gemm_raw(gy, w, False, False) if ctx.needs_input_grad[0] else None
+        gw = gemm_raw(gy, x, True, False) if ctx.needs_input_grad[1] else None
+        gb = colsum(gy) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return _fresh(gx, ctx.tap_box), gw, gb, (gy if ctx.needs_input_grad[3] else None)
+
+
+def linear_add(x: Tensor, weight: Tensor, bias: Tensor | None, addend: Tensor) -> Tensor:
+    """F.linear(x, weight, bias) + addend, one store."""
+    if not x.is_cuda or x.shape[0] == 0:
+        _lib.on_gpu(x)
+        return torch.nn.functional.linear(x, weight, bias) + addend
+    return _LinearAdd.apply(x, weight, bias, addend)
+
+
 def sage_layer(x: Tensor, adj, lin_l, lin_r, reduce: str, narrow: bool) -> Tensor:
     return _SageLayer.apply(x, adj, lin_l.weight, lin_l.bias, lin_r.weight, reduce, narrow)
 
