@@ -1367,7 +1367,7 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
     if want_graph and ShardedGraphedEpoch.capturable(world, args.training):
         err = None
         try:
-            graphed = ShardedGraphedEpoch(model, prob, opt, args.training, hp, sp, tp, warmup=max(args.warmup, 3))
+            graphed = ShardedGraphedEpoch(model, prob, opt, args.training, hp, sp, tp, warmup=3)
             graph_note = "hipGraph replay of the sharded train step + eval, collectives captured (dist.ShardedGraphedEpoch)"
         except Exception as e:  # noqa: BLE001
             err = f"{type(e).__name__}: {str(e)[:200]}"
@@ -1385,9 +1385,8 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
     elif want_graph:
         graph_note = f"eager launches: the sharded '{args.training}' step is not capturable"
     epoch = graphed.step if graphed is not None else eager_epoch
-    if graphed is None:
-        for _ in range(args.warmup):
-            eager_epoch()
+    for _ in range(args.warmup):      # the W untimed warm-up steps: of the program that is timed (replays, or eager epochs)
+        epoch()
     # The interpreter holds ~170k long-lived objects after the torch / RCCL imports; a full (generation-2) collection
     # walks all of them (~40 ms) and the per-step autograd / collective bookkeeping triggers one every few steps.
     # Freezing the survivors of set-up keeps later collections proportional to the per-step garbage.
