@@ -99,3 +99,69 @@ def test_capture_audit_flags_long_reductions_only():
     with CaptureAudit(any_device=True) as b:
         (x * 2).view(1000, 100).sum(1)
     b.check("unit test")
+
+
+def test_tensor_keyed_cache_is_lru_and_pins_inside_a_capture_block():
+    """efficient-gnns_amd/_cache.py: identity-keyed entries, least-recently-used eviction one at a time, and values handed out inside
+    ``pinning()`` stay referenced by the caller's list after the cache has evicted them (what a captured hipGraph needs)."""
+    import gc
+    import weakref
+    from efficient_gnns_amd._cache import TensorKeyedCache, pinning
+    c = TensorKeyedCache(capacity=2)
+    keys = [torch.arange(4) + i for i in range(4)]
+    built = []
+
+    def make(i):
+        def build():
+            built.append(i)
+            return torch.full((3,), float(i))
+        return build
+    a = c.get((keys[0],), (7,), make(0))
+    assert c.get((keys[0],), (7,), make(0)) is a and built == [0]            # hit: same object, not rebuilt
+    assert c.get((keys[0],), (8,), make(10)) is not a                         # another extra key: another entry
+    c.get((keys[1],), (7,), make(1))                                          # capacity 2: evicts the least recently used = (keys[0], 7)
+    assert len(c) == 2 and built == [0, 10, 1]
+    c.get((keys[0],), (7,), make(0))
+    assert built == [0, 10, 1, 0], "the evicted entry is rebuilt"
+    keys[1].add_(1)                                                          # an in-place edit changes the version: not the same data
+    c.get((keys[1],), (7,), make(11))
+    assert built[-1] == 11
+    with pinning() as pinned:
+        v = c.get((keys[2],), (), make(2))
+        ref = weakref.ref(v)
+    for i in range(3):                                                       # push it out of the cache
+        c.get((keys[3],), (i,), make(30 + i))
+    del v
+    gc.collect()
+    assert ref() is not None, "a value handed out inside pinning() must outlive its eviction"
+    del pinned
+    gc.collect()
+    assert ref() is None
+
+
+def test_dropin_accel_keeps_torch_paths_for_cpu_inputs_and_restores():
+    """dropin/accel.py on the CPU: CPU tensors keep torch's own BatchNorm1d / Linear (same values as before enable()), disable() restores
+    the original methods; enable() twice is harmless."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("egnn_dropin_accel_cpu", os.path.join(ROOT, "efficient-gnns_amd", "dropin", "accel.py"))
+    accel = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(accel)
+    bn0, lin0 = torch.nn.BatchNorm1d.forward, torch.nn.Linear.forward
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU())
+    x = torch.randn(32, 8)
+    want = net(x)
+    accel.enable()
+    accel.enable()
+    try:
+        assert accel.enabled() and torch.nn.BatchNorm1d.forward is not bn0
+        net2 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU())
+        net2.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
+        net2[1].running_mean.zero_(); net2[1].running_var.fill_(1.0); net2[1].num_batches_tracked.zero_()
+        got = net2(x)
+    finally:
+        accel.disable()
+    assert torch.nn.BatchNorm1d.forward is bn0 and torch.nn.Linear.forward is lin0 and not accel.enabled()
+    assert torch.allclose(got, want, atol=1e-6)
