@@ -63,8 +63,9 @@ def parse():
     ap.add_argument("--no-parity", action="store_true", help="skip the full-size GPU-vs-oracle parity step")
     ap.add_argument("--parity-trajectory-steps", type=int, default=3,
                     help="replayed steps with dropout 0.5 compared against the oracle with the same masks injected (0 = skip)")
-    ap.add_argument("--repeat-blocks", type=int, default=4,
-                    help="further blocks of --steps replays timed after the contract's block (spread of the measurement; 0 = none)")
+    ap.add_argument("--repeat-blocks", type=int, default=-1,
+                    help="further blocks of --steps replays timed after the contract's block (spread of the measurement; 0 = none; "
+                         "default: as many as fill ~2 s, at least 4, at most 50)")
     ap.add_argument("--graph", default="on", choices=["on", "off", "auto"],
                     help="on: the epoch (train step + eval) is captured once as a hipGraph and replayed (models.GraphedEpoch) -- a "
                          "capture failure ends the run with a non-zero exit code; off: eager launches; auto: replay if the capture "
@@ -733,7 +734,8 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         # the contract's block is the one above; further blocks of the same length show the spread of the measurement
-        for _ in range(args.repeat_blocks):
+        n_blocks = args.repeat_blocks if args.repeat_blocks >= 0 else max(4, min(50, int(np.ceil(2.0 / max(elapsed, 1e-3)))))
+        for _ in range(n_blocks):
             torch.cuda.synchronize()
             tb = time.perf_counter()
             for _ in range(args.steps):
@@ -869,6 +871,7 @@ def main():
         last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs],
         reference_loop=ref_loop,
         repeat_blocks_ms_per_step=[round(v, 3) for v in block_ms],   # further blocks of `steps` replays after the contract's block
+        repeat_blocks_median_ms_per_step=(round(float(np.median(block_ms)), 3) if block_ms else None),
     )
     if cpu:
         out["speedup_vs_cpu_baseline"] = round(out["value"] / cpu["value"], 1)
