@@ -9,6 +9,9 @@ kernels, and ``GraphedEpoch`` refuses to capture a step that still contains a lo
 """
 from __future__ import annotations
 
+import os
+import warnings
+
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
@@ -49,6 +52,10 @@ class CaptureAudit(TorchDispatchMode):
         return out
 
     def check(self, what: str) -> None:
+        if self.flagged and os.environ.get("EGNN_GRAPH_AUDIT", "1") == "0":
+            # the reproducer of the finding (tools/checks/lsp_trace.py VARIANT=refs GRAPH=1 SYNC=1) captures such a step on purpose
+            warnings.warn(f"{what}: long torch reductions in a captured step (EGNN_GRAPH_AUDIT=0): {self.flagged[:4]}")
+            return
         if self.flagged:
             ops = ", ".join(f"aten.{n} over {k} elements of {s}" for n, k, s in self.flagged[:6])
             raise LongReductionInCapture(

@@ -1,6 +1,7 @@
 """Bisect: bench.py's own set-up of the SAGE + LSP problem, then GraphedEpoch replays, with switches that swap single set-up
 steps for the ones tools/checks/lsp_trace.py uses (where the replayed loss_aux is right)."""
 import os, sys, types
+os.environ.setdefault("EGNN_GRAPH_AUDIT", "0")   # reproducer of the r04 finding: captures steps with long torch reductions on purpose
 import numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)

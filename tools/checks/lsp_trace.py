@@ -10,6 +10,8 @@ import math
 import os
 import sys
 
+os.environ.setdefault("EGNN_GRAPH_AUDIT", "0")   # the torch-reduction variants below are captured on purpose (the finding's reproducer)
+
 import numpy as np
 import torch
 
