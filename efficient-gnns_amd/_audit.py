@@ -62,3 +62,35 @@ class CaptureAudit(TorchDispatchMode):
                 f"{what}: the step contains long torch reductions ({ops}); their multi-block form relies on a memset node that does not "
                 "take effect reliably in replayed hipGraphs on this stack -- use the package's fixed-order kernels (ops.colsum, "
                 "ops_edge._LspLoss, ...) or run the step with eager launches")
+
+
+_HIP_NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event", 7: "event_record"}
+
+
+def graph_node_kinds(graph: "torch.cuda.CUDAGraph") -> dict:
+    """{node type: count, "edges": n, "chain": bool} of a captured graph that was created with ``keep_graph=True`` -- read through the
+    HIP runtime (hipGraphGetNodes / hipGraphNodeGetType / hipGraphGetEdges).  The shipped epochs are chains of kernel nodes only; a
+    ``memset`` node is what a long torch reduction leaves behind (see the module docstring)."""
+    import collections
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    g = ctypes.c_void_p(graph.raw_cuda_graph())
+    n = ctypes.c_size_t(0)
+    if hip.hipGraphGetNodes(g, None, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    nodes = (ctypes.c_void_p * n.value)()
+    hip.hipGraphGetNodes(g, nodes, ctypes.byref(n))
+    kinds = collections.Counter()
+    for nd in nodes:
+        t = ctypes.c_int(-1)
+        hip.hipGraphNodeGetType(ctypes.c_void_p(nd), ctypes.byref(t))
+        kinds[_HIP_NODE_TYPES.get(t.value, str(t.value))] += 1
+    ne = ctypes.c_size_t(0)
+    hip.hipGraphGetEdges(g, None, None, ctypes.byref(ne))
+    src, dst = (ctypes.c_void_p * ne.value)(), (ctypes.c_void_p * ne.value)()
+    hip.hipGraphGetEdges(g, src, dst, ctypes.byref(ne))
+    indeg, outdeg = collections.Counter(dst), collections.Counter(src)
+    chain = ne.value == n.value - 1 and all(indeg[x] <= 1 and outdeg[x] <= 1 for x in nodes)
+    out = dict(kinds)
+    out.update(edges=ne.value, chain=bool(chain))
+    return out

@@ -353,12 +353,20 @@ class GraphedEpoch:
                     body()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
+        inspect_nodes = os.environ.get("EGNN_GRAPH_NODE_CHECK", "0") == "1"    # tests: read the captured graph back and insist on kernel nodes only
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True) if inspect_nodes else torch.cuda.CUDAGraph()
         with self._installed():
             self._refresh()
             torch.cuda.synchronize(dev)
             with torch.cuda.graph(self.graph):
                 self.losses, self.out, self.accs = body()
+        self.node_kinds = None
+        if inspect_nodes:
+            from ._audit import LongReductionInCapture, graph_node_kinds
+            self.node_kinds = graph_node_kinds(self.graph)
+            if self.node_kinds.get("memset", 0) or not self.node_kinds["chain"]:
+                raise LongReductionInCapture(f"GraphedEpoch: the captured graph is not a chain of kernel nodes: {self.node_kinds}")
+            self.graph.instantiate()
         torch.cuda.synchronize(dev)
         self._refresh()                                        # randomness of the first replay
 

@@ -345,3 +345,31 @@ def test_locality_order_is_the_same_on_every_device():
     assert before_c == before_g and after_c == after_g
     assert perm_c is not None and torch.equal(perm_c, perm_g)
     assert sum(after_c) <= 0.7 * sum(before_c)     # (>= 40 % at 17 k nodes: tests/test_dist_gloo.py; this 8 k-node graph has 2 communities per range)
+
+
+@pytest.mark.parametrize("gnn,mode", CASES + [("gcn", "supervised")])
+def test_captured_epoch_graph_is_a_chain_of_kernel_nodes(small, gnn, mode, monkeypatch):
+    """The captured epoch read back through the HIP runtime (hipGraphGetNodes / NodeGetType / GetEdges, _audit.graph_node_kinds):
+    kernel nodes only, one chain -- no memset node (what ATen's multi-block reductions put there: DESIGN.md 4.1), no memcpy node."""
+    monkeypatch.setenv("EGNN_GRAPH_NODE_CHECK", "1")
+    data, d = small
+    hp = dict(HP, beta=100.0 if mode in ("lpw", "gpw") else 0.1)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    m = (PM.GCN if gnn == "gcn" else PM.SAGE)(data.num_features, 128, data.num_classes, 3, 0.5).to(DEV)
+    sp = tp = None
+    params = list(m.parameters())
+    if mode in ("nce", "gpw"):
+        sp, tp = PM.make_projection(128, hp["proj_dim"]).to(DEV), PM.make_projection(750, hp["proj_dim"]).to(DEV)
+        params += list(sp.parameters()) + list(tp.parameters())
+    opt = torch.optim.Adam(params, lr=0.01, fused=True, capturable=True)
+    ei = None
+    if mode == "lpw":
+        ei = subgraph(d.split_idx["train"], torch.stack(d.adj_t.coo()[:2]), relabel_nodes=True, num_nodes=data.num_nodes)[0]
+    ge = PM.GraphedEpoch(m, d.x, d.adj_t, d.y, d.split_idx["train"], opt, mode, hp, d.teacher_out_feat, d.teacher_logits, sp, tp,
+                         edge_index=ei, split_idx=d.split_idx, warmup=2)
+    kinds = ge.node_kinds
+    assert kinds is not None and kinds["chain"] and kinds.get("kernel", 0) > 50, kinds
+    assert set(kinds) <= {"kernel", "edges", "chain"}, kinds
+    losses, accs = ge.step()
+    assert all(np.isfinite(v) for v in losses)
