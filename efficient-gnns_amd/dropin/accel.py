@@ -11,6 +11,10 @@ everything else takes the original path -- at this package's kernels:
     two passes with the bias gradient of the layer in front formed on the way;
   * ``Linear.forward``       -> ``ops.linear`` (the split-bf16 / f32 MFMA GEMMs of the package).
 
+  * ``torch.optim.Adam(...)`` without an explicit ``fused`` / ``foreach`` choice over float GPU parameters -> ``fused=True``: the same
+    update (gnn.py:308-312 passes parameter groups and ``lr`` only) in one launch per group instead of PyTorch's default
+    multi-tensor chain (~0.3 ms per step on the headline problem).
+
 Same values within the fp32 tolerance of the package's parity tests; ``disable()`` restores torch's methods.  ``launch.py`` enables
 it unless ``--plain-torch-modules`` is given.
 """
@@ -44,6 +48,18 @@ def enable() -> None:
         return lin_forward(self, x)
     torch.nn.BatchNorm1d.forward = fast_bn
     torch.nn.Linear.forward = fast_linear
+    adam_init = torch.optim.Adam.__init__
+    _orig["adam"] = adam_init
+
+    def fused_adam_init(self, params, *args, **kwargs):
+        # materialise first: the script hands over generators (``model.parameters()``) inside its group dicts
+        params = [dict(g, params=list(g["params"])) if isinstance(g, dict) else g for g in list(params)]
+        if "fused" not in kwargs and "foreach" not in kwargs and len(args) < 6:     # (fused / foreach are keyword-only in practice)
+            flat = [p for g in params for p in (g["params"] if isinstance(g, dict) else [g])]
+            if flat and all(isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == torch.float32 for p in flat):
+                kwargs["fused"] = True
+        adam_init(self, params, *args, **kwargs)
+    torch.optim.Adam.__init__ = fused_adam_init
 
 
 def disable() -> None:
@@ -51,3 +67,4 @@ def disable() -> None:
         return
     torch.nn.BatchNorm1d.forward = _orig.pop("bn")
     torch.nn.Linear.forward = _orig.pop("lin")
+    torch.optim.Adam.__init__ = _orig.pop("adam")

@@ -233,6 +233,20 @@ def test_dropin_accel_modules_match_torch():
         got = run()
         bn3 = torch.nn.BatchNorm1d(4).to(DEV)
         assert bn3(torch.randn(2, 4, 5, device=DEV)).shape == (2, 4, 5)          # 3-D input: torch's own path
+        # torch.optim.Adam over GPU parameters without an explicit choice -> the fused implementation, same update as torch's default
+        lin_a, lin_b = torch.nn.Linear(16, 8).to(DEV), torch.nn.Linear(16, 8).to(DEV)
+        lin_b.load_state_dict(lin_a.state_dict())
+        opt_a = torch.optim.Adam([{"params": lin_a.parameters(), "lr": 0.01}])
+        assert opt_a.defaults.get("fused") is True and len(opt_a.param_groups[0]["params"]) == 2
+        opt_b = torch.optim.Adam([{"params": lin_b.parameters(), "lr": 0.01}], foreach=True)       # an explicit choice is respected
+        assert not opt_b.defaults.get("fused")
+        xx = torch.randn(32, 16, device=DEV)
+        for _ in range(3):
+            for lin, opt in ((lin_a, opt_a), (lin_b, opt_b)):
+                opt.zero_grad()
+                lin(xx).square().mean().backward()
+                opt.step()
+        assert float((lin_a.weight - lin_b.weight).abs().max()) <= 1e-6
         assert torch.nn.Linear(3, 2)(torch.randn(4, 3)).shape == (4, 2)         # CPU input: torch's own path
     finally:
         accel.disable()
