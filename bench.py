@@ -206,6 +206,41 @@ class NceProbe:
         return dict(calls=len(self.records), flops=flops, secs=secs)
 
 
+class GspProbe:
+    """Brackets the GSP forward entry point (egnn_gsp_fwd_f32: the student and teacher Gram tiles + the squared difference, f32-input
+    MFMA) with HIP events on the launch stream, for the `roofline_gsp` object of `--training gpw`."""
+
+    def __init__(self, lib):
+        self.lib, self.records, self.active = lib, [], False
+        self._orig = lib.egnn_gsp_fwd_f32
+
+    def __enter__(self):
+        orig = self._orig
+
+        def wrapped(*a):
+            if not self.active:
+                return orig(*a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = orig(*a)
+            e1.record()
+            Ps, Pt, S = int(a[2]), int(a[5]), int(a[6])
+            self.records.append((2.0 * S * S * (Ps + Pt), S, Ps, Pt, e0, e1))      # SURVEY 8(d): 2 S^2 (P_s + P_t)
+            return rc
+        self.lib.egnn_gsp_fwd_f32 = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.lib.egnn_gsp_fwd_f32 = self._orig
+
+    def summary(self):
+        if not self.records:
+            return None
+        flops = sum(r[0] for r in self.records)
+        secs = sum(r[4].elapsed_time(r[5]) * 1e-3 for r in self.records)
+        return dict(calls=len(self.records), flops=flops, secs=secs, S=self.records[0][1], Ps=self.records[0][2], Pt=self.records[0][3])
+
+
 class EdgeProbe:
     """Brackets the LSP forward entry points (egnn_edge_sim_f32 x 2 + egnn_lsp_loss_fwd_f32: per-edge similarities of gathered rows and the
     segment-softmax criterion, HBM / L2-bound gather work) with HIP events on the launch stream, for the `roofline_edges` object."""
@@ -753,10 +788,12 @@ def main():
     # per-kernel events, so the roofline objects are measured on `probe_epochs` eager epochs of the same problem right after
     # it; without a graph they are measured over the timed region itself
     n_probe = args.probe_epochs if graphed is not None else args.steps
-    with SpmmProbe(ops) as probe, NceProbe(_egnn_lib.load()) as nce_probe, EdgeProbe(_egnn_lib.load()) as edge_probe:
+    with SpmmProbe(ops) as probe, NceProbe(_egnn_lib.load()) as nce_probe, EdgeProbe(_egnn_lib.load()) as edge_probe, \
+            GspProbe(_egnn_lib.load()) as gsp_probe:
         probe.active = True
         nce_probe.active = True
         edge_probe.active = args.training == "lpw"
+        gsp_probe.active = args.training == "gpw"
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(n_probe):
@@ -774,6 +811,7 @@ def main():
         probe.active = False
         nce_probe.active = False
         edge_probe.active = False
+        gsp_probe.active = False
     if graphed is None:
         elapsed, losses, accs = eager_elapsed, l2, a2
     K = MODEL["hidden"]
@@ -840,6 +878,16 @@ def main():
                               note="E_tr = %d train-subgraph edges, N_tr = %d; rows are gathered 7.5 times each on average, so the request "
                                    "stream (gather_GBs) is what the memory system serves, from L2 / Infinity Cache for the most part" % (E_tr, n_tr),
                               traffic=None)
+    roofline_gsp = None
+    gsum = gsp_probe.summary()
+    if gsum:
+        tf = gsum["flops"] / gsum["secs"] / 1e12
+        roofline_gsp = dict(bound="mfma", kernel="gsp_fwd_kernel (egnn_gsp_fwd_f32): student + teacher Gram tiles and the squared difference of "
+                                                 "the similarity matrices, the GSP forward of one step", achieved=round(tf, 1), peak=157.3,
+                            unit="TFLOP/s (fp32-input MFMA)", frac=round(tf / 157.3, 4), flops_per_call=gsum["flops"] / gsum["calls"],
+                            us_per_call=round(gsum["secs"] / gsum["calls"] * 1e6, 1), calls_timed=gsum["calls"],
+                            shape=dict(S=gsum["S"], P_student=gsum["Ps"], P_teacher=gsum["Pt"]),
+                            note="the backward (two GEMMs on the stored weight matrices) runs on the split-bf16 pipeline through egnn_gemm_f32")
     roofline_local = None
     if not args.no_local_roofline:
         try:
@@ -870,7 +918,7 @@ def main():
                     adam=os.environ.get("EGNN_ADAM", "fused"),
                     memoise_first_layer_aggregation=os.environ.get("EGNN_GCN_MEMOISE_AX", "0") == "1",
                     cache_constant_row_gathers=os.environ.get("EGNN_CACHE_CONST_ROWS", "0") == "1"),
-        roofline=roofline, roofline_local=roofline_local, roofline_mfma=roofline_mfma, roofline_edges=roofline_edges, cpu_baseline=cpu, parity=parity,
+        roofline=roofline, roofline_local=roofline_local, roofline_mfma=roofline_mfma, roofline_edges=roofline_edges, roofline_gsp=roofline_gsp, cpu_baseline=cpu, parity=parity,
         launch=graph_note,
         eager=dict(epochs_per_s=round(n_probe / eager_elapsed, 3), epochs=n_probe,
                    note="eager launches with per-kernel event brackets (where the roofline objects are measured)"),
