@@ -955,9 +955,6 @@ class FlatGrads:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
-    def intact(self) -> bool:
-        return True
-
     def zero(self):
         """Before ``backward``: unset the gradients (no kernel)."""
         for p in self.params:
@@ -979,7 +976,7 @@ class FlatGrads:
 
 def _flat_grads_of(optimizer) -> FlatGrads:
     fg = getattr(optimizer, "_egnn_flat_grads", None)
-    if fg is None or not fg.intact():
+    if fg is None:
         fg = FlatGrads([p for g in optimizer.param_groups for p in g["params"]])
         optimizer._egnn_flat_grads = fg
     return fg
