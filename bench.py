@@ -737,6 +737,8 @@ def main():
         ei = torch.stack(d.adj_t.coo()[:2])
         edge_index = subgraph(d.split_idx["train"], ei, relabel_nodes=True, num_nodes=d.num_nodes)[0]
     parity = None if args.no_parity else parity_check(args, data, d, device, hp, PM)
+    # the other untimed GPU leg: the reference's own loop through dropin/ (own model, own optimizer; restores every hook it installs)
+    ref_loop = reference_loop(args, d, device, hp, epochs=args.reference_epochs) if args.reference_epochs > 0 else None
     seed_all(args.seed)
     model, sp, tp, opt = build_problem(PM, d, device, args, hp)
 
@@ -895,7 +897,6 @@ def main():
         except Exception as e:  # noqa: BLE001  (a secondary object must not take the headline line down)
             roofline_local = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
     cpu = cpu_baseline(args, data, hp) if args.cpu_epochs > 0 else None
-    ref_loop = reference_loop(args, d, device, hp, epochs=args.reference_epochs) if args.reference_epochs > 0 else None
 
     out = dict(
         metric="training epochs/sec, ogbn-arxiv 3-layer GCN student + G-CRD, 1/2/4/8 MI355X",
