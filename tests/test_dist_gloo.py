@@ -345,8 +345,11 @@ def _bench_worker(rank, world, port, path, workload="arxiv", overlap="1"):
     _patch_ops_with_oracle()
     import efficient_gnns_amd.dist as DD
     workload, _, training = workload.partition("-")          # "arxiv-gpw": the arxiv workload with another loss
-    args = types.SimpleNamespace(seed=0, scale=0.004 if workload == "arxiv" else 0.0006, gnn="gcn", training=training or "nce", warmup=1,
-                                 steps=2, workload=workload)
+    graph_kind = "chunglu"
+    if training == "local":                                   # "arxiv-local": the community graph (ids shuffled): ranges cut from the community order
+        training, graph_kind = "", "local"
+    args = types.SimpleNamespace(seed=0, scale=(0.02 if graph_kind == "local" else 0.004) if workload == "arxiv" else 0.0006, gnn="gcn",
+                                 training=training or "nce", warmup=1, steps=2, workload=workload, graph_kind=graph_kind)
     hp = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=128, proj_dim=16, kernel="rbf")
     cfg = dict(hidden=32, layers=3 if workload == "arxiv" else 2, dropout=0.5, lr=0.01)
     lines = []
@@ -365,7 +368,7 @@ def _bench_worker(rank, world, port, path, workload="arxiv", overlap="1"):
 
 
 @pytest.mark.parametrize("workload,world,overlap", [("arxiv", 2, "1"), ("arxiv", 2, "0"), ("mag", 2, "1"), ("mag", 4, "1"),
-                                                    ("arxiv-gpw", 2, "1"), ("arxiv-lpw", 2, "1")])
+                                                    ("arxiv-gpw", 2, "1"), ("arxiv-lpw", 2, "1"), ("arxiv-local", 4, "1")])
 def test_bench_entry_point_runs_sharded_and_prints_contract_json(tmp_path, workload, world, overlap):
     """bench.py's multi-rank entry (dist.bench_main) over gloo: the headline workload with and without the halo / compute
     overlap, and BASELINE.json configs[4] (MAG-shaped graph, SAGE-mean + logit KD) on 2 and 4 node-range shards."""
@@ -386,6 +389,10 @@ def test_bench_entry_point_runs_sharded_and_prints_contract_json(tmp_path, workl
     assert out["n_gpus"] == world and out["scaling"] == "strong" and out["value"] > 0 and "workload" in out["config"]
     assert ("mag" in out["config"]["workload"]) == (workload == "mag")   # ("arxiv-gpw" etc. are arxiv workloads)
     assert all(np.isfinite(out["last_losses"]))
+    order = out["config"]["node_order"]
+    assert "halo_rows_per_rank_as_given" in order and len(order["halo_rows_per_rank_as_given"]) == world
+    if workload == "arxiv-local":    # locality found: the ranges were cut from the community order and the halo shrank
+        assert order["order"].startswith("community order") and order["halo_rows_change"] < -0.1, order    # (-19 % on this 3.4 k-node graph)
 
 
 def _plan_worker(rank, world, port, q):
