@@ -438,3 +438,46 @@ def test_index_helpers_of_the_fused_paths_on_host():
     keep = member[ei[0]] & member[ei[1]]
     assert glob.shape == sub.shape and torch.equal(glob, ei[:, keep])
     assert PM._global_edges(sub, idx) is glob
+
+
+def test_ctypes_table_matches_the_header_argument_by_argument():
+    """Every prototype of include/egnn_hip.h parsed and compared with efficient-gnns_amd/_lib.py::SIGNATURES: same number of arguments,
+    same kind per argument (pointer / int64 / int / float / size_t / uint64) and same return type -- a mismatch would not fail at
+    load time, it would hand the kernels shifted arguments."""
+    import ctypes as C
+    import re
+    from efficient_gnns_amd import _lib
+    src = open(os.path.join(ROOT, "include", "egnn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    protos = re.findall(r"\b(int64_t|size_t|int|const\s+char\s*\*)\s+(egnn_\w+)\s*\(([^;{]*)\)\s*;", src)
+    assert len(protos) >= 80
+    kinds = {"p": C.c_void_p, "i64": C.c_int64, "i32": C.c_int, "f32": C.c_float, "sz": C.c_size_t, "u64": C.c_uint64, "str": C.c_char_p}
+
+    def kind(decl):
+        d = decl.strip()
+        if d in ("void", ""):
+            return None
+        if "*" in d:
+            return "str" if re.match(r"(const\s+)?char\s*\*", d) else "p"
+        t = d.rsplit(" ", 1)[0].replace("const", "").strip() if " " in d else d
+        return {"int64_t": "i64", "int": "i32", "float": "f32", "size_t": "sz", "uint64_t": "u64", "hipStream_t": "p"}[t]
+    seen = set()
+    for ret, name, args in protos:
+        seen.add(name)
+        assert name in _lib.SIGNATURES, f"{name} is declared in the header but missing from the ctypes table"
+        restype, argtypes = _lib.SIGNATURES[name]
+        want = [k for k in (kind(a) for a in args.split(",")) if k is not None]
+        got = []
+        for t in argtypes:
+            got.append(next(k for k, v in kinds.items() if v is t))
+        # char* buffers are bound as c_char_p or c_void_p alike
+        # (c_size_t and c_uint64 are one ctypes class on this platform: one kind)
+        norm = lambda ks: ["p" if k == "str" else ("u64" if k == "sz" else k) for k in ks]
+        assert norm(got) == norm(want), f"{name}: ctypes {got} vs header {want}"
+        rk = {"int": C.c_int, "size_t": C.c_size_t, "int64_t": C.c_int64}.get(ret.strip())
+        if rk is not None:
+            assert restype is rk, f"{name}: return type {restype} vs header {ret}"
+        else:
+            assert restype is C.c_char_p
+    assert seen == set(_lib.SIGNATURES)
