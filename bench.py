@@ -66,10 +66,12 @@ def parse():
     ap.add_argument("--repeat-blocks", type=int, default=-1,
                     help="further blocks of --steps replays timed after the contract's block (spread of the measurement; 0 = none; "
                          "default: as many as fill ~2 s, at least 4, at most 50)")
-    ap.add_argument("--graph", default="on", choices=["on", "off", "auto"],
+    ap.add_argument("--graph", default=None, choices=["on", "off", "auto"],
                     help="on: the epoch (train step + eval) is captured once as a hipGraph and replayed (models.GraphedEpoch) -- a "
                          "capture failure ends the run with a non-zero exit code; off: eager launches; auto: replay if the capture "
-                         "succeeds, eager launches otherwise (the `launch` field says which)")
+                         "succeeds, eager launches otherwise (the `launch` field says which).  Default: on for the single-GPU path; auto for "
+                         "the sharded path (all ranks agree on the outcome; a multi-rank capture has not met real multi-GPU hardware yet, "
+                         "and a line with eager launches is worth more than no line)")
     ap.add_argument("--no-local-roofline", action="store_true", help="skip the second roofline object (aggregation on the reordered community graph)")
     ap.add_argument("--probe-epochs", type=int, default=5, help="eager epochs with per-kernel HIP-event brackets for the roofline objects")
     ap.add_argument("--seed", type=int, default=0)
@@ -708,6 +710,9 @@ def main():
     import efficient_gnns_amd.models as PM
     import efficient_gnns_amd.ops as ops
 
+    sharded_path = world > 1 or args.force_sharded or args.workload == "mag"
+    if args.graph is None:
+        args.graph = "auto" if sharded_path else "on"
     if world > 1 or args.force_sharded or args.workload == "mag":
         if "MASTER_PORT" not in os.environ:
             # one process started by hand (--force-sharded / --workload mag): any free port (a fixed one can collide with the lingering
