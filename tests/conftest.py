@@ -33,6 +33,11 @@ def golden_criterion():
 
 
 @pytest.fixture(scope="session")
+def golden_train_dropout():
+    return np.load(os.path.join(GOLDEN, "train_arxiv_dropout.npz"), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
 def golden_criterion_ppi():
     return np.load(os.path.join(GOLDEN, "criterion_ppi.npz"))
 

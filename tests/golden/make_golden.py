@@ -324,6 +324,64 @@ def make_train_goldens():
     print("train_arxiv.npz:", len(runs), "runs")
 
 
+def make_train_dropout_goldens():
+    """The training regime the benchmark times: the reference's own GCN / SAGE + train() with dropout 0.5.  The masks come from
+    torch's CPU generator inside the reference's F.dropout calls (gnn.py:50,83); `torch.manual_seed(step_seed)` right before the
+    first step fixes them, and the oracle -- which calls F.dropout in the same order on the same shapes -- draws the SAME masks
+    from the same seed.  Pins the oracle's dropout-mode trajectory (oracle/training_parity.py injects the HIP path's masks into it)."""
+    ref = load_ref("arxiv_pyg/gnn.py", "ref_arxiv_gnn")
+    G = tiny_graph(seed=3, n=96, E=420)
+    n, F_in = G["x"].shape
+    C, Dt, H, P, L = 5, G["teacher_out_feat"].shape[1], 16, 12, 3
+    out = {"in_" + k: t2n(v) for k, v in G.items()}
+    out["hp"] = np.array([H, P, L, C], dtype=np.int64)
+    data = types.SimpleNamespace(x=G["x"], y=G["y"], edge_index=G["edge_index"], num_nodes=n)
+    data = osp.ToSparseTensor()(data)
+    data.adj_t = data.adj_t.to_symmetric()
+    rowptr, col, _ = data.adj_t.csr()
+    out["adj_rowptr"], out["adj_col"] = t2n(rowptr), t2n(col)
+    ei = torch.stack(data.adj_t.coo()[:2])
+    edge_index_tr = outils.subgraph(G["train_idx"], ei, relabel_nodes=True)[0]
+    out["train_subgraph_edge_index"] = t2n(edge_index_tr)
+    runs = [("gcn", "nce", dict(beta=0.1)), ("gcn", "kd", {}), ("gcn", "gpw", dict(kernel="cosine", beta=100.0)),
+            ("sage", "lpw", dict(kernel="cosine", beta=100.0)), ("sage", "nce", dict(beta=0.1))]
+    names = []
+    for i, (gnn, mode, kw) in enumerate(runs):
+        tag = f"run{i:02d}"
+        names.append(f"{tag}:{gnn}:{mode}:aux:" + ",".join(f"{k}={v}" for k, v in sorted(kw.items())))
+        a = dict(training=mode, alpha=0.9, kd_T=4.0, beta=0.5, nce_T=0.075, max_samples=24, proj_dim=P, kernel="rbf")
+        a.update(kw)
+        a = argparse.Namespace(**a)
+        torch.manual_seed(300 + i)
+        Model = ref.GCN if gnn == "gcn" else ref.SAGE
+        model = Model(F_in, H, C, L, 0.5)
+        sp = tp = None
+        if mode in ("nce", "gpw"):
+            sp = torch.nn.Sequential(torch.nn.Linear(H, P), torch.nn.BatchNorm1d(P), torch.nn.ReLU())
+            tp = torch.nn.Sequential(torch.nn.Linear(Dt, P), torch.nn.BatchNorm1d(P), torch.nn.ReLU())
+        params = [{"params": model.parameters(), "lr": 0.01}]
+        if sp is not None:
+            params += [{"params": sp.parameters(), "lr": 0.01}, {"params": tp.parameters(), "lr": 0.01}]
+        opt = torch.optim.Adam(params)
+        for k, v in model.state_dict().items():
+            out[f"{tag}__init__model.{k}"] = t2n(v)
+        if sp is not None:
+            for k, v in sp.state_dict().items():
+                out[f"{tag}__init__sproj.{k}"] = t2n(v)
+            for k, v in tp.state_dict().items():
+                out[f"{tag}__init__tproj.{k}"] = t2n(v)
+        torch.manual_seed(700 + i)            # the step seed: fixes the dropout masks of the 4 steps below
+        np.random.seed(700 + i)
+        losses = [ref.train(model, data, G["train_idx"], opt, a, G["teacher_out_feat"], G["teacher_logits"], sp, tp,
+                            edge_index_tr if mode == "lpw" else None) for _ in range(4)]
+        out[f"{tag}__losses"] = np.array(losses, dtype=np.float64)
+        for k, v in model.state_dict().items():
+            out[f"{tag}__final__model.{k}"] = t2n(v)
+    out["run_names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "train_arxiv_dropout.npz"), **out)
+    print("train_arxiv_dropout.npz:", len(runs), "runs")
+
+
 def make_ppi_teacher_goldens():
     """The reference's own GAT / TeacherNet bodies (skip connections, ELU, head averaging, out_feat) in eval mode on a
     small multi-graph-free input; GATConv itself is the oracle restatement (shim)."""
@@ -598,6 +656,7 @@ if __name__ == "__main__":
     install_shims()
     make_criterion_goldens()
     make_train_goldens()
+    make_train_dropout_goldens()
     make_ppi_teacher_goldens()
     make_mag_rgcn_goldens()
     make_ppi_train_goldens()

@@ -191,6 +191,43 @@ def test_train_and_eval_match_reference(golden_train):
             np.testing.assert_allclose(v.numpy(), G[f"{tag}__final__model.{k}"], rtol=1e-4, atol=1e-6, err_msg=f"{name}:{k}")
 
 
+def test_training_with_dropout_matches_reference(golden_train_dropout):
+    """The regime the benchmark times: the reference's own GCN / SAGE + train() with dropout 0.5 (tests/golden/train_arxiv_dropout.npz,
+    generated from arxiv_pyg/gnn.py by make_golden.py::make_train_dropout_goldens).  The oracle calls F.dropout in the reference's order
+    on the same shapes, so the same torch seed gives it the same masks: four steps' losses and the final weights must agree.  This is
+    the oracle the GPU trajectories are compared with after the HIP path's masks are injected (oracle/training_parity.py)."""
+    G = golden_train_dropout
+    for name in G["run_names"]:
+        name = str(name)
+        tag, gnn, mode, kdaux, hp = parse_run(name)
+        H, P, L, C = (int(v) for v in G["hp"])
+        x, y = as_t(G["in_x"]), as_t(G["in_y"])
+        tr = as_t(G["in_train_idx"])
+        tfeat, tlog = as_t(G["in_teacher_out_feat"]), as_t(G["in_teacher_logits"])
+        adj = build_graph(G)
+        model = (OM.GCN if gnn == "gcn" else OM.SAGE)(x.shape[1], H, C, L, 0.5)
+        model.load_state_dict({k.split("model.", 1)[1]: as_t(G[k]) for k in G.files if k.startswith(f"{tag}__init__model.")})
+        sp = tp = None
+        groups = [{"params": model.parameters(), "lr": 0.01}]
+        if mode in ("nce", "gpw"):
+            sp, tp = OM.make_projection(H, P), OM.make_projection(tfeat.shape[1], P)
+            sp.load_state_dict({k.split("sproj.", 1)[1]: as_t(G[k]) for k in G.files if k.startswith(f"{tag}__init__sproj.")})
+            tp.load_state_dict({k.split("tproj.", 1)[1]: as_t(G[k]) for k in G.files if k.startswith(f"{tag}__init__tproj.")})
+            groups += [{"params": sp.parameters(), "lr": 0.01}, {"params": tp.parameters(), "lr": 0.01}]
+        opt = torch.optim.Adam(groups)
+        ei = as_t(G["train_subgraph_edge_index"]) if mode == "lpw" else None
+        i = int(tag[3:])
+        torch.manual_seed(700 + i)
+        np.random.seed(700 + i)
+        losses = [OM.train_step(model, x, adj, y, tr, opt, mode, hp, tfeat, tlog, sp, tp, ei, kd_and_aux=kdaux) for _ in range(4)]
+        np.testing.assert_allclose(np.array(losses), G[f"{tag}__losses"], rtol=2e-5, atol=1e-7, err_msg=name)
+        assert len({tuple(l) for l in losses}) == 4
+        for k, v in model.state_dict().items():
+            if noise_driven(k, L):
+                continue
+            np.testing.assert_allclose(v.numpy(), G[f"{tag}__final__model.{k}"], rtol=2e-4, atol=2e-6, err_msg=f"{name}:{k}")
+
+
 def test_oracle_gat_and_teachernet_match_reference_bodies(golden_ppi_teacher):
     """The PPI teacher models (ppi_pyg/gnn.py GAT :86-117, TeacherNet :23-47) executed from the reference's own file when
     the golden was made; the oracle restatement with the same weights must reproduce logits and out_feat."""
