@@ -1453,7 +1453,8 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
             comm_per_epoch=dict(what="one epoch (train step + eval) traced after the timed region: payload bytes per rank and kind; "
                                      "overlap_window_us = own-column aggregation time the halo exchanges run under, exposed_comm_us = what the "
                                      "compute stream still waits for them afterwards (forward exchanges; HIP events)",
-                                per_rank=per_rank_comm),
+                                per_rank=per_rank_comm,
+                                halo_rows=partition),     # halo rows per rank in the given order / in the community order, and which one was cut
             roofline=roofline, cpu_baseline=None,
             last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs])
     dist.barrier()

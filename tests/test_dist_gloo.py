@@ -390,6 +390,7 @@ def test_bench_entry_point_runs_sharded_and_prints_contract_json(tmp_path, workl
     assert ("mag" in out["config"]["workload"]) == (workload == "mag")   # ("arxiv-gpw" etc. are arxiv workloads)
     assert all(np.isfinite(out["last_losses"]))
     order = out["config"]["node_order"]
+    assert out["comm_per_epoch"]["halo_rows"] == order
     assert "halo_rows_per_rank_as_given" in order and len(order["halo_rows_per_rank_as_given"]) == world
     if workload == "arxiv-local":    # locality found: the ranges were cut from the community order and the halo shrank
         assert order["order"].startswith("community order") and order["halo_rows_change"] < -0.1, order    # (-19 % on this 3.4 k-node graph)
