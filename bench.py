@@ -82,6 +82,10 @@ def parse():
                     help="sharded runs: auto = cut the node ranges from the community order when that lowers the halo; range = node ids as given")
     ap.add_argument("--graph-kind", default="chunglu", choices=["chunglu", "local", "local-sorted"],
                     help="synthetic graph of the sharded runs: chunglu (headline: no locality) | local (community structure, ids shuffled)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="all ranks of a multi-rank launch share cuda:0 and their collectives travel over gloo through host memory "
+                         "(efficient-gnns_amd/hostcomm.py): a FUNCTIONAL run of the sharded step on the real kernels with a non-empty halo "
+                         "on a one-GPU box (eager launches; its epochs/s is not a scaling measurement)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the node-range sharded (multi-GPU) code path even with one rank: RCCL init, halo plan, "
                          "SyncBN, row-block G-CRD -- a 1-GPU check of the path the N>1 runs take")
@@ -692,6 +696,8 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     cap_cpu_threads(int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     hp = dict(HP, max_samples=args.max_samples)
@@ -724,7 +730,11 @@ def main():
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
         import efficient_gnns_amd.dist as dist_mod
-        dist_mod.bench_main(args, hp, MODEL, rank, world, device)   # prints the line on rank 0; ends with barrier + destroy_process_group
+        if args.one_device:
+            from efficient_gnns_amd import hostcomm
+            hostcomm.install()
+            args.graph = "off"        # a host round trip cannot be captured into a hipGraph
+        dist_mod.bench_main(args, hp, MODEL, rank, world, device, backend="gloo" if args.one_device else "nccl")   # prints the line on rank 0; ends with barrier + destroy_process_group
         # leave without the interpreter / static-destructor teardown: communicator background threads have been seen racing it
         # (exit code -6 after all results were delivered) and the launcher reads every rank's exit code
         sys.stdout.flush()

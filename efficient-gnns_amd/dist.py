@@ -754,7 +754,8 @@ class _GatherPadded(torch.autograd.Function):
         gp = g.new_zeros(world * cap, g.shape[1])
         gp.index_copy_(0, perm, g.contiguous())                # perm holds unique positions
         if reduce_grad and world > 1:
-            if dist.get_backend(group) == "nccl":                # every rank only needs ITS block of the sum
+            from . import hostcomm
+            if dist.get_backend(group) == "nccl" or hostcomm.active():   # every rank only needs ITS block of the sum
                 mine = torch.empty(cap, g.shape[1], dtype=g.dtype, device=g.device)
                 dist.reduce_scatter_tensor(mine, gp, group=group)
                 return mine[:m], None, None, None, None, None, None
@@ -964,8 +965,17 @@ class FlatGrads:
         """After ``backward``: one batched copy of all gradients into the flat buffer (a parameter without gradient counts as 0)."""
         if not self.params:
             return
-        pieces = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
-        torch.cat(pieces, out=self.flat)
+        stale = [(p, v) for p, v in zip(self.params, self.views) if p.grad is None or p.grad.data_ptr() != v.data_ptr()]
+        if len(stale) == len(self.params):      # the step's usual case (``zero`` unset every gradient): one batched copy
+            torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params], out=self.flat)
+        else:
+            # some gradients ARE the views already (backward without a preceding ``zero``, a second all_reduce, gradient
+            # accumulation): autograd accumulated into the buffer in place; copy only the others (cat would overlap its output)
+            for p, v in stale:
+                if p.grad is None:
+                    v.zero_()
+                else:
+                    v.copy_(p.grad)
         for p, v in zip(self.params, self.views):
             p.grad = v
 
@@ -975,9 +985,11 @@ class FlatGrads:
 
 
 def _flat_grads_of(optimizer) -> FlatGrads:
+    """The optimizer's FlatGrads, rebuilt when its parameter list changed (``add_param_group`` after the first step)."""
+    params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad]
     fg = getattr(optimizer, "_egnn_flat_grads", None)
-    if fg is None:
-        fg = FlatGrads([p for g in optimizer.param_groups for p in g["params"]])
+    if fg is None or len(fg.params) != len(params) or any(a is not b for a, b in zip(fg.params, params)):
+        fg = FlatGrads(params)
         optimizer._egnn_flat_grads = fg
     return fg
 
@@ -1100,7 +1112,9 @@ def sharded_train_step_tensors(model, prob: ShardedProblem, optimizer, mode: str
         if sub.e_local > 0:
             loss_aux = ops_edge.lsp_loss(f_ext, sub.teacher_ext, sub.edge_index, hp["kernel"]) * (sub.e_local / max(sub.e_global, 1))
         else:
-            loss_aux = f_ext.sum() * 0.0          # no edge here: an exact zero that keeps the exchange's backward in the graph
+            # no edge here: an exact zero that keeps the exchange's backward in the graph -- from ONE row: a reduction over all of
+            # [n_ext, C] is the operator class _audit.CaptureAudit refuses inside a captured step (on this rank only: the ranks diverge)
+            loss_aux = f_ext[:1].sum() * 0.0
         loss = loss_cls + hp["beta"] * loss_aux
     else:
         raise NotImplementedError(f"sharded training mode '{mode}'")
@@ -1197,13 +1211,17 @@ class ShardedGraphedEpoch:
                         body()
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
-            self.graph = torch.cuda.CUDAGraph()
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True)
             self._refresh(require_fit=True)
             torch.cuda.synchronize(dev)
             # thread-local capture mode: the process group's watchdog thread polls the events of the warm-up collectives; in the
             # default (global) mode a call from ANY thread invalidates the capture (seen: abort in capture_end)
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.rep, self.correct = body()
+            # structural guard on every capture (_audit.check_captured_graph): no memset / host node next to the kernels and RCCL's nodes
+            from ._audit import check_captured_graph
+            self.node_kinds = check_captured_graph(self.graph, "ShardedGraphedEpoch", kernels_only=False)
+            self.graph.instantiate()
             torch.cuda.synchronize(dev)
         self._refresh()
 
@@ -1229,6 +1247,8 @@ class ShardedGraphedEpoch:
         return ShardedGraphedEpoch._Install(self)
 
     def _draw(self, require_fit: bool = False):
+        if getattr(self, "_uploaded", None) is not None:
+            self._uploaded.synchronize()     # the previous upload has left the pinned buffers (microseconds: it sits in front of the replay)
         self._overflow = None
         if self.static is not None:
             pick = self.static.draw()
@@ -1251,6 +1271,9 @@ class ShardedGraphedEpoch:
         elif self.n_pick:
             self._pick_dev.copy_(self._pick_host, non_blocking=True)
         self._seed_dev.copy_(self._seed_host, non_blocking=True)
+        # the copies above are only stream-ordered: the host must not rewrite the pinned staging buffers before the DMA has read them
+        self._uploaded = torch.cuda.Event()
+        self._uploaded.record()
 
     def _refresh(self, require_fit: bool = False):
         self._draw(require_fit)
@@ -1312,7 +1335,7 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
     device = torch.device(device)
     on_gpu = device.type == "cuda"
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend, **({"device_id": device} if on_gpu else {}))
+        dist.init_process_group(backend=backend, **({"device_id": device} if on_gpu and backend == "nccl" else {}))
     import random
     for s in (random.seed, np.random.seed, torch.manual_seed):
         s(args.seed)
@@ -1447,7 +1470,9 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
             dtype="f32", data="synthetic",
             config=dict(workload=wl,
                         partitioning=f"node-range shards x{world}: halo all_to_all {'overlapped with the own-column aggregation' if _OVERLAP else '(blocking)'}"
-                                     f" + SyncBN all-reduce + flat grad all-reduce over RCCL",
+                                     f" + SyncBN all-reduce + flat grad all-reduce over "
+                                     + ("RCCL" if backend == "nccl" else f"{backend} (host-staged: all ranks share one GPU, hostcomm.py -- a functional run, "
+                                                                          f"not a scaling measurement)" if on_gpu else backend),
                         mean_halo_rows_per_rank=int(float(halo) / world), node_order=partition),
             launch=graph_note,
             comm_per_epoch=dict(what="one epoch (train step + eval) traced after the timed region: payload bytes per rank and kind; "

@@ -37,13 +37,13 @@ def enable() -> None:
     _orig.update(bn=bn_forward, lin=lin_forward)
 
     def fast_bn(self, x):
-        if (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and self.weight is not None and self.bias is not None
+        if (not _double_backward_wanted(x) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and self.weight is not None and self.bias is not None
                 and self.track_running_stats and self.running_mean is not None and x.shape[0] > 1 and ops._bn_shape_ok(ops._rowmajor(x))):
             return ops.bn_act(x, self, relu=False, p=0.0, training=self.training)
         return bn_forward(self, x)
 
     def fast_linear(self, x):
-        if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and self.weight.dtype == torch.float32 and x.shape[0] > 0:
+        if not _double_backward_wanted(x) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and self.weight.dtype == torch.float32 and x.shape[0] > 0:
             return ops.linear(x, self.weight, self.bias)
         return lin_forward(self, x)
     torch.nn.BatchNorm1d.forward = fast_bn
@@ -54,12 +54,33 @@ def enable() -> None:
     def fused_adam_init(self, params, *args, **kwargs):
         # materialise first: the script hands over generators (``model.parameters()``) inside its group dicts
         params = [dict(g, params=list(g["params"])) if isinstance(g, dict) else g for g in list(params)]
-        if "fused" not in kwargs and "foreach" not in kwargs and len(args) < 6:     # (fused / foreach are keyword-only in practice)
+        # (fused / foreach are keyword-only in practice; ``differentiable=True`` excludes the fused implementation: left to torch)
+        if "fused" not in kwargs and "foreach" not in kwargs and len(args) < 6 and not kwargs.get("differentiable", False):
             flat = [p for g in params for p in (g["params"] if isinstance(g, dict) else [g])]
             if flat and all(isinstance(p, torch.Tensor) and p.is_cuda and p.dtype == torch.float32 for p in flat):
                 kwargs["fused"] = True
         adam_init(self, params, *args, **kwargs)
     torch.optim.Adam.__init__ = fused_adam_init
+
+
+_DOUBLE_BACKWARD = False
+
+
+class double_backward:
+    """``with accel.double_backward():`` -- inside the block BatchNorm1d / Linear take torch's own kernels again: the package's autograd
+    Functions implement first derivatives only (a ``create_graph=True`` backward through them raises)."""
+
+    def __enter__(self):
+        global _DOUBLE_BACKWARD
+        self.prev, _DOUBLE_BACKWARD = _DOUBLE_BACKWARD, True
+
+    def __exit__(self, *exc):
+        global _DOUBLE_BACKWARD
+        _DOUBLE_BACKWARD = self.prev
+
+
+def _double_backward_wanted(x) -> bool:
+    return _DOUBLE_BACKWARD
 
 
 def disable() -> None:

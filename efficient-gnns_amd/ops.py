@@ -1208,11 +1208,17 @@ def _tail_backward(ctx, g_h, g_xw, x, gamma, beta, mean, var, h, w, eps, relu, p
                                                       eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), _lib.ptr(dgamma),
                                                       _lib.ptr(dbeta), _lib.ptr(ws), nws, _lib.stream()), "egnn_bn_act_bwd_reduce_f32")
         sb, sg, inv_count = apply_sums()
-        if n > 0:
+        if n > 0 and cs is not None:
+            # apply half + the column sums of dx (the bias gradient of the conv in front) in the same pass, as on the fused route
+            _lib.check(lib.egnn_bn_act_bwd_apply_colsum_f32(_lib.ptr(x), x.stride(0), _lib.ptr(dh), dh.stride(0), n, C, _lib.ptr(mean),
+                                                            _lib.ptr(var), eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed,
+                                                            _lib.ptr(ctx.seed_dev), _lib.ptr(sb), _lib.ptr(sg), inv_count, _lib.ptr(dx),
+                                                            dx.stride(0), _lib.ptr(cs), _lib.ptr(ws), nws, _lib.stream()),
+                       "egnn_bn_act_bwd_apply_colsum_f32")
+        elif n > 0:
             _lib.check(lib.egnn_bn_act_bwd_apply_f32(_lib.ptr(x), x.stride(0), _lib.ptr(dh), dh.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var),
                                                      eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), _lib.ptr(sb),
                                                      _lib.ptr(sg), inv_count, _lib.ptr(dx), dx.stride(0), _lib.stream()), "egnn_bn_act_bwd_apply_f32")
-            cs = None            # this route forms no column sums of dx: ops.colsum computes them when a bias gradient asks
     if cs is not None:
         dx._egnn_colsum = (cs, dx._version)
     return dx, dgamma, dbeta, gw

@@ -94,6 +94,7 @@ HP = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=96, kernel="rb
 def _reference_run(gnn, mode, steps=3, hp=None):
     HP = dict(globals()["HP"], **(hp or {}))
     HP.pop("static_sigmas", None)
+    HP.pop("host_staged", None)
     import oracle.models as OM
     d = _make_data(train_ids_below=HP.pop("train_ids_below", None))
     torch.manual_seed(0)
@@ -147,6 +148,10 @@ def _worker(rank, world, port, gnn, mode, q, hp=None):
         _patch_ops_with_oracle()
         import efficient_gnns_amd.dist as DD
         import efficient_gnns_amd.models as PM
+        if HP.pop("host_staged", False):   # hostcomm's staging code on host tensors (its device <-> host copies are no-ops here)
+            from efficient_gnns_amd import hostcomm
+            hostcomm._STAGE_HOST_TENSORS = True
+            hostcomm.install()
         d = _make_data(train_ids_below=HP.pop("train_ids_below", None))
         prob = DD.ShardedProblem(d, world, rank, "cpu", None, need_gcn=True)
         if "static_sigmas" in HP:    # the sampled criteria in draw-independent shapes (what ShardedGraphedEpoch captures on > 1 rank)
@@ -481,6 +486,23 @@ def test_static_shape_sampled_criteria_match_the_oracle(gnn, mode, world, max_sa
     losses, logits, accs, n_halo = _spawn(_worker, world, gnn, mode, hp)
     ref_losses, ref_logits, ref_accs = _reference_run(gnn, mode, hp=hp)
     np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("gnn,mode,world", [("gcn", "nce", 3), ("sage", "lpw", 2)])
+def test_host_staged_collectives_carry_the_same_program(gnn, mode, world):
+    """efficient-gnns_amd/hostcomm.py (the transport of the several-ranks-on-one-GPU runs, tests/test_gpu_multirank.py): with its
+    wrappers installed and host tensors routed through the staging code -- all_to_all / all_gather / all_reduce on staged copies,
+    reduce_scatter as all_reduce + this rank's block, async calls completed on return -- the sharded steps reproduce the oracle."""
+    hp = dict(max_samples=96, host_staged=True)
+    if mode == "nce":
+        hp.update(static_sigmas=6.0)        # _GatherPadded's backward takes the reduce_scatter branch under hostcomm
+    if mode == "lpw":
+        hp.update(kernel="cosine", beta=100.0)
+    losses, logits, accs, n_halo = _spawn(_worker, world, gnn, mode, hp)
+    ref_losses, ref_logits, ref_accs = _reference_run(gnn, mode, hp=hp)
+    np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(logits, ref_logits.numpy(), rtol=1e-4, atol=1e-5)
+    assert n_halo > 0
 
 
 @pytest.mark.parametrize("gnn,mode,world,max_samples", [("gcn", "nce", 3, 40), ("gcn", "gpw", 2, 40), ("gcn", "nce", 3, -300)])

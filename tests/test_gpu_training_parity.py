@@ -159,6 +159,32 @@ def test_long_torch_reductions_are_flagged_and_refused():
     np.testing.assert_allclose(cs.cpu().double().numpy(), g.double().sum(0).cpu().numpy(), rtol=1e-5, atol=2e-3)
 
 
+def test_structural_guard_refuses_a_memset_node_the_name_list_does_not_know(small, monkeypatch):
+    """The default-on structural guard (_audit.check_captured_graph): with the operator-name audit switched off (EGNN_GRAPH_AUDIT=0) a
+    step whose criterion ends in ATen's long ``kl_div(..., 'mean')`` -- the memset node of DESIGN.md 4.1 -- is still refused, at capture
+    time, by what the captured graph CONTAINS; nothing is instantiated or replayed."""
+    import efficient_gnns_amd.ops_edge as OE
+    monkeypatch.setenv("EGNN_GRAPH_AUDIT", "0")
+    data, d = small
+    hp = dict(HP, beta=100.0)
+
+    def torch_tail(feat, teacher_feat, edge_index, kern, criterion="kld"):
+        plan = OE.edge_plan(edge_index, feat.shape[0])
+        p_s = OE._SegSoftmax.apply(OE._EdgeSim.apply(feat, plan, kern), plan.ptr_b)
+        p_t = OE._SegSoftmax.apply(OE._EdgeSim.apply(teacher_feat, plan, kern), plan.ptr_b)
+        # (+ a 4 M-element sum: multi-block for certain, whatever ATen's heuristics make of the 68 k edges of this graph)
+        return torch.nn.functional.kl_div(torch.log(p_s), p_t, log_target=False, reduction="mean") + 0.0 * big.sum()
+    big = torch.ones(4_000_000, device=DEV)
+    monkeypatch.setattr(OE, "lsp_loss", torch_tail)
+    torch.manual_seed(0)
+    m = PM.SAGE(data.num_features, 128, data.num_classes, 3, 0.5).to(DEV)
+    opt = torch.optim.Adam(m.parameters(), lr=0.01, fused=True, capturable=True)
+    ei = subgraph(d.split_idx["train"], torch.stack(d.adj_t.coo()[:2]), relabel_nodes=True, num_nodes=data.num_nodes)[0]
+    with pytest.warns(UserWarning, match="long torch reductions"), pytest.raises(LongReductionInCapture, match="memset"):
+        PM.GraphedEpoch(m, d.x, d.adj_t, d.y, d.split_idx["train"], opt, "lpw", hp, d.teacher_out_feat, d.teacher_logits,
+                        edge_index=ei, split_idx=d.split_idx, warmup=2)
+
+
 @pytest.mark.parametrize("n,C", [(1, 7), (13, 40), (90941, 40), (169343, 256), (5000, 750), (33, 1024)])
 def test_colsum_vs_float64(n, C):
     g = torch.Generator(device=DEV).manual_seed(n + C)
@@ -362,10 +388,10 @@ def test_locality_order_is_the_same_on_every_device():
 
 
 @pytest.mark.parametrize("gnn,mode", CASES + [("gcn", "supervised")])
-def test_captured_epoch_graph_is_a_chain_of_kernel_nodes(small, gnn, mode, monkeypatch):
-    """The captured epoch read back through the HIP runtime (hipGraphGetNodes / NodeGetType / GetEdges, _audit.graph_node_kinds):
-    kernel nodes only, one chain -- no memset node (what ATen's multi-block reductions put there: DESIGN.md 4.1), no memcpy node."""
-    monkeypatch.setenv("EGNN_GRAPH_NODE_CHECK", "1")
+def test_captured_epoch_graph_is_a_chain_of_kernel_nodes(small, gnn, mode):
+    """The captured epoch read back through the HIP runtime (hipGraphGetNodes / NodeGetType / GetEdges, _audit.graph_node_kinds; since
+    round 5 on EVERY capture, no switch): kernel nodes only, one chain -- no memset node (what ATen's multi-block reductions put
+    there: DESIGN.md 4.1), no memcpy node."""
     data, d = small
     hp = dict(HP, beta=100.0 if mode in ("lpw", "gpw") else 0.1)
     torch.manual_seed(0)
