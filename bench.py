@@ -212,6 +212,54 @@ class NceProbe:
         return dict(calls=len(self.records), flops=flops, secs=secs)
 
 
+class GemmProbe:
+    """Brackets every dense-GEMM entry point of the step that is NOT part of the G-CRD loss -- egnn_gemm_f32 / _ex / _add / _rows: the
+    layer transforms x W, their input gradients, the transposed weight-gradient products and the projection heads
+    (arxiv_pyg/gnn.py:47,296-306) -- with HIP events on the launch stream, for the `roofline_gemm` object.  A call's flops are
+    2 M N K; calls with a class-count-wide dimension (min(M, N, K) <= 64: the HBM-bound skinny kernels of csrc/gemm_skinny.hip) are
+    reported separately and are not part of the matrix-pipe fraction."""
+    NAMES = ("egnn_gemm_f32", "egnn_gemm_ex_f32", "egnn_gemm_add_f32", "egnn_gemm_rows_f32")
+
+    def __init__(self, lib):
+        self.lib, self.records, self.active = lib, [], False
+        self._orig = {n: getattr(lib, n) for n in self.NAMES}
+
+    def __enter__(self):
+        def wrap(name):
+            orig = self._orig[name]
+
+            def wrapped(*a):
+                if not self.active:
+                    return orig(*a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = orig(*a)
+                e1.record()
+                self.records.append((int(a[0]), int(a[1]), int(a[2]), int(a[3]), int(a[4]), name.endswith("rows_f32"), e0, e1))
+                return rc
+            return wrapped
+        for n in self.NAMES:
+            setattr(self.lib, n, wrap(n))
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self._orig.items():
+            setattr(self.lib, n, f)
+
+    def summary(self):
+        if not self.records:
+            return None
+        wide = [r for r in self.records if min(r[2], r[3], r[4]) > 64]
+        skinny = [r for r in self.records if min(r[2], r[3], r[4]) <= 64]
+        tot = lambda rs: (sum(2.0 * r[2] * r[3] * r[4] for r in rs), sum(r[6].elapsed_time(r[7]) * 1e-3 for r in rs))  # noqa: E731
+        shapes = {}
+        for r in wide:
+            key = f"{'T' if r[0] else 'N'}{'T' if r[1] else 'N'}{'+rows' if r[5] else ''} {r[2]}x{r[3]}x{r[4]}"
+            f, t, c = shapes.get(key, (0.0, 0.0, 0))
+            shapes[key] = (f + 2.0 * r[2] * r[3] * r[4], t + r[6].elapsed_time(r[7]) * 1e-3, c + 1)
+        return dict(wide=tot(wide), skinny=tot(skinny), n_wide=len(wide), n_skinny=len(skinny), shapes=shapes)
+
+
 class GspProbe:
     """Brackets the GSP forward entry point (egnn_gsp_fwd_f32: the student and teacher Gram tiles + the squared difference, f32-input
     MFMA) with HIP events on the launch stream, for the `roofline_gsp` object of `--training gpw`."""
@@ -806,8 +854,9 @@ def main():
     # it; without a graph they are measured over the timed region itself
     n_probe = args.probe_epochs if graphed is not None else args.steps
     with SpmmProbe(ops) as probe, NceProbe(_egnn_lib.load()) as nce_probe, EdgeProbe(_egnn_lib.load()) as edge_probe, \
-            GspProbe(_egnn_lib.load()) as gsp_probe:
+            GspProbe(_egnn_lib.load()) as gsp_probe, GemmProbe(_egnn_lib.load()) as gemm_probe:
         probe.active = True
+        gemm_probe.active = True
         nce_probe.active = True
         edge_probe.active = args.training == "lpw"
         gsp_probe.active = args.training == "gpw"
@@ -829,6 +878,7 @@ def main():
         nce_probe.active = False
         edge_probe.active = False
         gsp_probe.active = False
+        gemm_probe.active = False
     if graphed is None:
         elapsed, losses, accs = eager_elapsed, l2, a2
     K = MODEL["hidden"]
@@ -877,6 +927,24 @@ def main():
                              mfma_tflops_issued=round(tf * (6.0 if split else 1.0), 1),
                              flops_per_step=int(nsum["flops"] / max(1, n_probe)),
                              ms_per_step=round(1e3 * nsum["secs"] / max(1, n_probe), 3), calls_timed=nsum["calls"])
+    roofline_gemm = None
+    gmsum = gemm_probe.summary()
+    if gmsum and gmsum["wide"][1] > 0:
+        split = not os.environ.get("EGNN_GEMM_PIPE", "").startswith("f")
+        peak = 2500.0 / 6.0 if split else 157.3
+        fl, secs = gmsum["wide"]
+        tf = fl / secs / 1e12
+        per_shape = {k: dict(calls_per_step=round(c / max(1, n_probe), 2), us_per_call=round(1e6 * t / c, 1), tflops=round(f / t / 1e12, 1),
+                             frac=round(f / t / 1e12 / peak, 3)) for k, (f, t, c) in sorted(gmsum["shapes"].items(), key=lambda kv: -kv[1][1])}
+        roofline_gemm = dict(bound="mfma", kernel="every egnn_gemm_f32 / _ex / _add / _rows call of the step outside the G-CRD loss with all of "
+                                                  "M, N, K > 64: layer transforms, input gradients, transposed weight gradients (split-K), projection "
+                                                  "heads with fused row gathers; pack / split-K-reduce launches included",
+                             achieved=round(tf, 1), peak=round(peak, 1), unit="TFLOP/s (fp32 products)", frac=round(tf / peak, 4),
+                             flops_per_step=int(fl / max(1, n_probe)), ms_per_step=round(1e3 * secs / max(1, n_probe), 3),
+                             calls_per_step=round(gmsum["n_wide"] / max(1, n_probe), 2), by_shape=per_shape,
+                             skinny_calls=dict(what="calls with a class-count-wide dimension (<= 64): HBM-bound kernels of gemm_skinny.hip, not in frac",
+                                               calls_per_step=round(gmsum["n_skinny"] / max(1, n_probe), 2),
+                                               ms_per_step=round(1e3 * gmsum["skinny"][1] / max(1, n_probe), 3)))
     roofline_edges = None
     esum = edge_probe.summary()
     if esum and edge_index is not None:
@@ -934,7 +1002,7 @@ def main():
                     adam=os.environ.get("EGNN_ADAM", "fused"),
                     memoise_first_layer_aggregation=os.environ.get("EGNN_GCN_MEMOISE_AX", "0") == "1",
                     cache_constant_row_gathers=os.environ.get("EGNN_CACHE_CONST_ROWS", "0") == "1"),
-        roofline=roofline, roofline_local=roofline_local, roofline_mfma=roofline_mfma, roofline_edges=roofline_edges, roofline_gsp=roofline_gsp, cpu_baseline=cpu, parity=parity,
+        roofline=roofline, roofline_local=roofline_local, roofline_mfma=roofline_mfma, roofline_gemm=roofline_gemm, roofline_edges=roofline_edges, roofline_gsp=roofline_gsp, cpu_baseline=cpu, parity=parity,
         launch=graph_note,
         eager=dict(epochs_per_s=round(n_probe / eager_elapsed, 3), epochs=n_probe,
                    note="eager launches with per-kernel event brackets (where the roofline objects are measured)"),

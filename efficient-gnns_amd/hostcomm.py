@@ -90,8 +90,10 @@ def _broadcast(tensor, src=None, group=None, async_op=False, group_src=None):
 def _all_gather_into_tensor(output_tensor, input_tensor, group=None, async_op=False):
     if not _staged(group, input_tensor):
         return _ORIG["all_gather_into_tensor"](output_tensor, input_tensor, group=group, async_op=async_op)
-    hin = _down(input_tensor)
-    hout = torch.empty(output_tensor.shape, dtype=output_tensor.dtype)
+    # gloo wants the output as the flat concatenation of the (flat) inputs, whatever shape the caller gave it ([world, C] for a [C]
+    # input is fine over RCCL, refused here); the blocks are contiguous either way
+    hin = _down(input_tensor).reshape(-1)
+    hout = torch.empty(output_tensor.numel(), dtype=output_tensor.dtype)
     _ORIG["all_gather_into_tensor"](hout, hin, group=group)
     _up(output_tensor, hout)
     return _finish(async_op)
@@ -101,7 +103,7 @@ def _all_to_all_single(output, input, output_split_sizes=None, input_split_sizes
     if not _staged(group, input):
         return _ORIG["all_to_all_single"](output, input, output_split_sizes, input_split_sizes, group=group, async_op=async_op)
     hin = _down(input)
-    hout = torch.empty(output.shape, dtype=output.dtype)
+    hout = torch.empty(output.shape, dtype=output.dtype)       # (split sizes count rows of dim 0: the shapes stay as given)
     _ORIG["all_to_all_single"](hout, hin, output_split_sizes, input_split_sizes, group=group)
     _up(output, hout)
     return _finish(async_op)

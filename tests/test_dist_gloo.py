@@ -488,6 +488,59 @@ def test_static_shape_sampled_criteria_match_the_oracle(gnn, mode, world, max_sa
     np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-4, atol=1e-6)
 
 
+def _hostcomm_shapes_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from efficient_gnns_amd import hostcomm
+        hostcomm._STAGE_HOST_TENSORS = True
+        hostcomm.install()
+        # [world, C] output for a [C] input (ops._sync_stats): fine over RCCL, gloo itself insists on the flat concatenation
+        out = torch.empty(world, 5)
+        dist.all_gather_into_tensor(out, torch.arange(5.) + 10 * rank)
+        ok = all(torch.equal(out[r], torch.arange(5.) + 10 * r) for r in range(world))
+        o2 = torch.empty(world * 3, 4)
+        dist.all_gather_into_tensor(o2, torch.full((3, 4), float(rank)))
+        ok = ok and all(bool(o2[3 * r:3 * r + 3].eq(r).all()) for r in range(world))
+        full = torch.arange(world * 12.).view(world * 3, 4)
+        rs = torch.empty(3, 4)
+        dist.reduce_scatter_tensor(rs, full.clone())                  # (gloo has none: all_reduce + this rank's block)
+        ok = ok and torch.equal(rs, world * full[rank * 3:(rank + 1) * 3])
+        send = torch.arange(6.).view(3, 2) + 100 * rank                  # rows 0..r0 to rank 0, the rest to rank 1 (world 2)
+        counts_out = counts_in = [1, 2] if rank == 0 else [2, 1]      # rank 0 sends 1 + 2 rows and receives 1 + 2; rank 1: 2 + 1
+        recv = torch.empty(sum(counts_in), 2)
+        work = dist.all_to_all_single(recv, send, counts_in, counts_out, async_op=True)
+        work.wait()
+        want = torch.cat([send[:1], send[:2] + 100]) if rank == 0 else torch.cat([send[1:] - 100, send[2:]])
+        ok = ok and torch.equal(recv, want)
+        red = torch.ones(3) * (rank + 1)
+        dist.all_reduce(red)
+        ok = ok and bool(red.eq(sum(range(1, world + 1))).all()) and hostcomm.stats()["calls"] == 5
+        got = [None] * world
+        dist.all_gather_object(got, bool(ok))
+        if rank == 0:
+            q.put(got)
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+    _quiet_exit()
+
+
+def test_host_staged_collectives_shapes_and_semantics():
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hostcomm_shapes_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got == [True, True]
+
+
 @pytest.mark.parametrize("gnn,mode,world", [("gcn", "nce", 3), ("sage", "lpw", 2)])
 def test_host_staged_collectives_carry_the_same_program(gnn, mode, world):
     """efficient-gnns_amd/hostcomm.py (the transport of the several-ranks-on-one-GPU runs, tests/test_gpu_multirank.py): with its

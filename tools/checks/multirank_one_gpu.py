@@ -44,6 +44,15 @@ def all_cases():
     return cases
 
 
+def full_size_cases():
+    """Not part of the pytest run (evidence sessions: --cases full-...): the BASELINE.json configs[1] problem at FULL size (N = 169 343,
+    GCN-256 + G-CRD, S = 16 384, P = 256) on node-range shards against the single-GPU path, dropout 0."""
+    return {"full-gcn-nce-static-natural-ov1": dict(gnn="gcn", mode="nce", sigmas=6.0, order="natural", overlap=1, scale=1.0, hidden=256, proj=256,
+                                                    max_samples=16384, seed=0),
+            "full-sage-lpw-natural-ov1": dict(gnn="sage", mode="lpw", sigmas=None, order="natural", overlap=1, scale=1.0, hidden=256, proj=256,
+                                              max_samples=16384, seed=0)}
+
+
 def _problem(case, world, dev):
     import efficient_gnns_amd.data as D
     import efficient_gnns_amd.dist as DD
@@ -51,7 +60,7 @@ def _problem(case, world, dev):
     if case.get("workload") == "mag":
         d = DD.mag_problem(0.05, 5)             # N = 96 987, 2.1 M stored entries
     else:
-        d = D.arxiv_like(scale=0.02, seed=5, graph="local" if case["order"] == "community" else "chunglu")
+        d = D.arxiv_like(scale=case.get("scale", 0.02), seed=case.get("seed", 5), graph="local" if case["order"] == "community" else "chunglu")
         if case["order"] == "community":
             perm, before, after = DD.locality_order(d, world, dev)
             note = dict(halo_rows_as_given=before, halo_rows_community_order=after, reordered=perm is not None)
@@ -60,8 +69,9 @@ def _problem(case, world, dev):
     return d, note
 
 
-def _build(case, d, dev, hidden=64, proj=32):
+def _build(case, d, dev):
     import efficient_gnns_amd.models as PM
+    hidden, proj = case.get("hidden", 64), case.get("proj", 32)
     torch.manual_seed(0)
     np.random.seed(0)
     model = (PM.GCN if case["gnn"] == "gcn" else PM.SAGE)(d.num_features, hidden, d.num_classes, 3, 0.0).to(dev)
@@ -74,7 +84,7 @@ def _build(case, d, dev, hidden=64, proj=32):
 
 
 def _hp(case):
-    hp = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=256, kernel="rbf")
+    hp = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=case.get("max_samples", 256), kernel="rbf")
     if case["mode"] in ("gpw", "lpw"):
         hp.update(kernel="cosine", beta=100.0)
     return hp
@@ -94,6 +104,9 @@ def _single_gpu(case, d, dev, steps):
         from efficient_gnns_amd.utils import subgraph
         edge_index = subgraph(split["train"], torch.stack(adj.coo()[:2]), relabel_nodes=True, num_nodes=d.num_nodes)[0]
     tf = d.teacher_out_feat.to(dev) if getattr(d, "teacher_out_feat", None) is not None else None
+    if tf is not None:
+        from efficient_gnns_amd.ops import pad_pitch
+        tf = pad_pitch(tf)              # (what bench.py / the sharded problem hand the kernels: rows behind a 16-byte aligned pitch)
     tl = d.teacher_logits.to(dev) if getattr(d, "teacher_logits", None) is not None else None
     logits, accs = PM.evaluate(model, x, adj, y, split)
     losses = [PM.train_step(model, x, adj, y, split["train"], opt, case["mode"], hp, tf, tl, sp, tp, edge_index) for _ in range(steps)]
@@ -137,7 +150,7 @@ def _worker(rank, world, port, names, out_path, steps):
         from efficient_gnns_amd import _lib, hostcomm
         assert not _lib.HOST_STANDINS
         hostcomm.install()
-        cases = all_cases()
+        cases = dict(all_cases(), **full_size_cases())
         report = {}
         for name in names:
             case = cases[name]
