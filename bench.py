@@ -112,14 +112,13 @@ def build_problem(M, data, device, args, hp, dropout=None):
         sp = M.make_projection(MODEL["hidden"], hp["proj_dim"]).to(device)
         tp = M.make_projection(data.teacher_out_feat.shape[1], hp["proj_dim"]).to(device)
         groups += [{"params": sp.parameters(), "lr": MODEL["lr"]}, {"params": tp.parameters(), "lr": MODEL["lr"]}]
-    # the single-kernel (fused) implementation of the same torch.optim.Adam update (gnn.py:308-312); EGNN_ADAM=foreach
-    # selects PyTorch's default multi-kernel path
+    # the single-kernel (fused) implementation of the same torch.optim.Adam update (gnn.py:308-312)
     on_gpu = torch.device(device).type == "cuda"
-    if on_gpu and os.environ.get("EGNN_ADAM_GROUPS", "one") == "one":
+    if on_gpu:
         # the reference's three groups carry the same hyper-parameters (gnn.py:308-312: lr for all of them), so one group is the
         # same update; the fused optimizer launches once per GROUP (~42 us each, latency-bound on 0.5 M parameters)
         groups = [{"params": [p for g in groups for p in g["params"]], "lr": MODEL["lr"]}]
-    opt = torch.optim.Adam(groups, fused=(on_gpu and os.environ.get("EGNN_ADAM", "fused") == "fused"), capturable=on_gpu)
+    opt = torch.optim.Adam(groups, fused=on_gpu, capturable=on_gpu)
     return model, sp, tp, opt
 
 
@@ -999,7 +998,7 @@ def main():
                     gemm_backend=ops.gemm_backend(), partitioning="single GPU",
                     spmm_schedule=getattr(ops, "_SPMM_SCHEDULE", "classes"),
                     gcn_operand_order="aggregate on the narrower side of W (layer 1: (A x) W; same product as A (x W))",
-                    adam=os.environ.get("EGNN_ADAM", "fused"),
+                    adam="fused",
                     memoise_first_layer_aggregation=os.environ.get("EGNN_GCN_MEMOISE_AX", "0") == "1",
                     cache_constant_row_gathers=os.environ.get("EGNN_CACHE_CONST_ROWS", "0") == "1"),
         roofline=roofline, roofline_local=roofline_local, roofline_mfma=roofline_mfma, roofline_gemm=roofline_gemm, roofline_edges=roofline_edges, roofline_gsp=roofline_gsp, cpu_baseline=cpu, parity=parity,

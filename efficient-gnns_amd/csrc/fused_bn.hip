@@ -845,8 +845,7 @@ constexpr int kTailTileBlocks = 768;   // workgroups of the tile form = partial 
 
 constexpr int kDxBnRows = 256;      // rows per wave of skinny_dx_bn_kernel (one partial row of the column sums per 256 rows)
 inline bool tail_tile_form(int64_t C, int ksteps) {
-  static const bool off = getenv("EGNN_TAIL_TILE") && getenv("EGNN_TAIL_TILE")[0] == '0';   // A/B switch (tests run both forms)
-  return !off && C == 256 && ksteps <= 10;
+  return C == 256 && ksteps <= 10;   // (other widths take the MFMA-layout kernel: tests cover C = 64 / 128)
 }
 }  // namespace
 
@@ -958,11 +957,10 @@ __global__ __launch_bounds__(256, 4) void tail_fwd_tile_kernel(const BnParams q,
 }  // namespace
 
 // Y = alpha X W + bias for a 256-wide X and a narrow W in the tile form (see tail_fwd_tile_kernel<NT, false>); 1 = shape not taken.
-// Called by gemm.hip in front of egnn_skinny_fwd (gemm_skinny.hip).  EGNN_SKINNY_TILE=0 is the A/B switch.
+// Called by gemm.hip in front of egnn_skinny_fwd (gemm_skinny.hip).
 int egnn_skinny_fwd_tile(const float* X, int64_t ldx, const float* W, int64_t ldw, int w_kmajor, const float* bias, float* Y, int64_t ldy, int64_t M,
                          int64_t N, int64_t K, float alpha, hipStream_t st) {
-  static const bool off = getenv("EGNN_SKINNY_TILE") && getenv("EGNN_SKINNY_TILE")[0] == '0';
-  if (off || K != 256 || N < 1 || N > 64 || M < 4096 || ldx % 4 != 0 || !egnn_aligned16(X) || M * ldx >= (1LL << 31) - 64) return 1;
+  if (K != 256 || N < 1 || N > 64 || M < 4096 || ldx % 4 != 0 || !egnn_aligned16(X) || M * ldx >= (1LL << 31) - 64) return 1;
   const BnParams q{X, ldx, M, K, nullptr, nullptr, 0.f, nullptr, nullptr, 0, 0.f, 0ull, nullptr, nullptr};
   const int nt = (int)((N + 15) / 16);
   const int64_t nblk = (M + 15) / 16;

@@ -49,7 +49,7 @@ struct GemmArgs {
   const int64_t* rows;     // GATHER 1: storage rows of A ([M,K]) ; GATHER 2: storage rows of B ([K,N]); else unused
   int wide_store;          // output rows 16-byte aligned: epilogue through LDS with 16-byte stores
   int split_pipe;          // 1: products on the bf16 pipe (three-way operand split, gemm_split.h); 0: f32-input MFMA
-  const u32x4* planes;     // pre-split B (gemm_split.h, "planes" form) or null
+  const u32x4* planes;     // B cut into tile-packed bf16 planes for the DMA form (gemm3.h) or null
   int relu;                // C = max(alpha A B + bias, 0)
   const float* addend;     // optional [M,N] matrix added in the store: C = alpha A B + bias + addend (never together with relu)
   int64_t ld_add;
@@ -150,12 +150,10 @@ __device__ __forceinline__ void store_tile_wide(const f32x16 (&acc)[TM_][TN_], c
 
 // SPLIT: products on the bf16 matrix pipe from a three-way split of the fp32 operands (gemm_split.h); its LDS image
 // (72 KB for 128 x 128) is dynamic shared memory.
-// NTHR = 512: the 8-wave form of the split pipeline (waves 4 x 2, 256 x 128 block tile: 25 % less operand staging per FLOP)
-template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER = 0, bool SPLIT = false, int NTHR = 256>
-__global__ __launch_bounds__(NTHR, (SPLIT && NTHR == 256) ? 2 : 1) void gemm_kernel(const GemmArgs g) {
-  static_assert(NTHR == 256 || (SPLIT && BM == 256 && BN == 128), "the 8-wave form is the 256 x 128 split tile");
-  constexpr int WAVES_M = NTHR / 128;
-  using TS = typename std::conditional<NTHR == 256, typename TileSel<SPLIT, BM, BN>::type, TileShapeS<BM, BN, WAVES_M>>::type;
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER = 0, bool SPLIT = false>
+__global__ __launch_bounds__(256, SPLIT ? 2 : 1) void gemm_kernel(const GemmArgs g) {
+  constexpr int WAVES_M = 2;
+  using TS = typename TileSel<SPLIT, BM, BN>::type;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int64_t tiles_n = (g.N + BN - 1) / BN;
   // workgroup b runs on XCD b % 8: give every XCD a contiguous run of tiles, so that the column tiles of one row tile
@@ -180,12 +178,12 @@ __global__ __launch_bounds__(NTHR, (SPLIT && NTHR == 256) ? 2 : 1) void gemm_ker
     // the whole k-steps run a loop without per-element guards (rows past the edge of the last tile are clamped to the
     // last row and never stored); a ragged end of the reduction (K % 16) is one more, guarded, step
     const int64_t kfull = kbeg + ((kend - kbeg) / BK) * BK;
-    mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, true, GATHER == 1, GATHER == 2, NTHR>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kfull, id, id,
-                                                                                     smem, g.rows, g.rows);
+    mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, true, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kfull, id, id, smem,
+                                                                               g.rows, g.rows);
     if (kfull < kend) {
       __syncthreads();
-      mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2, NTHR>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kfull, kend, id,
-                                                                                        id, smem, g.rows, g.rows);
+      mainloop_split<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kfull, kend, id, id,
+                                                                                  smem, g.rows, g.rows);
     }
   } else {
     mainloop<BM, BN, AMAJ, BMAJ, VEC4, false, GATHER == 1, GATHER == 2>(acc, g.A, g.lda, m0, g.M, g.B, g.ldb, n0, g.N, kbeg, kend, id, id,
@@ -194,67 +192,6 @@ __global__ __launch_bounds__(NTHR, (SPLIT && NTHR == 256) ? 2 : 1) void gemm_ker
   const int wave = egnn_wave_id();
   if (g.wide_store) store_tile_wide<BM, BN, WAVES_M>(acc, g, m0, n0, split, egnn_lane(), wave >> 1, wave & 1, smem);
   else store_tile<BM, BN, WAVES_M>(acc, g, m0, n0, split, egnn_lane(), wave >> 1, wave & 1);
-}
-
-// B pre-split into planes (a small, much-reused operand): 128 x 128 block tile, waves 1 x 4, only A staged through LDS
-template <int AMAJ, bool VEC4, bool GA>
-__global__ __launch_bounds__(256, 2) void gemm_pb_kernel(const GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int64_t tiles_n = (g.N + 127) / 128;
-  const int64_t m0 = (blockIdx.x / tiles_n) * 128;
-  const int64_t n0 = (blockIdx.x % tiles_n) * 128;
-  const int split = blockIdx.y;
-  const int64_t kbeg = split * g.k_per_split;
-  int64_t kend = kbeg + g.k_per_split;
-  if (kend > g.K) kend = g.K;
-  const int lane = egnn_lane(), wave = egnn_wave_id();
-  const u32x4* bp = g.planes + ((n0 >> 5) + wave) * planes_nk(g.K) * (3 * 64) + lane;
-  f32x16 acc[4];
-#pragma unroll
-  for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
-  IdentityXf id;
-  if ((kend - kbeg) % BK == 0) mainloop_pb<AMAJ, VEC4, true, GA>(acc, g.A, g.lda, m0, g.M, bp, kbeg, kend, id, smem, g.rows);
-  else mainloop_pb<AMAJ, VEC4, false, GA>(acc, g.A, g.lda, m0, g.M, bp, kbeg, kend, id, smem, g.rows);
-  const bool partial = g.split_k > 1;
-  const float alpha = partial ? 1.f : g.alpha * (g.alpha_dev ? g.alpha_dev[0] : 1.f);
-  float* out = partial ? g.ws + (int64_t)split * g.M * g.N : g.C;
-  const int64_t ldo = partial ? g.N : g.ldc;
-  const int64_t c = n0 + wave * 32 + (lane & 31);
-  if (c < g.N) {
-    const float bv = (!partial && g.bias) ? g.bias[c] : 0.f;
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < g.M) {
-          float v = alpha * acc[tm][r] + bv;
-          if (g.addend && !partial) v += g.addend[row * g.ld_add + c];
-          out[row * ldo + c] = (g.relu && !partial) ? fmaxf(v, 0.f) : v;
-        }
-      }
-  }
-}
-
-template <int AMAJ, bool GA>
-int launch_pb(const GemmArgs& g, bool vec4, hipStream_t st) {
-  const int64_t tiles = ((g.M + 127) / 128) * ((g.N + 127) / 128);
-  if (tiles > 0x7fffffffLL) return EGNN_EINVAL;
-  const dim3 grid((unsigned)tiles, (unsigned)g.split_k);
-  constexpr size_t shm = 2 * 3 * 128 * S_ROW;
-  if (vec4) hipLaunchKernelGGL((gemm_pb_kernel<AMAJ, true, GA>), grid, dim3(256), shm, st, g);
-  else hipLaunchKernelGGL((gemm_pb_kernel<AMAJ, false, GA>), grid, dim3(256), shm, st, g);
-  return EGNN_OK;
-}
-
-// the planes form pays when B is small next to A (it is cut once, then read by every row tile)
-bool planes_form(int64_t M, int64_t N, int64_t K, bool b_gather) {
-  // measured slower than the two-operand staging on the layer shapes (169343 x 256 x 256: 205 vs 181 us: the fragment
-  // loads cost more L2 -> CU traffic than they save in LDS work), so it is opt-in: EGNN_GEMM_PLANES=1
-  static const bool on = getenv("EGNN_GEMM_PLANES") != nullptr;
-  return on && gemm_split_pipe() && !b_gather && N >= 96 && K >= 16 && M >= 3 * N && planes_bytes(N, K) <= (256u << 20);
 }
 
 // ---- DMA form (gemm3.h): a node-count-tall A [M, K] (k contiguous) against a SMALL B (layer weights) -------------------------
@@ -284,8 +221,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs g) {
 
 // shapes the DMA form takes: tall A with k contiguous, whole 128-column tiles of a small B, whole k-steps of 32
 bool dma_form(int trans_a, int64_t M, int64_t N, int64_t K, int split_k, bool gathers) {
-  static const bool off = getenv("EGNN_GEMM_DMA") && getenv("EGNN_GEMM_DMA")[0] == '0';   // A/B switch
-  return !off && gemm_split_pipe() && !trans_a && !gathers && split_k <= 1 && M >= 4096 && N % 128 == 0 && N >= 128 && N <= 1024 &&
+  return gemm_split_pipe() && !trans_a && !gathers && split_k <= 1 && M >= 4096 && N % 128 == 0 && N >= 128 && N <= 1024 &&
          K % DMA_BKT == 0 && K >= 2 * DMA_BKT && K <= 4096;
 }
 inline size_t dma_ws_bytes(int64_t N, int64_t K) { return egnn_gemm3::planes_bytes(N, K, 128, DMA_BKT) + 1024; }
@@ -302,17 +238,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
   }
 }
 
-template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER, bool SPLIT, int NTHR = 256>
+template <int BM, int BN, int AMAJ, int BMAJ, bool VEC4, int GATHER, bool SPLIT>
 int launch_one(const GemmArgs& g, dim3 grid, hipStream_t st) {
-  using TS = typename std::conditional<NTHR == 256, typename TileSel<SPLIT, BM, BN>::type, TileShapeS<BM, BN, NTHR / 128>>::type;
+  using TS = typename TileSel<SPLIT, BM, BN>::type;
   constexpr size_t shm = (size_t)TS::SMEM_FLOATS * sizeof(float);
-  return launch_dyn_lds<gemm_kernel<BM, BN, AMAJ, BMAJ, VEC4, GATHER, SPLIT, NTHR>>(grid, dim3(NTHR), shm, st, g);
-}
-
-// 8-wave 256 x 128 tiles: lab switch EGNN_GEMM_TILE=256 (default 128)
-bool wide_tile() {
-  static const bool on = getenv("EGNN_GEMM_TILE") && atoi(getenv("EGNN_GEMM_TILE")) == 256;
-  return on;
+  return launch_dyn_lds<gemm_kernel<BM, BN, AMAJ, BMAJ, VEC4, GATHER, SPLIT>>(grid, dim3(256), shm, st, g);
 }
 
 template <int BM, int BN, int AMAJ, int BMAJ, int GATHER = 0>
@@ -320,14 +250,6 @@ int launch_tile(const GemmArgs& g, bool vec4, hipStream_t st) {
   const int64_t tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   if (tiles > 0x7fffffffLL) return EGNN_EINVAL;
   dim3 grid((unsigned)tiles, (unsigned)g.split_k);
-  if constexpr (BM == 128 && BN == 128) {
-    if (g.split_pipe && wide_tile() && g.M >= 1024) {
-      const int64_t tiles8 = ((g.M + 255) / 256) * ((g.N + 127) / 128);
-      dim3 grid8((unsigned)tiles8, (unsigned)g.split_k);
-      return vec4 ? launch_one<256, 128, AMAJ, BMAJ, true, GATHER, true, 512>(g, grid8, st)
-                  : launch_one<256, 128, AMAJ, BMAJ, false, GATHER, true, 512>(g, grid8, st);
-    }
-  }
   if constexpr (BM % 128 == 0 && BN % 128 == 0) {
     if (g.split_pipe) {
       return vec4 ? launch_one<BM, BN, AMAJ, BMAJ, true, GATHER, true>(g, grid, st)
@@ -379,9 +301,8 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   }
   const bool wide = split_k > 1 ? (N % 4 == 0 && egnn_aligned16(ws))
                                 : (ldc % 4 == 0 && egnn_aligned16(C) && (!addend || (ld_add % 4 == 0 && egnn_aligned16(addend))));
-  static const bool narrow_forced = getenv("EGNN_GEMM_NARROW_STORE") != nullptr;   // A/B switch for the epilogue form
   GemmArgs g{M, N, K, A, lda, B, ldb, bias, C, ldc, alpha, nullptr, split_k,
-             ((ksteps + split_k - 1) / split_k) * BK, ws, a_rows ? a_rows : b_rows, (wide && !narrow_forced) ? 1 : 0,
+             ((ksteps + split_k - 1) / split_k) * BK, ws, a_rows ? a_rows : b_rows, wide ? 1 : 0,
              gemm_split_pipe() ? 1 : 0,
              nullptr, (flags & 1) ? 1 : 0, addend, ld_add};
   hipStream_t st = (hipStream_t)stream;
@@ -389,7 +310,6 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   const int amaj = trans_a ? MNMAJOR : KMAJOR;   // A stored [K,M] when transposed
   const int bmaj = trans_b ? KMAJOR : MNMAJOR;   // B stored [N,K] when transposed, else [K,N]
   int rc;
-  const size_t split_ws = split_k > 1 ? (size_t)split_k * M * N * sizeof(float) : 0;
   if (dma_form(trans_a, M, N, K, split_k, a_rows || b_rows) && ws && ws_bytes >= dma_ws_bytes(N, K) && lda % 4 == 0 && egnn_aligned16(A)) {
     char* planes = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws) + 1023) & ~(uintptr_t)1023);
     // B(k, n): stored [N, K] when trans_b (k contiguous), else [K, N]
@@ -401,16 +321,6 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
     if (rc != EGNN_OK) return rc;
     return egnn_launch_status();
   }
-  if (planes_form(M, N, K, b_rows != nullptr) && ws && ws_bytes >= split_ws + planes_bytes(N, K) + 16) {
-    u32x4* planes = reinterpret_cast<u32x4*>((reinterpret_cast<uintptr_t>(ws) + split_ws + 15) & ~(uintptr_t)15);
-    g.planes = planes;
-    const int64_t units = planes_nb(N) * planes_nk(K) * 64;
-    IdentityXf id;
-    hipLaunchKernelGGL((presplit_kernel<IdentityXf>), dim3((unsigned)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096)), dim3(256), 0, st, B, ldb,
-                       bmaj == KMAJOR ? 1 : 0, N, K, id, planes);
-    if (a_rows) rc = launch_pb<KMAJOR, true>(g, vec4, st);
-    else rc = amaj == KMAJOR ? launch_pb<KMAJOR, false>(g, vec4, st) : launch_pb<MNMAJOR, false>(g, vec4, st);
-  } else
   if (a_rows) {
     rc = bmaj == KMAJOR ? launch_major<KMAJOR, KMAJOR, 1>(g, vec4, st) : launch_major<KMAJOR, MNMAJOR, 1>(g, vec4, st);
   } else if (b_rows) {
@@ -430,7 +340,6 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
 extern "C" size_t egnn_gemm_ws_floats(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, int split_k) {
   size_t need = split_k > 1 ? (size_t)split_k * (size_t)M * (size_t)N : 0;
   const int kind = skinny_kind(trans_a, trans_b, M, N, K, false);
-  if (kind == 0 && planes_form(M, N, K, false)) need += planes_bytes(N, K) / sizeof(float) + 8;   // B cut into bf16 planes (gemm_split.h)
   if (kind == 0 && dma_form(trans_a, M, N, K, split_k, false)) {   // tile-packed planes of B for the DMA form (gemm3.h)
     const size_t dma = dma_ws_bytes(N, K) / sizeof(float) + 1;
     if (dma > need) need = dma;

@@ -294,120 +294,6 @@ __device__ __forceinline__ void mainloop_split(f32x16 (&acc)[TM_][TN_], const fl
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// "Planes" form of a SMALL, much-reused B operand (layer weights; the [S,256] embedding matrices of the G-CRD loss):
-// op(B)[K,N] is cut into its three bf16 terms ONCE per call (presplit_kernel) and laid out in MFMA-fragment order,
-//     unit (nb, ks, p) = 1 KB:  lane l (column 32 nb + (l & 31), g = l >> 5) holds k = 16 ks + 8 g + 0..7 of plane p
-//     address = ((nb * nk + ks) * 3 + p) * 1 KB + 16 l
-// so that a wave owning 32 output columns fetches its B fragments of a k-step with three coalesced 1 KB loads straight
-// into registers (L2-resident): no LDS, no split VALU and no barrier traffic for B; only the big A operand is staged and
-// cut in the loop.  Wave arrangement 1 x 4: every wave holds all 128 rows x 32 columns of the block tile.
-// (opt-in, EGNN_GEMM_PLANES=1: measured slower than the two-operand staging on the layer shapes, see gemm.hip)
-__host__ __device__ inline int64_t planes_nk(int64_t K) { return (K + BK - 1) / BK; }
-__host__ __device__ inline int64_t planes_nb(int64_t N) { return ((N + 127) / 128) * 4; }   // 32-column units, whole 128-column tiles
-__host__ __device__ inline size_t planes_bytes(int64_t N, int64_t K) { return (size_t)planes_nb(N) * (size_t)planes_nk(K) * 3 * 1024; }
-
-// B(k, n): b_kmajor = 1 -> stored [N,K] (k contiguous), else [K,N].  One thread per (nb, ks, lane).
-template <class XF>
-__global__ __launch_bounds__(256) void presplit_kernel(const float* __restrict__ B, int64_t ldb, int b_kmajor, int64_t N, int64_t K,
-                                                       XF xf, u32x4* __restrict__ out) {
-  const int64_t nk = planes_nk(K);
-  const int64_t total = planes_nb(N) * nk * 64;
-  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    const int l = (int)(t & 63);
-    const int64_t unit = t >> 6, ks = unit % nk, nb = unit / nk;
-    const int64_t n = nb * 32 + (l & 31), k0 = ks * BK + (l >> 5) * 8;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int64_t k = k0 + j;
-      v[j] = (n < N && k < K) ? xf(b_kmajor ? B[n * ldb + k] : B[k * ldb + n], n, k) : 0.f;
-    }
-    u32x4 p0, p1, p2;
-    split8(v, p0, p1, p2);
-    u32x4* o = out + unit * 3 * 64 + l;
-    o[0] = p0;
-    o[64] = p1;
-    o[128] = p2;
-  }
-}
-
-constexpr int PB_DEPTH = 4;   // ring depth (k-steps) of both the A register stages and the B fragment stages
-
-// acc[tm] (tm = 0..3: rows 32 tm .. 32 tm + 31 of the 128-row block tile, this wave's 32 columns) += A[m0:m0+128, kbeg:kend] *
-// planes.  `bp` points at unit (this wave's nb, k-step 0, plane 0), lane included; kbeg is a multiple of 16.
-template <int AMAJ, bool VEC4, bool FULLONLY, bool GA = false, class XFA>
-__device__ __forceinline__ void mainloop_pb(f32x16 (&acc)[4], const float* __restrict__ A, int64_t lda, int64_t m0, int64_t M,
-                                            const u32x4* __restrict__ bp, int64_t kbeg, int64_t kend, const XFA& xfa, float* smem,
-                                            const int64_t* arows = nullptr) {
-  constexpr int D = PB_DEPTH;
-  constexpr int A_BUF = 3 * 128 * S_ROW;
-  const int nk = (int)((kend - kbeg + BK - 1) / BK);
-  if (nk <= 0) return;
-  const int lane = egnn_lane();
-  StagerS<128, AMAJ, VEC4, XFA, GA> sa[D];
-  u32x4 bq[D][3];
-  char* s = reinterpret_cast<char*>(smem);
-  const int ks0 = (int)(kbeg / BK);
-  auto stage_of = [&](int st) { return st < nk ? st : nk - 1; };   // clamped: see mainloop_split
-  auto load_a = [&](auto slot, int st) { sa[slot.value].template load<FULLONLY>(A, lda, m0, M, kbeg + (int64_t)stage_of(st) * BK, kend, xfa, arows); };
-  auto load_b = [&](auto slot, int st) {
-    const u32x4* q = bp + (int64_t)(ks0 + stage_of(st)) * (3 * 64);
-    bq[slot.value][0] = q[0];
-    bq[slot.value][1] = q[64];
-    bq[slot.value][2] = q[128];
-  };
-  auto step = [&](auto uc, int cur, bool more, int st_next_a, int st_next_b) {
-    constexpr int u = uc.value;
-    constexpr int sl_a = (u + 1) % D, sl_b = u % D;
-    const char* sA = s + cur * A_BUF + (lane & 31) * S_ROW + (lane >> 5) * 16;
-    u32x4 a[4][3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm) a[tm][p] = *reinterpret_cast<const u32x4*>(sA + p * 128 * S_ROW + tm * 32 * S_ROW);
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PBn[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-#pragma unroll
-      for (int tm = 0; tm < 4; ++tm)
-        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[tm][PA[t]]), __builtin_bit_cast(bf16x8, bq[sl_b][PBn[t]]),
-                                                          acc[tm], 0, 0, 0);
-      if (t == EGNN_SPLIT_COMMIT_AFTER && more) {
-        sa[sl_a].store(s + (cur ^ 1) * A_BUF);
-        load_a(std::integral_constant<int, sl_a>{}, st_next_a);
-      }
-    }
-    if (more) load_b(std::integral_constant<int, sl_b>{}, st_next_b);
-  };
-  static_for<D>([&](auto d) {
-    load_a(d, d.value);
-    load_b(d, d.value);
-  });
-  sa[0].store(s);
-  load_a(std::integral_constant<int, 0>{}, D);
-  __syncthreads();
-  int kt0 = 0;
-  if constexpr (FULLONLY) {
-    for (; kt0 + D <= nk; kt0 += D) {   // D is even: LDS buffer = u & 1; one basic block per D steps (see mainloop_split)
-      static_for<D>([&](auto u) {
-        step(u, u.value & 1, true, kt0 + u.value + 1 + D, kt0 + u.value + D);
-        __syncthreads();
-      });
-    }
-  }
-  for (; kt0 < nk; kt0 += D) {
-    static_for<D>([&](auto u) {
-      const int kt = kt0 + u.value;
-      if (kt < nk) {
-        step(u, u.value & 1, kt + 1 < nk, kt + 1 + D, kt + D);
-        __syncthreads();
-      }
-    });
-  }
-}
-
-
 // EGNN_GEMM_PIPE=f32 keeps every product on the f32-input MFMA (the A/B switch of the two pipelines)
 static inline bool egnn_split_pipe() {
   static const bool on = !(getenv("EGNN_GEMM_PIPE") && getenv("EGNN_GEMM_PIPE")[0] == 'f');

@@ -526,9 +526,7 @@ constexpr int kNce3SplitMax = 8;   // k ranges of the reduction (fixed-order red
 static inline int nce3_split(int64_t M) {
   // 4 k-ranges: 2 378 vs 2 433 us (8) vs 2 718 us (2) for forward + backward at S = 16 384, P = 256 (fewer partials to reduce, still one
   // workgroup per CU on the 256 x 256 side).  At S = 8 192 the 256 x 256 side has 32 tiles: 8 ranges fill the 256 CUs, 4 leave half of
-  // them idle (735 vs 814 us).  EGNN_NCE_KSPLIT = 2 | 4 | 8 is the lab knob.
-  static const int n = getenv("EGNN_NCE_KSPLIT") ? atoi(getenv("EGNN_NCE_KSPLIT")) : 0;
-  if (n == 2 || n == 4 || n == 8) return n;
+  // them idle (735 vs 814 us).
   return (M / 256) * 4 >= 256 ? 4 : 8;
 }
 
@@ -540,9 +538,8 @@ inline size_t nce3_ws_floats(int64_t M, int64_t P, int64_t Kd) {
 // true when this side of the backward can take the DMA pipeline (whole tiles, aligned E, unit-rows form with a workspace)
 template <int AMAJ>
 inline bool nce3_takes(int64_t M, int64_t Kd, int64_t P, int64_t ldz, const float* Z, bool expz, bool vec4, const float* ws) {
-  static const bool off = getenv("EGNN_NCE_DMA") && getenv("EGNN_NCE_DMA")[0] == '0';   // A/B switch: EGNN_NCE_DMA=0 keeps the staged pipeline
   constexpr int BM = AMAJ == KMAJOR ? 128 : 256, BN = AMAJ == KMAJOR ? 128 : 256, BKT = AMAJ == KMAJOR ? 32 : 16;
-  return !off && egnn_split_pipe() && expz && vec4 && ws && M % BM == 0 && P % BN == 0 && Kd % (kNce3SplitMax * BKT) == 0 && ldz % 4 == 0 &&
+  return egnn_split_pipe() && expz && vec4 && ws && M % BM == 0 && P % BN == 0 && Kd % (kNce3SplitMax * BKT) == 0 && ldz % 4 == 0 &&
          egnn_aligned16(Z) && Kd / kNce3SplitMax >= 4 * BKT;
 }
 
@@ -591,7 +588,7 @@ int launch_bwd(const float* Z, int64_t ldz, int64_t M, int64_t Kd, int64_t diag_
   // With a workspace the reduction is split so that every CU gets ~3 workgroups of 128 x 128 (fixed-order reduce
   // afterwards).  Without one: 128-row tiles only when they still give every CU at least two workgroups (one wave per
   // SIMD cannot hide its own staging), else the 64-row tile doubles the workgroup count.
-  static const int64_t min_tiles = getenv("EGNN_NCE_BM128_MIN_TILES") ? atoll(getenv("EGNN_NCE_BM128_MIN_TILES")) : 600;
+  constexpr int64_t min_tiles = 600;
   const int nsplit = ws ? nce_bwd_split(M, P, Kd) : 1;
   const bool big = ws || t128 >= min_tiles;
   const int64_t ksteps = (Kd + BK - 1) / BK;

@@ -1371,9 +1371,9 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
         sp = swap_batchnorm(PM.make_projection(model_cfg["hidden"], hp["proj_dim"]).to(device))
         tp = swap_batchnorm(PM.make_projection(data.teacher_out_feat.shape[1], hp["proj_dim"]).to(device))
         groups += [{"params": sp.parameters(), "lr": model_cfg["lr"]}, {"params": tp.parameters(), "lr": model_cfg["lr"]}]
-    if on_gpu and os.environ.get("EGNN_ADAM_GROUPS", "one") == "one":   # same hyper-parameters in every group (gnn.py:308-312): one launch
+    if on_gpu:   # same hyper-parameters in every group (gnn.py:308-312): one launch
         groups = [{"params": [p for g in groups for p in g["params"]], "lr": model_cfg["lr"]}]
-    opt = torch.optim.Adam(groups, fused=(on_gpu and os.environ.get("EGNN_ADAM", "fused") == "fused"), capturable=on_gpu)
+    opt = torch.optim.Adam(groups, fused=on_gpu, capturable=on_gpu)
     torch.manual_seed(args.seed + 1000 + rank)               # dropout masks differ per shard
 
     def eager_epoch():

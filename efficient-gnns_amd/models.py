@@ -21,10 +21,12 @@ from .sparse import SparseTensor
 
 
 _EVAL_BN_FOLD = True   # (no environment switch any more; tests flip the attribute to compare the fold with the separate normalisation pass)
-_TRAIN_ROWS = os.environ.get("EGNN_TRAIN_ROWS", "1") == "1"       # A/B switch: [train_idx] row picks inside the CE / KD kernels
-_LSP_FULL_ROWS = os.environ.get("EGNN_LSP_FULL_ROWS", "1") == "1"    # A/B switch: LSP on the full tensors through composed edge ids
-_FUSED_TAIL = os.environ.get("EGNN_FUSED_TAIL", "1") == "1"        # A/B switch: ops.bn_act_linear for the last hidden layer of a GCN
-_SAMPLED_HEADS = os.environ.get("EGNN_SAMPLED_HEADS", "1") == "1"  # A/B switch: projection heads form only the rows a sampled criterion keeps
+# Fusions measured in round 3 (profiles/r03_bench_line_r02_paths.json: all five off = 130.5 vs 144.3 epochs/s); module attributes, no
+# environment switches -- tests flip them to compare each fused form with its composed one.
+_TRAIN_ROWS = True        # [train_idx] row picks inside the CE / KD kernels
+_LSP_FULL_ROWS = True     # LSP on the full tensors through composed edge ids
+_FUSED_TAIL = True        # ops.bn_act_linear for the last hidden layer of a GCN
+_SAMPLED_HEADS = True     # projection heads form only the rows a sampled criterion keeps
 
 
 class _Student(nn.Module):
@@ -40,57 +42,63 @@ class _Student(nn.Module):
         for m in list(self.convs) + list(self.bns):
             m.reset_parameters()
 
-    def _fused_tail(self, x, adj_t):
-        """True when the last hidden layer's BatchNorm + activation and the output conv's narrow ``x @ W`` can run as one op
-        (``ops.bn_act_linear``): GCN on a plain SparseTensor adjacency, training, classes <= 64."""
-        last = self.convs[-1]
-        return (_FUSED_TAIL and self.training and torch.is_grad_enabled() and x.is_cuda and isinstance(adj_t, SparseTensor)
-                and isinstance(last, GCNConv) and type(self.bns[-1]) is nn.BatchNorm1d and last.in_channels >= last.out_channels
-                and last.out_channels <= 64 and last.in_channels % 64 == 0 and not hasattr(adj_t, "gcn_normalized"))
+    # ---- the layer plan ---------------------------------------------------------------------------------------------------
+    # Every hidden layer is conv -> BatchNorm -> ReLU -> dropout (gnn.py:47-50).  WHICH kernels run it depends on five facts that
+    # hold for a whole forward pass (mode, grad mode, device, adjacency kind, module types); ``_layer_form`` names the pair
+    # (conv form, activation form) of a layer and ``forward`` only executes it:
+    #   conv form   "fold"   test(): eval-mode BatchNorm folded into the conv's weights, ReLU in the last kernel's store (no act.)
+    #               "stats"  training GCNConv on a plain adjacency: BatchNorm statistics from the aggregation's store epilogue
+    #               "plain"  conv(x, adj_t)
+    #   act. form   "tail"       last hidden layer of a GCN: BN + ReLU + dropout + gradient tap + the output conv's h @ W as ONE op
+    #               "tail_sync"  the same on node-range shards (dist.SyncBatchNorm1d: all-rank statistics)
+    #               "bn_act"     fused BN + ReLU + dropout kernels (torch.nn.BatchNorm1d)
+    #               "sync"       dist.SyncBatchNorm1d.fused_act
+    #               "torch"      another norm module (CPU tensors: the gloo tests' stand-in switch only)
+    def _layer_form(self, li, x, adj_t):
+        conv, bn, last = self.convs[li], self.bns[li], self.convs[-1]
+        training, grad, gpu = self.training, torch.is_grad_enabled(), x.is_cuda
+        plain_adj, sharded_adj = isinstance(adj_t, SparseTensor), hasattr(adj_t, "gcn_normalized")
+        gcn, torch_bn, sync_bn = isinstance(conv, GCNConv), isinstance(bn, nn.BatchNorm1d), hasattr(bn, "fused_act")
+        if (_EVAL_BN_FOLD and not training and not grad and gcn and gpu and not conv._uses_memoised_input(x)
+                and ((type(bn) is nn.BatchNorm1d and bn.track_running_stats and plain_adj) or (sharded_adj and sync_bn))):
+            return "fold", None
+        conv_form = "stats" if (gcn and torch_bn and gpu and training and plain_adj) else "plain"
+        act = "bn_act" if (torch_bn and gpu) else ("sync" if sync_bn else "torch")
+        if (li == len(self.bns) - 1 and _FUSED_TAIL and training and grad and gpu and isinstance(last, GCNConv)
+                and last.in_channels >= last.out_channels):
+            if plain_adj and not sharded_adj and type(bn) is nn.BatchNorm1d and last.out_channels <= 64 and last.in_channels % 64 == 0:
+                act = "tail"
+            elif sharded_adj and hasattr(bn, "fused_act_linear"):
+                act = "tail_sync"
+        return conv_form, act
 
     def forward(self, x, adj_t):
-        n_hidden = len(self.bns)
         for li, (conv, bn) in enumerate(zip(self.convs[:-1], self.bns)):
-            sharded = hasattr(adj_t, "gcn_normalized") and hasattr(bn, "fused_act")       # node-range shard + dist.SyncBatchNorm1d
-            if (_EVAL_BN_FOLD and not self.training and not torch.is_grad_enabled() and isinstance(conv, GCNConv) and x.is_cuda
-                    and ((type(bn) is nn.BatchNorm1d and bn.track_running_stats and isinstance(adj_t, SparseTensor)) or sharded)
-                    and not conv._uses_memoised_input(x)):
-                # test(): BatchNorm on running statistics folded into the conv's weights, ReLU in the last kernel's store
+            conv_form, act = self._layer_form(li, x, adj_t)
+            if conv_form == "fold":
                 x = self.out_feat = conv(x, adj_t, eval_bn=bn)
                 continue
-            if (isinstance(conv, GCNConv) and isinstance(bn, nn.BatchNorm1d) and x.is_cuda and self.training
-                    and isinstance(adj_t, SparseTensor)):
-                # BatchNorm follows (gnn.py:47-48): its batch statistics come out of the aggregation's store epilogue
-                x = conv(x, adj_t, bn_stats_shift=bn.running_mean, want_bn_stats=True)
-            else:
-                x = conv(x, adj_t)
-            if li == n_hidden - 1 and self._fused_tail(x, adj_t):
-                # last hidden layer: BatchNorm + ReLU + dropout, the gradient tap and the output conv's x @ W as one op, whose
-                # backward is one pass over the [N, hidden] tensors (ops._BnActLinear)
-                both = ops.bn_act_linear(x, bn, self.convs[-1].weight, relu=True, p=self.dropout, training=True)
+            x = conv(x, adj_t, bn_stats_shift=bn.running_mean, want_bn_stats=True) if conv_form == "stats" else conv(x, adj_t)
+            if act in ("tail", "tail_sync"):
+                # (h, h @ W_out) in one op whose backward is one pass over the [N, hidden] tensors (ops._BnActLinear); None = the fused
+                # kernels do not take this shape: the composed form below
+                both = (ops.bn_act_linear(x, bn, self.convs[-1].weight, relu=True, p=self.dropout, training=True) if act == "tail"
+                        else bn.fused_act_linear(x, self.convs[-1].weight, True, self.dropout, True))
                 if both is not None:
                     self.out_feat, xw = both
                     return self.convs[-1](self.out_feat, adj_t, xw=xw)
-            if (li == n_hidden - 1 and _FUSED_TAIL and self.training and torch.is_grad_enabled() and hasattr(bn, "fused_act_linear")
-                    and isinstance(self.convs[-1], GCNConv) and hasattr(adj_t, "gcn_normalized")
-                    and self.convs[-1].in_channels >= self.convs[-1].out_channels):
-                # the same fused tail on node-range shards: all-rank statistics (dist.SyncBatchNorm1d), one all-reduce in its backward
-                both = bn.fused_act_linear(x, self.convs[-1].weight, True, self.dropout, True)
-                if both is not None:
-                    self.out_feat, xw = both
-                    return self.convs[-1](self.out_feat, adj_t, xw=xw)
-            if isinstance(bn, nn.BatchNorm1d) and x.is_cuda:   # fused BN + ReLU + dropout kernels (gnn.py:48-50)
+                act = "bn_act" if act == "tail" else "sync"
+            if act == "bn_act":
                 x = ops.bn_act(x, bn, relu=True, p=self.dropout, training=self.training)
-            elif hasattr(bn, "fused_act"):                      # dist.SyncBatchNorm1d on sharded runs (all-rank statistics)
+            elif act == "sync":
                 x = bn.fused_act(x, True, self.dropout, self.training)
-            else:                                               # another norm module on the GPU; CPU tensors: tests' stand-in switch only
-                _lib.on_gpu(x)
+            else:
+                _lib.on_gpu(x)         # raises for a CPU tensor outside the tests' stand-in switch
                 x = F.dropout(F.relu(bn(x)), p=self.dropout, training=self.training)
             self.out_feat = x
         if self.training and x.is_cuda:
-            # the last hidden state has two consumers (the last conv and student_proj(out_feat[train_idx]), gnn.py:150):
-            # the projection's row-compact input gradient is added into the conv's dense one instead of autograd's
-            # zero-fill + scatter + full-size add (ops._GradTap)
+            # the last hidden state has two consumers (the last conv and student_proj(out_feat[train_idx]), gnn.py:150): the projection's
+            # row-compact input gradient is added into the conv's dense one instead of autograd's zero-fill + scatter + full-size add
             x = self.out_feat = ops.grad_tap(x)
         return self.convs[-1](x, adj_t)
 

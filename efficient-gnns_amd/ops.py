@@ -36,7 +36,7 @@ def _rowmajor(x: Tensor) -> Tensor:
 # SpMM
 # ------------------------------------------------------------------------------------------------
 # 'blocks' (default): egnn_spmm_csr_blk_f32; 'segments': egnn_spmm_csr_seg_f32; 'classes': short / mid / long row classes
-_SPMM_SCHEDULE = os.environ.get("EGNN_SPMM_SCHEDULE", "blocks")
+_SPMM_SCHEDULE = "blocks"   # "blocks" (row blocks, K >= 64) -> "segments" (K < 64) -> "classes" (max / unaligned); tests pin one by setting the attribute
 
 
 class HipStatsUnavailable(RuntimeError):
@@ -391,8 +391,10 @@ def gemm_raw(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False,
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
     if split_k is None:
         # reductions over many rows into a small output (dW = X^T dY): spread K over the chip
+        # (two workgroups per CU = 512 slots: 2 or 4 output tiles take 128 ranges -- 163 vs 178 us on 256 x 256 x 169 343, 106 vs 140 us on
+        # 128 x 256 x 169 343; from 6 tiles on 64 ranges stay ahead: profiles/r05_splitk_sweep.txt)
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
-        split_k = 1 if tiles >= 128 or K < 4096 else max(1, min(64, 512 // max(tiles, 1), K // 1024))
+        split_k = 1 if tiles >= 128 or K < 4096 else max(1, min(128 if tiles <= 4 else 64, 512 // max(tiles, 1), K // 1024))
     lib = _lib.load()
     ws = None
     # split-K partials, the skinny kernels' row-chunk partials, the bf16 planes of a small B operand (gemm_split.h)

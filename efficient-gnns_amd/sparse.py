@@ -21,11 +21,11 @@ from . import _lib
 
 import os
 
-SHORT_ROW_MAX = int(os.environ.get("EGNN_SHORT_ROW_MAX", "64"))    # rows up to this length share a wavefront
-LONG_ROW_THRESHOLD = int(os.environ.get("EGNN_LONG_ROW_MIN", "512"))  # rows above it get a 16-wave workgroup
-SEG_MAX = int(os.environ.get("EGNN_SPMM_SEG_MAX", "64"))   # entries per range of the segment schedule
-BLK_ROWS = int(os.environ.get("EGNN_SPMM_BLK_ROWS", "32"))  # rows per workgroup of the row-block schedule (multiple of 32)
-PLAN_CHUNK = int(os.environ.get("EGNN_PLAN_CHUNK", "1"))  # >1: length-sort short rows inside chunks of this many rows (measured slower: locality wins)
+SHORT_ROW_MAX = 64          # rows up to this length share a wavefront
+LONG_ROW_THRESHOLD = 512    # rows above it get a 16-wave workgroup
+SEG_MAX = 64                # entries per range of the segment schedule
+BLK_ROWS = 32               # rows per workgroup of the row-block schedule (multiple of 32; 32 / 64 / 128: 346 / 352 / 357 us, r02_spmm_lab.md)
+PLAN_CHUNK = 1              # >1: length-sort short rows inside chunks of this many rows (measured slower: locality wins)
 
 
 def _ind2ptr(row: Tensor, n_rows: int) -> Tensor:

@@ -9,7 +9,12 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator); no entry
- *     point allocates, frees, synchronises or keeps global state: all are re-entrant;
+ *     point allocates, frees or synchronises, and none keeps state between calls: all are re-entrant.
+ *     Two process-wide, write-once values exist: the GEMM pipeline choice read from the environment on
+ *     first use (EGNN_GEMM_PIPE=f32 pins every product to the f32-input MFMA; default: the bf16-split
+ *     pipeline, csrc/gemm_split.h) and the per-device "large dynamic LDS" opt-in of the kernels that need
+ *     more than 64 KB (hipFuncSetAttribute, once per kernel and device).  No other environment variable
+ *     is read by the library;
  *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream);
  *   - dense matrices are row-major fp32 with an explicit leading dimension in ELEMENTS;
  *   - sparse structure is CSR; index arrays are int32 or int64, selected by `index_bits` (32|64).
