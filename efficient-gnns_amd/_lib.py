@@ -86,6 +86,9 @@ SIGNATURES = {
     "egnn_bn_act_rows_fwd_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _i64, _p]),
     "egnn_bn_act_rows_bwd_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _i32, _p, _p,
                                         _p, _i64, _p, _p, _sz, _p]),
+    "egnn_bn_act_rows_bwd_reduce_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _p, _p, _sz, _p]),
+    "egnn_bn_act_rows_bwd_apply_f32": (_i32, [_p, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _p, _f32, _p, _p,
+                                              _i64, _p, _p, _sz, _p]),
     "egnn_bn_act_linear_fwd_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _f32, _p, _p, _i32, _f32, _u64, _p, _p, _i64, _i32, _i64, _p, _i64, _p,
                                           _i64, _p]),
     "egnn_skinny_dx_bn_ws_floats": (_sz, [_i64, _i64]),
@@ -133,7 +136,7 @@ def load() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.egnn_abi_version() != 5:
+    if lib.egnn_abi_version() != 6:
         raise HipExtensionError("libegnn_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -506,41 +506,74 @@ extern "C" int egnn_bn_act_rows_fwd_f32(const float* x, int64_t ld, int64_t n, i
   return egnn_launch_status();
 }
 
+// The backward of the picked-rows form in its two halves (a node-range shard all-reduces [sum d | sum d xhat] between them: SyncBN).
+extern "C" int egnn_bn_act_rows_bwd_reduce_f32(const float* x, int64_t ld, int64_t n, int64_t C, const int64_t* pick, int64_t n_pick,
+                                               const float* dy, int64_t ld_dy, const float* mean, const float* var, float eps,
+                                               const float* gamma, const float* beta, int relu, float p, uint64_t seed,
+                                               const uint64_t* seed_dev, float* dgamma, float* dbeta, float* ws, size_t ws_floats, void* stream) {
+  EGNN_CHECK_ARG(n > 0 && n_pick > 0 && n_pick <= n && pick && x && dy && mean && var && dgamma && dbeta && ws && ld >= C && ld_dy >= C);
+  if (!shape_ok(x, ld, C) || !shape_ok(dy, ld_dy, C)) return EGNN_EALIGN;
+  if (ws_floats < egnn_bn_ws_floats(C)) return EGNN_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const BnParams qp{x, ld, n_pick, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed, (const unsigned long long*)seed_dev, pick};
+  // sum d, sum d xhat over the picked rows (every other output row has no gradient)
+  const int64_t want = (n_pick + 3) / 4;
+  const int nbr = (int)(want < kStatBlocks ? want : kStatBlocks);
+  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nbr), dim3(256), 0, st, qp, dy, ld_dy, ws);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)((C + kMergeCols - 1) / kMergeCols)), dim3(256), 0, st, ws, nbr, C, dbeta, dgamma);
+  return egnn_launch_status();
+}
+
+// sum_dbeta / sum_dgamma: the sums the mean / variance terms use (this tensor's own, or the all-rank ones), inv_count = 1 / rows they span
+// (0: running statistics, no such terms).  local_dbeta (needed with dx_colsum): sum d over THIS tensor's picked rows -- the picked rows'
+// own term gamma rstd d sums to gamma rstd local_dbeta per column.  n_pick == 0 (a shard without sampled rows): every row still
+// receives the mean / variance terms.
+extern "C" int egnn_bn_act_rows_bwd_apply_f32(const float* x, int64_t ld, int64_t n, int64_t C, const int64_t* pick, int64_t n_pick,
+                                              const float* dy, int64_t ld_dy, const float* mean, const float* var, float eps,
+                                              const float* gamma, const float* beta, int relu, float p, uint64_t seed,
+                                              const uint64_t* seed_dev, const float* sum_dbeta, const float* sum_dgamma, float inv_count,
+                                              const float* local_dbeta, float* dx, int64_t ld_dx, float* dx_colsum, float* ws,
+                                              size_t ws_floats, void* stream) {
+  EGNN_CHECK_ARG(n > 0 && n_pick >= 0 && n_pick <= n && x && mean && var && sum_dbeta && sum_dgamma && dx && ld >= C && ld_dx >= C);
+  EGNN_CHECK_ARG(n_pick == 0 || (pick && dy && ld_dy >= C));
+  EGNN_CHECK_ARG(dx_colsum == nullptr || n_pick == 0 || local_dbeta);
+  if (!shape_ok(x, ld, C) || !shape_ok(dx, ld_dx, C) || (n_pick > 0 && !shape_ok(dy, ld_dy, C))) return EGNN_EALIGN;
+  if (dx_colsum && (ws == nullptr || ws_floats < egnn_bn_ws_floats(C))) return EGNN_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const BnParams qp{x, ld, n_pick, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed, (const unsigned long long*)seed_dev, pick};
+  const BnParams qa{x, ld, n, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed, (const unsigned long long*)seed_dev, nullptr};
+  // every row: the mean / variance terms;  then the picked rows: + gamma rstd d
+  int nb = row_blocks(n);
+  if (dx_colsum) {
+    if (nb > 2 * kStatBlocks) nb = 2 * kStatBlocks;
+    nb = (nb + 1) & ~1;
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<true, 1>), dim3(nb), dim3(256), 0, st, qa, (const float*)nullptr, (int64_t)0, sum_dbeta, sum_dgamma,
+                       inv_count, dx, ld_dx, ws);
+  } else {
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<false, 1>), dim3(nb), dim3(256), 0, st, qa, (const float*)nullptr, (int64_t)0, sum_dbeta, sum_dgamma,
+                       inv_count, dx, ld_dx, (float*)nullptr);
+  }
+  if (n_pick > 0)
+    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<false, 2>), dim3(row_blocks(n_pick)), dim3(256), 0, st, qp, dy, ld_dy, sum_dbeta, sum_dgamma, inv_count,
+                       dx, ld_dx, (float*)nullptr);
+  if (dx_colsum)
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((C + kMergeCols - 1) / kMergeCols)), dim3(256), 0, st, ws, nb / 2, C, dx_colsum, gamma,
+                       var, eps, n_pick > 0 ? local_dbeta : (const float*)nullptr);
+  return egnn_launch_status();
+}
+
 extern "C" int egnn_bn_act_rows_bwd_f32(const float* x, int64_t ld, int64_t n, int64_t C, const int64_t* pick, int64_t n_pick,
                                         const float* dy, int64_t ld_dy, const float* mean, const float* var, float eps, const float* gamma,
                                         const float* beta, int relu, float p, uint64_t seed, const uint64_t* seed_dev, int batch_stats,
                                         float* dgamma, float* dbeta, float* dx, int64_t ld_dx, float* dx_colsum, float* ws, size_t ws_floats,
                                         void* stream) {
-  EGNN_CHECK_ARG(n > 0 && n_pick > 0 && n_pick <= n && pick && x && dy && mean && var && dgamma && dbeta && dx && ws && ld >= C &&
-                 ld_dy >= C && ld_dx >= C);
-  if (!shape_ok(x, ld, C) || !shape_ok(dy, ld_dy, C) || !shape_ok(dx, ld_dx, C)) return EGNN_EALIGN;
-  if (ws_floats < egnn_bn_ws_floats(C)) return EGNN_EWORKSPACE;
-  hipStream_t st = (hipStream_t)stream;
-  const BnParams qp{x, ld, n_pick, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed, (const unsigned long long*)seed_dev, pick};
-  const BnParams qa{x, ld, n, C, mean, var, eps, gamma, beta, relu, p, (unsigned long long)seed, (const unsigned long long*)seed_dev, nullptr};
-  // sum d, sum d xhat over the picked rows
-  const int64_t want = (n_pick + 3) / 4;
-  const int nbr = (int)(want < kStatBlocks ? want : kStatBlocks);
-  hipLaunchKernelGGL(bn_act_bwd_reduce_kernel, dim3(nbr), dim3(256), 0, st, qp, dy, ld_dy, ws);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((unsigned)((C + kMergeCols - 1) / kMergeCols)), dim3(256), 0, st, ws, nbr, C, dbeta, dgamma);
-  // every row: the mean / variance terms;  then the picked rows: + gamma rstd d
-  const float inv_count = batch_stats ? 1.f / (float)n : 0.f;
-  int nb = row_blocks(n);
-  if (dx_colsum) {
-    if (nb > 2 * kStatBlocks) nb = 2 * kStatBlocks;
-    nb = (nb + 1) & ~1;
-    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<true, 1>), dim3(nb), dim3(256), 0, st, qa, (const float*)nullptr, (int64_t)0, dbeta, dgamma,
-                       inv_count, dx, ld_dx, ws);
-  } else {
-    hipLaunchKernelGGL((bn_act_bwd_apply_kernel<false, 1>), dim3(nb), dim3(256), 0, st, qa, (const float*)nullptr, (int64_t)0, dbeta, dgamma,
-                       inv_count, dx, ld_dx, (float*)nullptr);
-  }
-  hipLaunchKernelGGL((bn_act_bwd_apply_kernel<false, 2>), dim3(row_blocks(n_pick)), dim3(256), 0, st, qp, dy, ld_dy, dbeta, dgamma, inv_count, dx,
-                     ld_dx, (float*)nullptr);
-  if (dx_colsum)
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((C + kMergeCols - 1) / kMergeCols)), dim3(256), 0, st, ws, nb / 2, C, dx_colsum, gamma,
-                       var, eps, (const float*)dbeta);
-  return egnn_launch_status();
+  EGNN_CHECK_ARG(n > 0 && n_pick > 0 && dx && ld_dx >= C);
+  if (!shape_ok(dx, ld_dx, C)) return EGNN_EALIGN;
+  const int rc = egnn_bn_act_rows_bwd_reduce_f32(x, ld, n, C, pick, n_pick, dy, ld_dy, mean, var, eps, gamma, beta, relu, p, seed, seed_dev, dgamma,
+                                                 dbeta, ws, ws_floats, stream);
+  if (rc != EGNN_OK) return rc;
+  return egnn_bn_act_rows_bwd_apply_f32(x, ld, n, C, pick, n_pick, dy, ld_dy, mean, var, eps, gamma, beta, relu, p, seed, seed_dev, dbeta, dgamma,
+                                        batch_stats ? 1.f / (float)n : 0.f, dbeta, dx, ld_dx, dx_colsum, ws, ws_floats, stream);
 }
 
 extern "C" int egnn_bn_act_bwd_f32(const float* x, int64_t ld, const float* dy, int64_t ld_dy, int64_t n, int64_t C,

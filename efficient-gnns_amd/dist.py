@@ -570,16 +570,19 @@ class SyncBatchNorm1d(nn.Module):
         self._update_running(mean, var, n)
         return y
 
-    def fused_act(self, x: Tensor, relu: bool, p: float, training: bool) -> Tensor:
+    def fused_act(self, x: Tensor, relu: bool, p: float, training: bool, pick: Tensor | None = None) -> Tensor:
         """dropout(relu(self(x)), p) -- on the GPU through the fused BN + ReLU + dropout kernels (ops.sync_bn_act /
-        ops.bn_act), elsewhere (gloo tests) through the torch operators above."""
+        ops.bn_act), elsewhere (gloo tests) through the torch operators above.  ``pick`` (unique row ids): only those rows of the
+        result are formed; the statistics still span every row of every rank."""
         if not (_lib.on_gpu(x) and ops.bn_shape_ok(x)):
             y = self(x)
             y = torch.relu(y) if relu else y
-            return torch.nn.functional.dropout(y, p, training) if p > 0 else y
+            y = torch.nn.functional.dropout(y, p, training) if p > 0 else y
+            return y if pick is None else y[pick]
         if not training:   # running statistics: the single-GPU kernel applies as it is
-            return ops._BnAct.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, relu, 0.0, 0, False)
-        y, mean, var, n = ops.sync_bn_act(x, self, relu, p, training, self.group)
+            y = ops._BnAct.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps, relu, 0.0, 0, False)
+            return y if pick is None else y[pick]
+        y, mean, var, n = ops.sync_bn_act(x, self, relu, p, training, self.group, pick)
         self._update_running(mean, var, n)
         return y
 
@@ -736,8 +739,11 @@ class _GatherPadded(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, perm, cap, rank, world, reduce_grad, group):
         m, Q = x.shape
-        pad = x.new_zeros(cap, Q)
-        pad[:m].copy_(x)
+        if m == cap:                       # a full block (one rank: always): nothing to pad
+            pad = x.contiguous()
+        else:
+            pad = x.new_zeros(cap, Q)
+            pad[:m].copy_(x)
         if world > 1:
             allx = torch.empty(world * cap, Q, dtype=x.dtype, device=x.device)
             dist.all_gather_into_tensor(allx, pad, group=group)
@@ -751,8 +757,9 @@ class _GatherPadded(torch.autograd.Function):
     def backward(ctx, g):
         (perm,) = ctx.saved_tensors
         m, cap, rank, world, reduce_grad, group = ctx.meta
-        gp = g.new_zeros(world * cap, g.shape[1])
-        gp.index_copy_(0, perm, g.contiguous())                # perm holds unique positions
+        # perm holds unique positions; when it addresses EVERY padded row (one rank: cap == S) no row is left to zero
+        gp = g.new_empty(world * cap, g.shape[1]) if perm.numel() == world * cap else g.new_zeros(world * cap, g.shape[1])
+        gp.index_copy_(0, perm, g.contiguous())
         if reduce_grad and world > 1:
             from . import hostcomm
             if dist.get_backend(group) == "nccl" or hostcomm.active():   # every rank only needs ITS block of the sum
@@ -776,11 +783,12 @@ class _BalancedNCE(torch.autograd.Function):
         per = (S + world - 1) // world
         r0 = min(rank * per, S)
         r1 = min(r0 + per, S)
-        loss = torch.zeros(1, dtype=torch.float32, device=fhat_all.device)
         saved = [fhat_all, t_all]
         if r1 > r0:
             Z, lse, loss = ops.nce_block_fwd(fhat_all[r0:r1], t_all, r0, tau, 1.0 / S)
             saved += [Z, lse]
+        else:
+            loss = torch.zeros(1, dtype=torch.float32, device=fhat_all.device)
         if world > 1:
             dist.all_reduce(loss, group=group)
         ctx.save_for_backward(*saved)
@@ -792,12 +800,15 @@ class _BalancedNCE(torch.autograd.Function):
         tau, r0, r1, S = ctx.meta
         saved = ctx.saved_tensors
         fhat_all, t_all = saved[0], saved[1]
-        df_all = torch.zeros_like(fhat_all)
         if r1 > r0:
             df, dt_all = ops.nce_block_bwd(fhat_all[r0:r1], t_all, r0, 1.0 / (S * tau), saved[2], saved[3], g.contiguous().to(torch.float32), tau)
-            df_all[r0:r1].copy_(df)
+            if r0 == 0 and r1 == S:        # one rank: the block is the whole problem
+                df_all = df
+            else:
+                df_all = torch.zeros_like(fhat_all)
+                df_all[r0:r1].copy_(df)
         else:
-            dt_all = torch.zeros_like(t_all)
+            df_all, dt_all = torch.zeros_like(fhat_all), torch.zeros_like(t_all)
         return df_all, dt_all, None, None, None, None
 
 
@@ -818,13 +829,13 @@ def _static_sample_ready(prob: "ShardedProblem") -> bool:
 
 
 def _static_sampled_pair(prob: "ShardedProblem", f: Tensor, t: Tensor, normalize: bool, reduce_grad: bool):
-    """(student rows, teacher rows) [S, P] of the global sample in draw order, identical on every rank, from this rank's
-    projected train rows f / t -- ONE all-gather of the [cap, Ps + Pt] block."""
+    """(student rows, teacher rows) [S, P] of the global sample in draw order, identical on every rank, from this rank's projected
+    rows f / t [m, P] (the rows ``static_sample.idx_dev[:m]`` of the heads' outputs, already picked) -- ONE all-gather of the
+    [cap, Ps + Pt] block."""
     ss = prob.static_sample
-    idx = ss.idx_dev[:ss.m]
     if ss.m > 0:
-        fs = ops.gather_normalize(f, idx) if normalize else ops.take_rows(f, idx)
-        ts = ops.gather_normalize(t, idx) if normalize else ops.take_rows(t, idx)
+        fs = ops.gather_normalize(f, None) if normalize else f
+        ts = ops.gather_normalize(t, None) if normalize else t
         block = torch.cat([fs, ts], dim=1)
     else:   # a rank without train rows: an empty block that stays attached to both heads' graphs
         block = torch.cat([f[:0], t[:0]], dim=1)
@@ -896,6 +907,7 @@ class ShardedProblem:
         self.sample_hook = None          # ShardedGraphedEpoch: static device buffer instead of the per-step host draw + upload
         self.static_sample = None        # StaticSample: the sampled criteria run in draw-independent shapes
         self._forced_pick = None
+        self._zero = None
         self.x = data.x[lo:hi].to(device)
         self.adj.register_static(self.x)          # input features never change: halo copy fetched once
         self.y = data.y[lo:hi].to(device)
@@ -920,6 +932,15 @@ class ShardedProblem:
             m = (idx >= lo) & (idx < hi)
             self.split_local[k] = (idx[m] - lo).to(device)
             self.split_sizes[k] = idx.numel()
+
+
+def _zero_scalar(prob: "ShardedProblem") -> Tensor:
+    if prob._zero is None:
+        prob._zero = torch.zeros((), dtype=torch.float32, device=prob.x.device)     # a constant: made once, never written
+    return prob._zero
+
+
+ShardedProblem.zero_scalar = _zero_scalar
 
 
 def _train_subgraph(prob: ShardedProblem) -> _TrainSubgraph:
@@ -1041,41 +1062,50 @@ def sharded_train_step_tensors(model, prob: ShardedProblem, optimizer, mode: str
             p.train()
     group = prob.group
     take = ops.take_rows if _lib.on_gpu(prob.x) else (lambda t, i: t[i])   # train ids are unique: gather / scatter without a sort
-    out = take(model(prob.x, prob.adj), prob.train_local)
-    labels = prob.y.squeeze(1)[prob.train_local]
-    frac = out.shape[0] / prob.n_train_global               # local mean -> contribution to the global mean
-    dev = out.device
-    zero = torch.zeros((), dtype=torch.float32, device=dev)
+    logits = model(prob.x, prob.adj)
+    rows, n_tr = prob.train_local, int(prob.train_local.numel())
+    labels = prob.y.view(-1)
+    frac = n_tr / prob.n_train_global                      # local mean -> contribution to the global mean
+    dev = logits.device
+    zero = prob.zero_scalar()
     # A rank that owns no train row still has to run the SAME backward collectives as its peers (halo exchange and
     # SyncBN reductions of every layer): its loss terms are exact zeros that stay attached to the model's graph.
-    # (formed only on such a rank: ``out`` is then empty and the sum is a trivial launch, never a long reduction inside a captured step)
-    attached_zero = (out.sum() * 0.0) if out.shape[0] == 0 else None
+    # (formed only on such a rank, from ONE row: never a long reduction inside a captured step, _audit.py)
+    attached_zero = (logits[:1].sum() * 0.0) if n_tr == 0 else None
+    # gnn.py:109-110 `out = model(...)[train_idx]`, `y.squeeze(1)[train_idx]`, `teacher_logits[train_idx]`: the row picks happen inside
+    # the CE / KD kernels (their backward writes the dense logits gradient) -- no gather / zero-fill + scatter of [n_train, classes]
+    ce = lambda: ops.cross_entropy(logits, labels, rows) * frac   # noqa: E731
+
+    def heads(pick):
+        """(student rows, teacher rows) of the projection heads: all local train rows enter the Linear and the (all-rank) BatchNorm
+        statistics; with ``pick`` only those output rows are normalised and stored (ops.sync_bn_act(..., pick=))."""
+        if hasattr(student_proj, "forward_rows") and prob.x.is_cuda:
+            return (student_proj.forward_rows(model.out_feat, rows, pick=pick), teacher_proj.forward_rows(prob.teacher_out_feat, rows, pick=pick))
+        f, t = student_proj(take(model.out_feat, rows)), teacher_proj(take(prob.teacher_out_feat, rows))
+        return (f, t) if pick is None else (f[pick], t[pick])
     if mode == "supervised":
-        loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else attached_zero
+        loss_cls = ce() if n_tr else attached_zero
         loss_aux = zero
         loss = loss_cls
     elif mode == "kd":
-        if out.shape[0]:
-            lc, lk = ops.ce_and_kd(out, labels, prob.teacher_logits[prob.train_local], hp["kd_T"])
+        if n_tr:
+            lc, lk = ops.ce_and_kd(logits, labels, prob.teacher_logits, hp["kd_T"], rows)
             loss_cls, loss_aux = lc * frac, lk * frac
         else:
             loss_cls = loss_aux = attached_zero
         loss = loss_aux * (hp["alpha"] * hp["kd_T"] ** 2) + loss_cls * (1 - hp["alpha"])
     elif mode == "nce":
-        loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else attached_zero
-        if hasattr(student_proj, "forward_rows") and prob.x.is_cuda:
-            f = student_proj.forward_rows(model.out_feat, prob.train_local)
-            t = teacher_proj.forward_rows(prob.teacher_out_feat, prob.train_local)
-        else:
-            f = student_proj(take(model.out_feat, prob.train_local))
-            t = teacher_proj(take(prob.teacher_out_feat, prob.train_local))
+        loss_cls = ce() if n_tr else attached_zero
         if _static_sample_ready(prob):
+            ss = prob.static_sample
+            f, t = heads(ss.idx_dev[:ss.m])
             fhat_all, t_all = _static_sampled_pair(prob, f, t, normalize=True, reduce_grad=True)
             loss_aux = _BalancedNCE.apply(fhat_all, t_all, hp["nce_T"], prob.rank, prob.world, group)
         else:
             idx, counts = _sampled_rows(prob, hp["max_samples"], dev)
-            fhat = ops.gather_normalize(f, idx)
-            that = ops.gather_normalize(t, idx)
+            f, t = heads(idx)
+            fhat = ops.gather_normalize(f, None)
+            that = ops.gather_normalize(t, None)
             loss_aux = _DistNCE.apply(fhat, that, hp["nce_T"], counts, prob.rank, group)
         # loss_aux is already the global value on every rank: scale its gradient contribution once (1/world per rank
         # would double count the all-reduce of parameter grads), so only the local row block's graph carries grad
@@ -1084,26 +1114,23 @@ def sharded_train_step_tensors(model, prob: ShardedProblem, optimizer, mode: str
         # GSP (criterion.py:57-92): the sampled rows of all ranks are gathered and the all-pairs loss is evaluated in full on
         # every rank (same NumPy draw everywhere; S <= 4096 in the configuration of record)
         from . import ops_pairwise
-        loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else attached_zero
-        if hasattr(student_proj, "forward_rows") and prob.x.is_cuda:
-            f = student_proj.forward_rows(model.out_feat, prob.train_local)
-            t = teacher_proj.forward_rows(prob.teacher_out_feat, prob.train_local)
-        else:
-            f = student_proj(take(model.out_feat, prob.train_local))
-            t = teacher_proj(take(prob.teacher_out_feat, prob.train_local))
+        loss_cls = ce() if n_tr else attached_zero
         if _static_sample_ready(prob):
+            ss = prob.static_sample
+            f, t = heads(ss.idx_dev[:ss.m])
             fs, ts = _static_sampled_pair(prob, f, t, normalize=False, reduce_grad=False)
         else:
             idx, counts = _sampled_rows(prob, hp["max_samples"], dev)
-            fs = _GatherSampledRows.apply(f[idx], counts, prob.rank, group)
-            ts = _GatherSampledRows.apply(t[idx], counts, prob.rank, group)
+            f, t = heads(idx)
+            fs = _GatherSampledRows.apply(f, counts, prob.rank, group)
+            ts = _GatherSampledRows.apply(t, counts, prob.rank, group)
         loss_aux = ops_pairwise.gsp_loss(fs, ts, None, hp["kernel"])      # the GLOBAL value on every rank
         loss = loss_cls + hp["beta"] * loss_aux
     elif mode == "lpw":
         # LSP (criterion.py:95-126): every rank owns the softmax groups of its train nodes; remote train neighbours' rows of the
         # student's hidden state arrive by a halo exchange (autograd: reverse exchange), the teacher's once
         from . import ops_edge
-        loss_cls = (ops.cross_entropy(out, labels) * frac) if out.shape[0] else attached_zero
+        loss_cls = ce() if n_tr else attached_zero
         sub = _train_subgraph(prob)
         f_ext = sub.extend(model.out_feat)
         if sub.teacher_ext is None:

@@ -150,9 +150,8 @@ class ProjectionHead(nn.Sequential):
             y = self(x[idx])
             return y if pick is None else y[pick]
         y = ops.linear_rows(x, idx, lin.weight, lin.bias)
-        if hasattr(bn, "fused_act"):                            # dist.SyncBatchNorm1d
-            y = bn.fused_act(y, True, 0.0, self.training)
-            return y if pick is None else y[pick]
+        if hasattr(bn, "fused_act"):                            # dist.SyncBatchNorm1d: all-rank statistics, only the picked rows formed
+            return bn.fused_act(y, True, 0.0, self.training, pick=pick)
         if not isinstance(bn, nn.BatchNorm1d):
             y = self[2](bn(y))
             return y if pick is None else y[pick]

@@ -388,6 +388,15 @@ def gemm_raw(a: Tensor, b: Tensor, trans_a: bool = False, trans_b: bool = False,
         Kb, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
     if K != Kb:
         raise ValueError(f"gemm: inner dimensions differ ({K} vs {Kb})")
+    if K == 0 or M == 0 or N == 0:
+        # an empty reduction (dW = dY^T X[rows] on a shard that owns no train row) or an empty output: exact zeros (+ bias / addend),
+        # no launch -- the entry points take non-null operands only
+        c = torch.zeros(M, N, dtype=torch.float32, device=a.device)
+        if bias is not None and M > 0 and N > 0:
+            c += bias
+        if addend is not None:
+            c += addend
+        return c.clamp_(min=0) if relu else c
     c = torch.empty(M, N, dtype=torch.float32, device=a.device)
     if split_k is None:
         # reductions over many rows into a small output (dW = X^T dY): spread K over the chip
@@ -1247,6 +1256,20 @@ def bn_act_linear(x: Tensor, bn: "torch.nn.BatchNorm1d", w: Tensor, relu: bool =
 # ------------------------------------------------------------------------------------------------
 # the same fused BatchNorm + ReLU + dropout with batch statistics that span all ranks (node-range shards)
 # ------------------------------------------------------------------------------------------------
+_ROW_COUNTS: dict = {}
+
+
+def _row_count(n: int, dev) -> Tensor:
+    """float32 [1] device constant holding ``n`` (made once per value and device, never written)."""
+    key = (int(n), str(dev))
+    t = _ROW_COUNTS.get(key)
+    if t is None:
+        if len(_ROW_COUNTS) > 64:
+            _ROW_COUNTS.clear()
+        t = _ROW_COUNTS[key] = torch.full((1,), float(n), dtype=torch.float32, device=dev)
+    return t
+
+
 def _sync_stats(x: Tensor, group):
     """(mean, biased var, total rows [1]) of the rows of ALL ranks: the per-shard (mean, var, n) triples are all-gathered and merged in
     rank order (Chan's parallel-variance formula, identical on every rank).  An empty shard contributes n = 0."""
@@ -1262,9 +1285,10 @@ def _sync_stats(x: Tensor, group):
         ws = torch.empty(nws, dtype=torch.float32, device=dev)
         _lib.check(lib.egnn_bn_stats_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(stats), _lib.ptr(stats[C:]), _lib.ptr(ws), nws,
                                          _lib.stream()), "egnn_bn_stats_f32")
-        stats[2 * C:].fill_(float(n))     # a fill kernel, not a host->device copy
     if world == 1:
-        return stats[:C], stats[C:2 * C], stats[2 * C:]
+        return stats[:C], stats[C:2 * C], _row_count(n, dev)          # (a cached constant: no fill launch per call)
+    if n > 0:
+        stats[2 * C:].fill_(float(n))     # a fill kernel, not a host->device copy
     allst = torch.empty(world, 2 * C + 1, dtype=torch.float32, device=dev)
     dist.all_gather_into_tensor(allst, stats, group=group)
     merged = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
@@ -1276,21 +1300,33 @@ def _sync_stats(x: Tensor, group):
 
 class _SyncBnAct(torch.autograd.Function):
     """Two small collectives per direction: the per-shard (n, mean, var) triples are all-gathered and merged (``_sync_stats``); the
-    backward all-reduces [sum d, sum d*xhat]."""
+    backward all-reduces [sum d, sum d*xhat].  ``pick`` (unique int64 row ids, may be empty): only those output rows are formed
+    (egnn_bn_act_rows_fwd_f32) -- the statistics, and dx, still span every row of every rank (the projection heads under a sampled
+    criterion, gnn.py:296-306 -> criterion.py:62-65,134-137)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu, p, seed, group):
+    def forward(ctx, x, gamma, beta, eps, relu, p, seed, group, pick=None):
         x = _rowmajor(x)
         n, C = x.shape
         lib, dev = _lib.load(), x.device
         mean, var, total = _sync_stats(x, group)
         seed_dev = _DROPOUT_SEED_DEV if p > 0 else None     # the per-step seed of a replayed graph (fresh masks in every replay)
-        y = torch.empty(n, C, dtype=torch.float32, device=dev)
-        if n > 0:
-            rc = lib.egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
-                                         _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(seed_dev), _lib.ptr(y), y.stride(0), _lib.stream())
-            _lib.check(rc, "egnn_bn_act_fwd_f32")
-        ctx.save_for_backward(x, gamma, beta, mean, var, total)
+        if pick is None:
+            y = torch.empty(n, C, dtype=torch.float32, device=dev)
+            if n > 0:
+                rc = lib.egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
+                                             _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(seed_dev), _lib.ptr(y), y.stride(0), _lib.stream())
+                _lib.check(rc, "egnn_bn_act_fwd_f32")
+        else:
+            if pick.dtype != torch.int64 or pick.dim() != 1 or not pick.is_contiguous() or pick.numel() > n:
+                raise ValueError("sync_bn_act: `pick` must be a contiguous 1-D int64 tensor of unique row ids")
+            y = torch.empty(pick.numel(), C, dtype=torch.float32, device=dev)
+            if pick.numel() > 0:
+                rc = lib.egnn_bn_act_rows_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(pick), pick.numel(), _lib.ptr(mean), _lib.ptr(var),
+                                                  float(eps), _lib.ptr(gamma), _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(seed_dev),
+                                                  _lib.ptr(y), y.stride(0), _lib.stream())
+                _lib.check(rc, "egnn_bn_act_rows_fwd_f32")
+        ctx.save_for_backward(x, gamma, beta, mean, var, total, *([] if pick is None else [pick]))
         ctx.cfg = (float(eps), int(relu), float(p), int(seed), group)
         ctx.seed_dev = seed_dev
         ctx.mark_non_differentiable(mean, var, total)
@@ -1299,20 +1335,26 @@ class _SyncBnAct(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, _gm, _gv, _gt):
         import torch.distributed as dist
-        x, gamma, beta, mean, var, total = ctx.saved_tensors
+        x, gamma, beta, mean, var, total = ctx.saved_tensors[:6]
+        pick = ctx.saved_tensors[6] if len(ctx.saved_tensors) > 6 else None
         eps, relu, p, seed, group = ctx.cfg
         gy = _rowmajor(gy)
         n, C = x.shape
         lib, dev = _lib.load(), x.device
+        n_red = n if pick is None else pick.numel()                  # rows that carry a gradient
         sums = torch.empty(2 * C, dtype=torch.float32, device=dev)   # [dbeta | dgamma] of this shard
-        ws = None
-        if n > 0:
-            nws = lib.egnn_bn_ws_floats(C)
-            ws = torch.empty(nws, dtype=torch.float32, device=dev)
+        nws = lib.egnn_bn_ws_floats(C)
+        ws = torch.empty(nws, dtype=torch.float32, device=dev) if n > 0 else None
+        if n_red > 0 and pick is None:
             rc = lib.egnn_bn_act_bwd_reduce_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var),
                                                 eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), _lib.ptr(sums[C:]),
                                                 _lib.ptr(sums), _lib.ptr(ws), nws, _lib.stream())
             _lib.check(rc, "egnn_bn_act_bwd_reduce_f32")
+        elif n_red > 0:
+            rc = lib.egnn_bn_act_rows_bwd_reduce_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(pick), n_red, _lib.ptr(gy), gy.stride(0),
+                                                     _lib.ptr(mean), _lib.ptr(var), eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed,
+                                                     _lib.ptr(ctx.seed_dev), _lib.ptr(sums[C:]), _lib.ptr(sums), _lib.ptr(ws), nws, _lib.stream())
+            _lib.check(rc, "egnn_bn_act_rows_bwd_reduce_f32")
         else:
             sums.zero_()
         local = sums                                                 # parameter grads stay local (the flat all-reduce sums them)
@@ -1324,21 +1366,29 @@ class _SyncBnAct(torch.autograd.Function):
         if n > 0:
             # the column sums of dx (bias gradient of the conv / Linear in front) come out of the same pass (ops.colsum picks the tag up)
             cs = torch.empty(C, dtype=torch.float32, device=dev)
-            rc = lib.egnn_bn_act_bwd_apply_colsum_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var),
-                                                      eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev), _lib.ptr(scaled),
-                                                      _lib.ptr(scaled[C:]), 1.0, _lib.ptr(dx), dx.stride(0), _lib.ptr(cs), _lib.ptr(ws), nws,
-                                                      _lib.stream())
-            _lib.check(rc, "egnn_bn_act_bwd_apply_colsum_f32")
+            if pick is None:
+                rc = lib.egnn_bn_act_bwd_apply_colsum_f32(_lib.ptr(x), x.stride(0), _lib.ptr(gy), gy.stride(0), n, C, _lib.ptr(mean),
+                                                          _lib.ptr(var), eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed, _lib.ptr(ctx.seed_dev),
+                                                          _lib.ptr(scaled), _lib.ptr(scaled[C:]), 1.0, _lib.ptr(dx), dx.stride(0), _lib.ptr(cs),
+                                                          _lib.ptr(ws), nws, _lib.stream())
+                _lib.check(rc, "egnn_bn_act_bwd_apply_colsum_f32")
+            else:
+                rc = lib.egnn_bn_act_rows_bwd_apply_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(pick), n_red, _lib.ptr(gy), gy.stride(0),
+                                                        _lib.ptr(mean), _lib.ptr(var), eps, _lib.ptr(gamma), _lib.ptr(beta), relu, p, seed,
+                                                        _lib.ptr(ctx.seed_dev), _lib.ptr(scaled), _lib.ptr(scaled[C:]), 1.0, _lib.ptr(local),
+                                                        _lib.ptr(dx), dx.stride(0), _lib.ptr(cs), _lib.ptr(ws), nws, _lib.stream())
+                _lib.check(rc, "egnn_bn_act_rows_bwd_apply_f32")
             dx._egnn_colsum = (cs, dx._version)
-        return dx, local[C:], local[:C], None, None, None, None, None
+        return dx, local[C:], local[:C], None, None, None, None, None, None
 
 
-def sync_bn_act(x: Tensor, bn, relu: bool, p: float, training: bool, group=None):
+def sync_bn_act(x: Tensor, bn, relu: bool, p: float, training: bool, group=None, pick: Tensor | None = None):
     """Training-mode dropout(relu(bn(x))) with all-rank statistics; returns (y, mean, biased var, total rows) so that the
-    module can update its running statistics.  ``bn`` needs weight / bias / eps (dist.SyncBatchNorm1d)."""
+    module can update its running statistics.  ``bn`` needs weight / bias / eps (dist.SyncBatchNorm1d).  ``pick``: only those rows of
+    the result (see _SyncBnAct)."""
     drop = p if (training and p > 0) else 0.0
     seed = _draw_dropout_seed() if drop > 0 else 0
-    return _SyncBnAct.apply(x, bn.weight, bn.bias, bn.eps, relu, drop, seed, group)
+    return _SyncBnAct.apply(x, bn.weight, bn.bias, bn.eps, relu, drop, seed, group, pick)
 
 
 class _SyncBnActLinear(torch.autograd.Function):

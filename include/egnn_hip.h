@@ -39,7 +39,7 @@ extern "C" {
 #define EGNN_EWORKSPACE (-3) /* caller-provided workspace too small */
 #define EGNN_EALIGN (-4)   /* pointer / leading dimension not aligned as the entry point requires */
 
-#define EGNN_ABI_VERSION 5
+#define EGNN_ABI_VERSION 6
 int egnn_abi_version(void);
 const char* egnn_error_string(int code);
 /* Number of distinct kernels-families compiled in; used by the loader's self check. */
@@ -469,6 +469,23 @@ int egnn_bn_act_rows_bwd_f32(const float* x, int64_t ld, int64_t n, int64_t C, c
                              int64_t ld_dy, const float* mean, const float* var, float eps, const float* gamma, const float* beta,
                              int relu, float p, uint64_t seed, const uint64_t* seed_dev, int batch_stats, float* dgamma, float* dbeta,
                              float* dx, int64_t ld_dx, float* dx_colsum, float* ws, size_t ws_floats, void* stream);
+
+/* The two halves of egnn_bn_act_rows_bwd_f32 (which is their composition): on node-range shards the projection heads' BatchNorm has
+ * all-rank statistics (/root/reference/arxiv_pyg/gnn.py:296-306 on shards: dist.SyncBatchNorm1d), so [sum d | sum d xhat] is all-reduced
+ * between them.
+ *   reduce: dgamma = sum d xhat, dbeta = sum d over the picked rows of THIS tensor (same workspace as egnn_bn_ws_floats).
+ *   apply:  dx [n, C] from the sums the mean / variance terms use (sum_dbeta / sum_dgamma with inv_count = 1 / rows they span; the
+ *           all-rank sums already divided by the row total go with inv_count = 1), n_pick >= 0; dx_colsum nullable -- it needs
+ *           local_dbeta, this tensor's own sum d, because the picked rows' own term is local. */
+int egnn_bn_act_rows_bwd_reduce_f32(const float* x, int64_t ld, int64_t n, int64_t C, const int64_t* pick, int64_t n_pick, const float* dy,
+                                    int64_t ld_dy, const float* mean, const float* var, float eps, const float* gamma, const float* beta,
+                                    int relu, float p, uint64_t seed, const uint64_t* seed_dev, float* dgamma, float* dbeta, float* ws,
+                                    size_t ws_floats, void* stream);
+int egnn_bn_act_rows_bwd_apply_f32(const float* x, int64_t ld, int64_t n, int64_t C, const int64_t* pick, int64_t n_pick, const float* dy,
+                                   int64_t ld_dy, const float* mean, const float* var, float eps, const float* gamma, const float* beta,
+                                   int relu, float p, uint64_t seed, const uint64_t* seed_dev, const float* sum_dbeta,
+                                   const float* sum_dgamma, float inv_count, const float* local_dbeta, float* dx, int64_t ld_dx,
+                                   float* dx_colsum, float* ws, size_t ws_floats, void* stream);
 
 /* Backward of  h = act(bn(x)) [M, C]  followed by the narrow Linear  h W  (W [C, Ks] for w_kmajor = 0, [Ks, C] rows for 1 -- the same
  * flag as egnn_bn_act_linear_fwd_f32; Ks <= 64, C % 64 == 0)

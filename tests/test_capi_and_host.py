@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/egnn_hip.h but not exported"
     assert set(syms) == set(E._lib.SIGNATURES), "ctypes table and header disagree"
-    assert E._lib.load().egnn_abi_version() == 5
+    assert E._lib.load().egnn_abi_version() == 6
     assert "gfx950" in E._lib.build_info()
     assert E._lib.load().egnn_error_string(-3) == b"workspace too small"
 

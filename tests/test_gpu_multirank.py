@@ -30,12 +30,13 @@ def _run(world, tmp_path_factory):
                        capture_output=True, text=True, timeout=2400)
     report = json.load(open(out)) if os.path.exists(out) else {}
     keep = os.environ.get("EGNN_MULTIRANK_REPORT_DIR")        # evidence sessions keep the per-case report
-    if keep and report:
+    if keep:
         os.makedirs(keep, exist_ok=True)
-        with open(os.path.join(keep, f"multirank_w{world}.json"), "w") as f:
-            json.dump(report, f, indent=1)
+        if report:
+            with open(os.path.join(keep, f"multirank_w{world}.json"), "w") as f:
+                json.dump(report, f, indent=1)
         with open(os.path.join(keep, f"multirank_w{world}.log"), "w") as f:
-            f.write(p.stdout[-20000:] + "\n--- stderr ---\n" + p.stderr[-5000:])
+            f.write(p.stdout[-20000:] + "\n--- stderr ---\n" + p.stderr[-12000:])
     return p, report
 
 
@@ -60,6 +61,8 @@ def _check(run, name):
     assert e["acc_abs_err"] <= 1.5 * e["acc_one_node"], (e["accs"], e["ref_accs"])
     if "nce-static" in name or "gpw-static" in name:
         assert all(1 < i["static_cap"] < 256 for i in e["per_rank"]), "the static layout is the one that ran"
+    if "notrain" in name:
+        assert e["per_rank"][-1]["n_train_local"] == 0 and e["per_rank"][0]["n_train_local"] > 0
     if "overflow" in name:
         assert all(i["static_cap"] == 1 for i in e["per_rank"])
     if "community" in name:
