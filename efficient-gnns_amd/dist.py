@@ -322,6 +322,52 @@ class _HaloExchange(torch.autograd.Function):
         return g_local, None
 
 
+def _overlap_forward(x_local, sadj, a_own, a_halo, static_halo, bias=None, relu=False, addend=None):
+    """y = A_own x_own + A_halo x_halo (+ addend) (+ bias, ReLU in the LAST piece's store) with the halo exchange IN FLIGHT under the
+    first product.  Plain function (no autograd): the body of ``_OverlapAggregate`` and of ``_ShardedSageLayer``."""
+    plan, group = sadj.plan, sadj.group
+    K = x_local.shape[1]
+    work = None
+    if static_halo is not None:
+        x_halo = static_halo
+    else:
+        send_buf = x_local.index_select(0, sadj.send_idx_dev).contiguous()
+        x_halo = torch.empty(plan.n_halo, K, dtype=x_local.dtype, device=x_local.device)
+        work = dist.all_to_all_single(x_halo, send_buf, plan.recv_counts, plan.send_counts, group=group, async_op=True)
+    probe = CommTrace.active is not None and CommTrace.active.probe_overlap and work is not None and x_local.is_cuda
+    if probe:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+    last_is_own = not plan.n_halo                              # bias (+ ReLU) go into the store of the row sums' LAST piece
+    y = _agg(a_own, x_local, addend=addend, bias=bias if last_is_own else None, relu=relu and last_is_own)   # runs while the halo rows travel
+    if probe:
+        ev[1].record()
+    if work is not None:
+        work.wait()
+    if probe:   # ev0..ev1: compute the exchange is hidden under; ev1..ev2: what the stream still waits for it afterwards
+        ev[2].record()
+        CommTrace.active.overlap.append(tuple(ev))
+    if plan.n_halo:
+        y = _agg(a_halo, x_halo, addend=y, bias=bias, relu=relu)
+    return y
+
+
+def _overlap_backward(g_y, sadj, a_own, a_halo, addend=None):
+    """g_x = A_own^T g_y (+ addend) + (the peers' A_halo^T g_y rows, returned by the reverse exchange and added into their owner rows
+    in a fixed order), the exchange in flight under the first product."""
+    plan, group = sadj.plan, sadj.group
+    g_y = g_y.contiguous()
+    K = g_y.shape[1]
+    back = torch.empty(plan.send_idx.numel(), K, dtype=g_y.dtype, device=g_y.device)
+    g_halo = _agg(a_halo.t(), g_y) if plan.n_halo else torch.zeros(0, K, dtype=g_y.dtype, device=g_y.device)
+    work = dist.all_to_all_single(back, g_halo, plan.send_counts, plan.recv_counts, group=group, async_op=True)
+    g_x = _agg(a_own.t(), g_y, addend=addend)                    # runs while the halo gradients travel back
+    work.wait()
+    if back.shape[0]:
+        g_x = _agg(sadj.scatter, back, addend=g_x)
+    return g_x
+
+
 class _OverlapAggregate(torch.autograd.Function):
     """y = A_own x_own + A_halo x_halo with the halo exchange IN FLIGHT under the first product (and, in the backward, the
     reverse exchange under A_own^T g): the entries of a shard are split by column ownership, so the overlap does not
@@ -329,50 +375,66 @@ class _OverlapAggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_local, sadj, a_own, a_halo, static_halo, bias=None, relu=False):
-        plan, group = sadj.plan, sadj.group
-        K = x_local.shape[1]
-        work = None
-        if static_halo is not None:
-            x_halo = static_halo
-        else:
-            send_buf = x_local.index_select(0, sadj.send_idx_dev).contiguous()
-            x_halo = torch.empty(plan.n_halo, K, dtype=x_local.dtype, device=x_local.device)
-            work = dist.all_to_all_single(x_halo, send_buf, plan.recv_counts, plan.send_counts, group=group, async_op=True)
-        probe = CommTrace.active is not None and CommTrace.active.probe_overlap and work is not None and x_local.is_cuda
-        if probe:
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            ev[0].record()
-        last_is_own = not plan.n_halo                              # bias (+ ReLU) go into the store of the row sums' LAST piece
-        y = _agg(a_own, x_local, bias=bias if last_is_own else None, relu=relu and last_is_own)   # runs while the halo rows travel
-        if probe:
-            ev[1].record()
-        if work is not None:
-            work.wait()
-        if probe:   # ev0..ev1: compute the exchange is hidden under; ev1..ev2: what the stream still waits for it afterwards
-            ev[2].record()
-            CommTrace.active.overlap.append(tuple(ev))
-        if plan.n_halo:
-            y = _agg(a_halo, x_halo, addend=y, bias=bias, relu=relu)
+        y = _overlap_forward(x_local, sadj, a_own, a_halo, static_halo, bias, relu)
         ctx.sadj, ctx.pieces, ctx.has_bias = sadj, (a_own, a_halo), bias is not None
         return y
 
     @staticmethod
     def backward(ctx, g_y):
-        sadj = ctx.sadj
         a_own, a_halo = ctx.pieces
-        plan, group = sadj.plan, sadj.group
         g_y = g_y.contiguous()
-        K = g_y.shape[1]
-        work = None
-        back = torch.empty(plan.send_idx.numel(), K, dtype=g_y.dtype, device=g_y.device)
-        g_halo = _agg(a_halo.t(), g_y) if plan.n_halo else torch.zeros(0, K, dtype=g_y.dtype, device=g_y.device)
-        work = dist.all_to_all_single(back, g_halo, plan.send_counts, plan.recv_counts, group=group, async_op=True)
-        g_x = _agg(a_own.t(), g_y)                                  # runs while the halo gradients travel back
-        work.wait()
-        if back.shape[0]:
-            g_x = _agg(sadj.scatter, back, addend=g_x)
+        g_x = _overlap_backward(g_y, ctx.sadj, a_own, a_halo)
         g_b = ops.colsum(g_y) if (ctx.has_bias and ctx.needs_input_grad[5]) else None
         return g_x, None, None, None, None, g_b, None
+
+
+class _ShardedSageLayer(torch.autograd.Function):
+    """``ops._SageLayer`` on a node-range shard: SAGEConv (``lin_l(aggr_j x_j) + lin_r(x_i)``, gnn.py:79-84) as ONE autograd node whose
+    aggregation is the overlapped halo-exchange form above -- ``lin_r(x)`` is the addend of the GEMM / aggregation store, the input
+    gradient's second path ``g W_r`` the addend of the backward aggregation's first piece (no element-wise pass over [n, C] in either
+    direction); ``narrow`` (out < in): ``x W_l^T`` is aggregated instead of x, the halo then carries `out` floats per row."""
+
+    @staticmethod
+    def forward(ctx, x, sadj, a_own, a_halo, static_halo, wl, bl, wr, narrow):
+        ctx.tap_box = getattr(x, "_egnn_tap", None)
+        x = x.contiguous()
+        r = ops.gemm_raw(x, wr, False, True)                                   # lin_r(x)
+        if narrow:
+            t = ops.gemm_raw(x, wl, False, True)                               # x W_l^T: aggregated with bias + lin_r(x) in the stores
+            out = _overlap_forward(t, sadj, a_own, a_halo, None, bias=bl, addend=r)
+            agg = None
+        else:
+            agg = _overlap_forward(x, sadj, a_own, a_halo, static_halo)
+            out = ops.gemm_raw(agg, wl, False, True, bias=bl, addend=r)        # lin_l(agg) + lin_r(x) in one store
+        ctx.save_for_backward(x, wl, wr, *([] if agg is None else [agg]))
+        ctx.sadj, ctx.pieces, ctx.narrow, ctx.has_bias = sadj, (a_own, a_halo), narrow, bl is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wl, wr = ctx.saved_tensors[:3]
+        agg = ctx.saved_tensors[3] if len(ctx.saved_tensors) > 3 else None
+        a_own, a_halo = ctx.pieces
+        g = g.contiguous()
+        need_x = ctx.needs_input_grad[0]
+        gx = gwl = gbl = gwr = None
+        if ctx.needs_input_grad[7]:
+            gwr = ops.gemm_raw(g, x, True, False)                              # dW_r = g^T x
+        if ctx.has_bias and ctx.needs_input_grad[6]:
+            gbl = ops.colsum(g)
+        # EVERY rank runs the backward exchange (a collective), whether or not its own input needs a gradient
+        if ctx.narrow:
+            dt = _overlap_backward(g, ctx.sadj, a_own, a_halo)
+            if ctx.needs_input_grad[5]:
+                gwl = ops.gemm_raw(dt, x, True, False)                         # dW_l = dt^T x
+            if need_x:
+                gx = ops.gemm_raw(dt, wl, False, False, addend=ops.gemm_raw(g, wr, False, False))     # dt W_l + g W_r
+        else:
+            if ctx.needs_input_grad[5]:
+                gwl = ops.gemm_raw(g, agg, True, False)                        # dW_l = g^T agg
+            if need_x:
+                gx = _overlap_backward(ops.gemm_raw(g, wl, False, False), ctx.sadj, a_own, a_halo, addend=ops.gemm_raw(g, wr, False, False))
+        return ops._fresh(gx, ctx.tap_box), None, None, None, None, gwl, gbl, gwr, None
 
 
 class ShardedAdj:
@@ -490,6 +552,22 @@ class ShardedAdj:
         if relu:
             return ops.spmm_raw(adj, x_ext, reduce, bias=bias, relu=True)[0]
         return ops.spmm(adj, x_ext, reduce, bias=bias)
+
+    def sage_layer(self, x_local: Tensor, lin_l, lin_r, reduce: str, narrow: bool):
+        """SAGEConv on this shard as one autograd node (``_ShardedSageLayer``); None when the fused form does not apply (blocking
+        exchange mode, CPU stand-ins, a layer whose input needs no gradient and is not the registered static input -- its backward
+        exchange would be skipped by autograd on this rank only)."""
+        if not (_OVERLAP and x_local.is_cuda and reduce in ("sum", "add", "mean") and lin_r.bias is None and self.plan.n_local > 0):
+            return None
+        st = self._static
+        static = st is not None and st[0] is x_local and not x_local.requires_grad and x_local._version == st[2]
+        if torch.is_grad_enabled() and not (static or x_local.requires_grad):
+            return None
+        if static and narrow:
+            return None                       # the narrow form aggregates x W_l^T: the static halo of x does not apply
+        own, halo = self._split(reduce == "mean", True)
+        return _ShardedSageLayer.apply(x_local, self, own, halo, st[1][self.plan.n_local:] if static else None, lin_l.weight, lin_l.bias,
+                                       lin_r.weight, narrow)
 
     def halo_fraction(self) -> float:
         return self.plan.n_halo / max(1, self.plan.n - self.plan.n_local)

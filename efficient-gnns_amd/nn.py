@@ -168,6 +168,11 @@ class SAGEConv(nn.Module):
 
     def forward(self, x: Tensor, edge_index) -> Tensor:
         if hasattr(edge_index, "aggregate"):  # node-range shard (dist.ShardedAdj)
+            if _SAGE_FUSED and hasattr(edge_index, "sage_layer"):
+                # one autograd node with accumulating stores and (out < in) the narrow-first order, as on one GPU (ops._SageLayer)
+                out = edge_index.sage_layer(x, self.lin_l, self.lin_r, self.aggr, _SAGE_NARROW_FIRST and self.out_channels < self.in_channels)
+                if out is not None:
+                    return out
             agg = edge_index.aggregate(x, self.aggr, valueless=True)
             # lin_l(agg) + lin_r(x): the second product is added in the first GEMM's store (ops.linear_add)
             return ops.linear_add(agg, self.lin_l.weight, self.lin_l.bias, ops.linear(x, self.lin_r.weight, None))

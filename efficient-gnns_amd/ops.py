@@ -1142,6 +1142,7 @@ def _tail_backward(ctx, g_h, g_xw, x, gamma, beta, mean, var, h, w, eps, relu, p
     pend = []
     if ctx.box is not None:
         pend, ctx.box.pending = ctx.box.pending, []
+        pend = [(i, r) for i, r in pend if r.shape[0] > 0]      # (a shard without train rows taps zero rows: nothing to add)
     n, C = x.shape
     Ks = w.shape[1]
     lib, dev = _lib.load(), x.device

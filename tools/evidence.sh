@@ -14,8 +14,7 @@ for s in $STAGES; do case $s in
 smoke) echo "== smoke"; timeout 600 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "rc=$?"; tail -1 $O/smoke.log | cut -c1-300;;
 tests) echo "== pytest -m gpu"; timeout 1700 python -m pytest tests -m gpu -q -rfE --tb=short -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "rc=$?"; tail -1 $O/pytest_gpu.log;;
 bench) echo "== bench (default arguments)"; timeout 1200 python bench.py > $O/bench.log 2>&1; echo "rc=$?"; grep "^{" $O/bench.log | tail -1 > $O/bench_line.json; cut -c1-300 $O/bench_line.json
-       echo "== bench, f32-input MFMA pipeline"; EGNN_GEMM_PIPE=f32 timeout 900 python bench.py --cpu-epochs 0 --no-local-roofline 2>&1 | grep "^{" | tail -1 > $O/bench_line_f32pipe.json; cut -c1-200 $O/bench_line_f32pipe.json
-       echo "== bench, round-2 code paths (EGNN_GEMM_DMA=0 EGNN_NCE_DMA=0 EGNN_TRAIN_ROWS=0 EGNN_FUSED_TAIL=0 EGNN_SAMPLED_HEADS=0)"; EGNN_GEMM_DMA=0 EGNN_NCE_DMA=0 EGNN_TRAIN_ROWS=0 EGNN_FUSED_TAIL=0 EGNN_SAMPLED_HEADS=0 timeout 900 python bench.py --cpu-epochs 0 --no-local-roofline --no-parity 2>&1 | grep "^{" | tail -1 > $O/bench_line_r02_paths.json; cut -c1-200 $O/bench_line_r02_paths.json;;
+       echo "== bench, f32-input MFMA pipeline"; EGNN_GEMM_PIPE=f32 timeout 900 python bench.py --cpu-epochs 0 --no-local-roofline 2>&1 | grep "^{" | tail -1 > $O/bench_line_f32pipe.json; cut -c1-200 $O/bench_line_f32pipe.json;;
 rocprof) echo "== rocprof kernel stats of bench"; rm -rf /tmp/profev; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/profev -o $TAG -- python $R/bench.py --steps 10 --warmup 2 --cpu-epochs 0 > $O/rocprof_bench.log 2>&1); echo "rc=$?"
        find /tmp/profev -name "*kernel_stats*" -exec cp {} $O/bench_kernel_stats.csv \; ; find /tmp/profev -name "*domain_stats*" -exec cp {} $O/bench_domain_stats.csv \; ; head -8 $O/bench_kernel_stats.csv | cut -c1-200;;
 epoch) echo "== one eager epoch"; bash tools/epoch_kernels.sh > $O/epoch_kernels.log 2>&1; cp gpurun_out/epoch_kernels/last_epoch.txt $O/epoch_kernels.txt; head -1 $O/epoch_kernels.txt;;
