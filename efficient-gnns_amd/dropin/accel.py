@@ -16,7 +16,9 @@ everything else takes the original path -- at this package's kernels:
     multi-tensor chain (~0.3 ms per step on the headline problem).
 
 Same values within the fp32 tolerance of the package's parity tests; ``disable()`` restores torch's methods.  ``launch.py`` enables
-it unless ``--plain-torch-modules`` is given.
+it unless ``--plain-torch-modules`` is given.  Scoped forms for code that must not change torch process-wide: ``with accel.scope():``
+(enabled inside the block only) and ``with accel.double_backward():`` (torch's own kernels for a ``create_graph=True`` region: the
+package's autograd Functions implement first derivatives only); an ``Adam(differentiable=True)`` is left to torch.
 """
 from __future__ import annotations
 
@@ -81,6 +83,19 @@ class double_backward:
 
 def _double_backward_wanted(x) -> bool:
     return _DOUBLE_BACKWARD
+
+
+class scope:
+    """``with accel.scope():`` -- the re-pointed methods only inside the block (restored on exit, also on an exception)."""
+
+    def __enter__(self):
+        self.was = enabled()
+        enable()
+        return self
+
+    def __exit__(self, *exc):
+        if not self.was:
+            disable()
 
 
 def disable() -> None:
