@@ -217,7 +217,7 @@ class GemmProbe:
     (arxiv_pyg/gnn.py:47,296-306) -- with HIP events on the launch stream, for the `roofline_gemm` object.  A call's flops are
     2 M N K; calls with a class-count-wide dimension (min(M, N, K) <= 64: the HBM-bound skinny kernels of csrc/gemm_skinny.hip) are
     reported separately and are not part of the matrix-pipe fraction."""
-    NAMES = ("egnn_gemm_f32", "egnn_gemm_ex_f32", "egnn_gemm_add_f32", "egnn_gemm_rows_f32")
+    NAMES = ("egnn_gemm_f32", "egnn_gemm_ex_f32", "egnn_gemm_add_f32", "egnn_gemm_rows_f32", "egnn_gemm_tn_planes_f32", "egnn_gemm_rows_planes_f32")
 
     def __init__(self, lib):
         self.lib, self.records, self.active = lib, [], False
@@ -234,7 +234,12 @@ class GemmProbe:
                 e0.record()
                 rc = orig(*a)
                 e1.record()
-                self.records.append((int(a[0]), int(a[1]), int(a[2]), int(a[3]), int(a[4]), name.endswith("rows_f32"), e0, e1))
+                if name == "egnn_gemm_tn_planes_f32":      # C = A^T B[rows], B cut once into planes: (M, N, K, ...)
+                    self.records.append((1, 0, int(a[0]), int(a[1]), int(a[2]), "+rows(planes)", e0, e1))
+                elif name == "egnn_gemm_rows_planes_f32":  # C = A[rows] B^T, A cut once into planes
+                    self.records.append((0, 1, int(a[0]), int(a[1]), int(a[2]), "+rows(planes)", e0, e1))
+                else:
+                    self.records.append((int(a[0]), int(a[1]), int(a[2]), int(a[3]), int(a[4]), "+rows" if name.endswith("rows_f32") else "", e0, e1))
                 return rc
             return wrapped
         for n in self.NAMES:
@@ -253,7 +258,7 @@ class GemmProbe:
         tot = lambda rs: (sum(2.0 * r[2] * r[3] * r[4] for r in rs), sum(r[6].elapsed_time(r[7]) * 1e-3 for r in rs))  # noqa: E731
         shapes = {}
         for r in wide:
-            key = f"{'T' if r[0] else 'N'}{'T' if r[1] else 'N'}{'+rows' if r[5] else ''} {r[2]}x{r[3]}x{r[4]}"
+            key = f"{'T' if r[0] else 'N'}{'T' if r[1] else 'N'}{r[5]} {r[2]}x{r[3]}x{r[4]}"
             f, t, c = shapes.get(key, (0.0, 0.0, 0))
             shapes[key] = (f + 2.0 * r[2] * r[3] * r[4], t + r[6].elapsed_time(r[7]) * 1e-3, c + 1)
         return dict(wide=tot(wide), skinny=tot(skinny), n_wide=len(wide), n_skinny=len(skinny), shapes=shapes)
@@ -937,7 +942,8 @@ def main():
                              frac=round(f / t / 1e12 / peak, 3)) for k, (f, t, c) in sorted(gmsum["shapes"].items(), key=lambda kv: -kv[1][1])}
         roofline_gemm = dict(bound="mfma", kernel="every egnn_gemm_f32 / _ex / _add / _rows call of the step outside the G-CRD loss with all of "
                                                   "M, N, K > 64: layer transforms, input gradients, transposed weight gradients (split-K), projection "
-                                                  "heads with fused row gathers; pack / split-K-reduce launches included",
+                                                  "heads with fused row gathers (the teacher head's constant input cut once into planes: "
+                                                  "egnn_gemm_{tn,rows}_planes_f32); pack / split-K-reduce launches included",
                              achieved=round(tf, 1), peak=round(peak, 1), unit="TFLOP/s (fp32 products)", frac=round(tf / peak, 4),
                              flops_per_step=int(fl / max(1, n_probe)), ms_per_step=round(1e3 * secs / max(1, n_probe), 3),
                              calls_per_step=round(gmsum["n_wide"] / max(1, n_probe), 2), by_shape=per_shape,

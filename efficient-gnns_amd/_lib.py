@@ -45,6 +45,14 @@ SIGNATURES = {
     "egnn_gemm_add_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _i32, _p, _sz, _p]),
     "egnn_bn_fold_f32": (_i32, [_p, _i64, _i64, _i64, _p, _p, _p, _p, _p, _f32, _p, _i64, _p, _p]),
     "egnn_gemm_rows_f32": (_i32, [_i32, _i32, _i64, _i64, _i64, _f32, _p, _i64, _p, _p, _i64, _p, _p, _p, _i64, _i32, _p, _sz, _p]),
+    "egnn_gemm_tn_planes_bytes": (_sz, [_i64, _i64]),
+    "egnn_gemm_tn_planes_pack_f32": (_i32, [_p, _i64, _p, _i64, _i64, _p, _sz, _p]),
+    "egnn_gemm_tn_planes_ws_floats": (_sz, [_i64, _i64, _i64]),
+    "egnn_gemm_tn_planes_f32": (_i32, [_i64, _i64, _i64, _f32, _p, _i64, _p, _p, _i64, _p, _sz, _p]),
+    "egnn_gemm_rows_planes_bytes": (_sz, [_i64, _i64]),
+    "egnn_gemm_rows_planes_pack_f32": (_i32, [_p, _i64, _p, _i64, _i64, _p, _sz, _p]),
+    "egnn_gemm_rows_planes_ws_bytes": (_sz, [_i64, _i64]),
+    "egnn_gemm_rows_planes_f32": (_i32, [_i64, _i64, _i64, _f32, _p, _p, _i64, _p, _p, _i64, _p, _sz, _p]),
     "egnn_ce_kd_ws_floats": (_sz, [_i64]),
     "egnn_ce_kd_fwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _f32, _p, _p, _p]),
     "egnn_ce_kd_bwd_f32": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _f32, _p, _p, _p, _p, _i64, _p]),

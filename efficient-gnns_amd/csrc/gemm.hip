@@ -226,15 +226,132 @@ bool dma_form(int trans_a, int64_t M, int64_t N, int64_t K, int split_k, bool ga
 }
 inline size_t dma_ws_bytes(int64_t N, int64_t K) { return egnn_gemm3::planes_bytes(N, K, 128, DMA_BKT) + 1024; }
 
+// ---- transposed product against a CONSTANT operand cut once into planes (gemm3.h, F32M x PLANES) ---------------------------------
+// dW = dY^T X[idx] of the teacher projection head (arxiv_pyg/gnn.py:296-306 via autograd): X -- the teacher's [N, 750] features -- never
+// changes, so its gathered rows are cut ONCE per (X, idx) into tile-packed bf16 planes with the reduction index (the train position)
+// as k: the per-step product then reads dY down LDS columns (F32M: the only form a [K, M] operand can take) against planes that need
+// neither a gather nor a cut in the loop -- the lab's fastest form (f32m_pln 256 x 256: 49-54 % of the six-product peak against 33 %
+// for the register-staged gather-fused kernel on this shape).  256 x 256 tiles, k-steps of 16, three LDS stages, split over k.
+constexpr int TNP_BKT = 16, TNP_RB = 256;
+using TnpTile = egnn_gemm3::Tile<egnn_gemm3::F32M, egnn_gemm3::PLANES, 4, 4, TNP_BKT, 3>;
+
+__global__ __launch_bounds__(256, 1) void gemm_tn_planes_kernel(const float* __restrict__ A, int64_t lda, const char* __restrict__ planes, int64_t nks,
+                                                                int64_t M, int64_t Np, int64_t K, int64_t k_per_split, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int64_t tiles_n = Np / TnpTile::BN;
+  int64_t tile = blockIdx.x;
+  if (tiles_n > 1 && tiles_n <= 8) {   // the column tiles of a row tile follow each other on ONE XCD (they share the dY tile)
+    const int64_t tiles = gridDim.x, q = tiles >> 3, rem = tiles & 7, xcd = tile & 7, j = tile >> 3;
+    tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + j;
+  }
+  const int64_t m0 = (tile / tiles_n) * TnpTile::BM, n0 = (tile % tiles_n) * TnpTile::BN;
+  const int64_t kbeg = (int64_t)blockIdx.y * k_per_split, kend = kbeg + k_per_split;   // whole k-steps; past K: zero planes x the last dY row
+  f32x16 acc[4][4];
+  zero_acc(acc);
+  egnn_gemm3::mainloop<egnn_gemm3::F32M, egnn_gemm3::PLANES, 4, 4, TNP_BKT, 3, 1>(acc, A, lda, m0, planes, nks, n0, kbeg, kend,
+                                                                                    reinterpret_cast<char*>(smem), K);
+  const int lane = egnn_lane(), wave = egnn_wave_id();
+  const int wm = wave >> 1, wn = wave & 1;
+  float* out = ws + (int64_t)blockIdx.y * M * Np;
+#pragma unroll
+  for (int tn = 0; tn < 4; ++tn) {
+    const int64_t c = n0 + wn * 128 + tn * 32 + (lane & 31);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * 128 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        out[row * Np + c] = acc[tm][tn][r];
+      }
+  }
+}
+
+// C[m, n] = alpha * sum over the k-ranges (fixed order: four interleaved lanes, combined in lane order -- see splitk_reduce_kernel) of
+// ws[s][m][n], n < N (the planes' padded columns are dropped)
+__global__ __launch_bounds__(256) void gemm_tn_planes_reduce_kernel(const float* __restrict__ ws, int splits, int64_t M, int64_t Np, int64_t N,
+                                                                   float alpha, float* __restrict__ C, int64_t ldc) {
+  __shared__ float sh[4][64];
+  const int64_t total = M * N;
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+    const int64_t t = base + e;
+    const int64_t row = t / N, c = t % N;
+    float s = 0.f;
+    if (t < total) {
+      const float* p = ws + row * Np + c;
+#pragma unroll 8
+      for (int k = q; k < splits; k += 4) s += p[(int64_t)k * M * Np];
+    }
+    sh[q][e] = s;
+    __syncthreads();
+    if (q == 0 && t < total) C[row * ldc + c] = alpha * (((sh[0][e] + sh[1][e]) + sh[2][e]) + sh[3][e]);
+    __syncthreads();
+  }
+}
+
+// ---- forward of the same Linear: y = X[idx] W^T + b with the CONSTANT gathered rows cut once into planes (PLANES x PLANES) -------------
+// A = the planes of X[idx] (row blocks of 128 gathered rows x k-steps of 16: the gather is baked in at pack time), B = W cut per call;
+// both stages are lane-linear LDS-DMA copies, no VALU on either operand in the loop.  128 x 128 tiles, three LDS stages, two
+// workgroups per CU.
+constexpr int PP_BKT = 16, PP_RB = 128;
+using PpTile = egnn_gemm3::Tile<egnn_gemm3::PLANES, egnn_gemm3::PLANES, 2, 2, PP_BKT, 3>;
+
+__global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const GemmArgs g, const char* __restrict__ planes_a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int64_t tiles_n = g.N / 128;
+  int64_t tile = blockIdx.x;
+  if (tiles_n > 1 && tiles_n <= 8) {   // the column tiles of a row tile next to each other on one XCD (see gemm_kernel)
+    const int64_t tiles = gridDim.x, q = tiles >> 3, rem = tiles & 7, xcd = tile & 7, j = tile >> 3;
+    tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + j;
+  }
+  const int64_t m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
+  const int64_t nks = (g.K + PP_BKT - 1) / PP_BKT;
+  f32x16 acc[2][2];
+  zero_acc(acc);
+  egnn_gemm3::mainloop<egnn_gemm3::PLANES, egnn_gemm3::PLANES, 2, 2, PP_BKT, 3, 1>(acc, planes_a, nks, m0, g.planes, nks, n0, 0, nks * PP_BKT,
+                                                                                     reinterpret_cast<char*>(smem));
+  const int wave = egnn_wave_id();
+  if (g.wide_store) store_tile_wide<128, 128, 2>(acc, g, m0, n0, 0, egnn_lane(), wave >> 1, wave & 1, smem);
+  else store_tile<128, 128, 2>(acc, g, m0, n0, 0, egnn_lane(), wave >> 1, wave & 1);
+}
+
+// k-ranges: fill the 256 CUs (one 256 x 256 workgroup each) with whole k-steps; <= 128 ranges
+inline void tnp_split(int64_t Np, int64_t K, int& splits, int64_t& k_per_split) {
+  const int64_t tiles = Np / TnpTile::BN;       // per 256-row tile of the output (the usual case: M = 256, one row tile)
+  int64_t s = 256 / (tiles > 0 ? tiles : 1);
+  if (s < 1) s = 1;
+  if (s > 128) s = 128;
+  const int64_t ksteps = (K + TNP_BKT - 1) / TNP_BKT;
+  if (s > ksteps / 8) s = ksteps / 8 > 0 ? ksteps / 8 : 1;       // at least 8 k-steps per range (the pipeline's fill)
+  k_per_split = ((ksteps + s - 1) / s) * TNP_BKT;
+  splits = (int)((K + k_per_split - 1) / k_per_split);
+}
+
+// Fixed-order reduction of the split-K partials: 64 output elements per workgroup x 4 split lanes (lane q adds partials q, q + 4, ...
+// with eight loads in flight), the four lane sums are combined in lane order.  (One thread per element walking all partials in turn
+// was latency-bound: 31 us for 128 partials of 256 x 256 -- 1 TB/s.)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs g) {
+  __shared__ float sh[4][64];
   const int64_t total = g.M * g.N;
   const float alpha = g.alpha * (g.alpha_dev ? g.alpha_dev[0] : 1.f);
-  for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+  const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+    const int64_t t = base + e;
     float s = 0.f;
-    for (int k = 0; k < g.split_k; ++k) s += g.ws[(int64_t)k * total + t];  // fixed order
-    const int64_t row = t / g.N, c = t % g.N;
-    const float v = alpha * s + (g.bias ? g.bias[c] : 0.f) + (g.addend ? g.addend[row * g.ld_add + c] : 0.f);
-    g.C[row * g.ldc + c] = g.relu ? fmaxf(v, 0.f) : v;
+    if (t < total) {
+      const float* p = g.ws + t;
+#pragma unroll 8
+      for (int k = q; k < g.split_k; k += 4) s += p[(int64_t)k * total];
+    }
+    sh[q][e] = s;
+    __syncthreads();
+    if (q == 0 && t < total) {
+      const float sum = ((sh[0][e] + sh[1][e]) + sh[2][e]) + sh[3][e];
+      const int64_t row = t / g.N, c = t % g.N;
+      const float v = alpha * sum + (g.bias ? g.bias[c] : 0.f) + (g.addend ? g.addend[row * g.ld_add + c] : 0.f);
+      g.C[row * g.ldc + c] = g.relu ? fmaxf(v, 0.f) : v;
+    }
+    __syncthreads();
   }
 }
 
@@ -331,8 +448,8 @@ static int gemm_impl(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, 
   else rc = launch_major<MNMAJOR, MNMAJOR>(g, vec4, st);
   if (rc != EGNN_OK) return rc;
   if (split_k > 1) {
-    const int64_t blocks = (M * N + 255) / 256;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, g);
+    const int64_t blocks = (M * N + 63) / 64;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, g);
   }
   return egnn_launch_status();
 }
@@ -374,4 +491,83 @@ extern "C" int egnn_gemm_rows_f32(int trans_a, int trans_b, int64_t M, int64_t N
                                   const float* bias, float* C, int64_t ldc, int split_k, float* ws, size_t ws_bytes,
                                   void* stream) {
   return gemm_impl(trans_a, trans_b, M, N, K, alpha, A, lda, a_rows, B, ldb, b_rows, bias, C, ldc, split_k, ws, ws_bytes, stream);
+}
+
+// ---- C = alpha A^T B for a CONSTANT, row-gathered B cut once into planes (see gemm_tn_planes_kernel) -----------------------------------
+extern "C" size_t egnn_gemm_tn_planes_bytes(int64_t N, int64_t K) {
+  const int64_t Np = (N + TNP_RB - 1) / TNP_RB * TNP_RB;
+  int splits; int64_t kps;
+  tnp_split(Np, K, splits, kps);
+  return egnn_gemm3::planes_bytes(Np, (int64_t)splits * kps, TNP_RB, TNP_BKT) + 1024;
+}
+
+extern "C" int egnn_gemm_tn_planes_pack_f32(const float* B, int64_t ldb, const int64_t* b_rows, int64_t N, int64_t K, void* planes,
+                                            size_t planes_bytes, void* stream) {
+  EGNN_CHECK_ARG(B && planes && N > 0 && K > 0 && ldb >= N);
+  if (planes_bytes < egnn_gemm_tn_planes_bytes(N, K) || (reinterpret_cast<uintptr_t>(planes) & 1023u)) return EGNN_EWORKSPACE;
+  const int64_t Np = (N + TNP_RB - 1) / TNP_RB * TNP_RB;
+  int splits; int64_t kps;
+  tnp_split(Np, K, splits, kps);
+  // operand rows = the N columns of B (zero planes past N), k = the K (gathered) rows of B (zero planes past K, up to whole k-ranges)
+  egnn_gemm3::pack_planes_kernel<TNP_RB, TNP_BKT><<<dim3(16384), dim3(256), 0, (hipStream_t)stream>>>(
+      B, ldb, 0, N, K, nullptr, nullptr, nullptr, 0.f, (char*)planes, b_rows, (int64_t)splits * kps);
+  return egnn_launch_status();
+}
+
+extern "C" size_t egnn_gemm_tn_planes_ws_floats(int64_t M, int64_t N, int64_t K) {
+  const int64_t Np = (N + TNP_RB - 1) / TNP_RB * TNP_RB;
+  int splits; int64_t kps;
+  tnp_split(Np, K, splits, kps);       // (the k-ranges do not depend on M: the planes were padded with the same)
+  return (size_t)splits * (size_t)M * (size_t)Np;
+}
+
+extern "C" int egnn_gemm_tn_planes_f32(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const void* planes,
+                                       float* C, int64_t ldc, float* ws, size_t ws_floats, void* stream) {
+  EGNN_CHECK_ARG(M > 0 && N > 0 && K > 0 && A && planes && C && lda >= M && ldc >= N);
+  if (M % TnpTile::BM != 0 || lda % 4 != 0 || !egnn_aligned16(A) || (reinterpret_cast<uintptr_t>(planes) & 1023u) || !gemm_split_pipe())
+    return EGNN_EALIGN;
+  if (ws == nullptr || ws_floats < egnn_gemm_tn_planes_ws_floats(M, N, K)) return EGNN_EWORKSPACE;
+  const int64_t Np = (N + TNP_RB - 1) / TNP_RB * TNP_RB;
+  int splits; int64_t kps;
+  tnp_split(Np, K, splits, kps);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)((M / TnpTile::BM) * (Np / TnpTile::BN)), (unsigned)splits);
+  const int rc = launch_dyn_lds<gemm_tn_planes_kernel>(grid, dim3(256), (size_t)TnpTile::SMEM_BYTES, st, A, lda, (const char*)planes,
+                                                       (int64_t)splits * kps / TNP_BKT, M, Np, K, kps, ws);
+  if (rc != EGNN_OK) return rc;
+  const int64_t blocks = (M * N + 63) / 64;
+  hipLaunchKernelGGL(gemm_tn_planes_reduce_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, ws, splits, M, Np, N, alpha, C,
+                     ldc);
+  return egnn_launch_status();
+}
+
+// ---- C = alpha A[a_rows] B^T + bias for a CONSTANT, row-gathered A cut once into planes (see gemm_pp_kernel) ----------------------------
+extern "C" size_t egnn_gemm_rows_planes_bytes(int64_t M, int64_t K) { return egnn_gemm3::planes_bytes(M, K, PP_RB, PP_BKT) + 1024; }
+
+extern "C" int egnn_gemm_rows_planes_pack_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t M, int64_t K, void* planes,
+                                              size_t planes_bytes, void* stream) {
+  EGNN_CHECK_ARG(A && planes && M > 0 && K > 0 && lda >= K);
+  if (planes_bytes < egnn_gemm_rows_planes_bytes(M, K) || (reinterpret_cast<uintptr_t>(planes) & 1023u)) return EGNN_EWORKSPACE;
+  egnn_gemm3::pack_planes<PP_RB, PP_BKT>(A, lda, 1, M, K, nullptr, a_rows, nullptr, 0.f, (char*)planes, (hipStream_t)stream);
+  return egnn_launch_status();
+}
+
+extern "C" size_t egnn_gemm_rows_planes_ws_bytes(int64_t N, int64_t K) { return egnn_gemm3::planes_bytes(N, K, PP_RB, PP_BKT) + 2048; }
+
+extern "C" int egnn_gemm_rows_planes_f32(int64_t M, int64_t N, int64_t K, float alpha, const void* planes_a, const float* B, int64_t ldb,
+                                         const float* bias, float* C, int64_t ldc, void* ws, size_t ws_bytes, void* stream) {
+  EGNN_CHECK_ARG(M > 0 && N > 0 && K > 0 && planes_a && B && C && ldb >= K && ldc >= N);
+  if (N % 128 != 0 || (reinterpret_cast<uintptr_t>(planes_a) & 1023u) || !gemm_split_pipe()) return EGNN_EALIGN;
+  if (ws == nullptr || ws_bytes < egnn_gemm_rows_planes_ws_bytes(N, K)) return EGNN_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char* planes_b = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(ws) + 1023) & ~(uintptr_t)1023);
+  egnn_gemm3::pack_planes<PP_RB, PP_BKT>(B, ldb, 1, N, K, nullptr, nullptr, nullptr, 0.f, planes_b, st);   // B stored [N, K]: k contiguous
+  const bool wide = ldc % 4 == 0 && egnn_aligned16(C);
+  GemmArgs g{M, N, K, nullptr, 0, nullptr, 0, bias, C, ldc, alpha, nullptr, 1, 0, nullptr, nullptr, wide ? 1 : 0, 1,
+             reinterpret_cast<const u32x4*>(planes_b), 0, nullptr, 0};
+  const int64_t tiles = ((M + 127) / 128) * (N / 128);
+  if (tiles > 0x7fffffffLL) return EGNN_EINVAL;
+  const int rc = launch_dyn_lds<gemm_pp_kernel>(dim3((unsigned)tiles), dim3(256), (size_t)PpTile::SMEM_BYTES, st, g, (const char*)planes_a);
+  if (rc != EGNN_OK) return rc;
+  return egnn_launch_status();
 }

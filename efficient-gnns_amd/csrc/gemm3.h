@@ -59,7 +59,8 @@ __device__ __forceinline__ void dma16(const void* g, void* lds_wave_base) {
 // Issues this wave's share of the DMA of one operand stage.
 //   F32K / F32M: p = fp32 matrix, ld = leading dimension, r0 = first row of the block tile, k0 = first k of the stage
 //   PLANES:      p = packed planes, nks = k-steps of the whole operand, r0 / k0 as above (multiples of R / BKT)
-// rmax (F32K): rows at or past it re-read row rmax - 1 (the last row tile of a ragged operand; such rows are never stored)
+// rmax (F32K): rows at or past it re-read row rmax - 1 (the last row tile of a ragged operand; such rows are never stored);
+// rmax (F32M): the same for the k-rows of the transposed operand (a ragged reduction whose other operand is zero-padded planes)
 template <int MODE, int R, int BKT>
 __device__ __forceinline__ void issue_stage(const void* __restrict__ p, int64_t ld_or_nks, int64_t r0, int64_t k0, char* lds, int wave, int lane,
                                             int64_t rmax = INT64_MAX) {
@@ -82,7 +83,9 @@ __device__ __forceinline__ void issue_stage(const void* __restrict__ p, int64_t 
       constexpr int CPR = R / 4;                             // 16-byte chunks per k-row
       const int cidx = q * 64 + lane;
       const int kk = cidx / CPR, c = cidx % CPR;
-      dma16((const float*)p + (k0 + kk) * ld_or_nks + r0 + 4 * c, dst);
+      int64_t kr = k0 + kk;
+      if (kr >= rmax) kr = rmax - 1;                         // rmax = k limit here: k-rows past it re-read the last one (their partner planes are zero)
+      dma16((const float*)p + kr * ld_or_nks + r0 + 4 * c, dst);
     }
   }
 }
@@ -282,13 +285,17 @@ __host__ __device__ inline size_t planes_bytes(int64_t rows, int64_t K, int RB, 
 
 // X(r, k): k_major = 1 -> X[r * ld + k], else X[k * ld + r].  One thread per 16-byte output chunk (8 k-values of one row);
 // rows / k past the end are zero planes.  Optional factors applied before the cut: scale[row] (per operand row) and
-// exp(kshift - klse[k]) (per k: the row weights w_i of the G-CRD backward, criterion.py:139-145 via nce.hip).  ridx: row gather.
+// exp(kshift - klse[k]) (per k: the row weights w_i of the G-CRD backward, criterion.py:139-145 via nce.hip).  ridx: row gather;
+// kidx: gather along k (k-value j of the operand is storage index kidx[j]: the train rows of a [N, features] matrix as the
+// reduction dimension of dW = dY^T X[train_idx]).
 template <int RB, int BKT>
 __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restrict__ X, int64_t ld, int k_major, int64_t rows, int64_t K,
                                                           const float* __restrict__ scale, const int64_t* __restrict__ ridx,
-                                                          const float* __restrict__ klse, float kshift, char* __restrict__ out) {
+                                                          const float* __restrict__ klse, float kshift, char* __restrict__ out,
+                                                          const int64_t* __restrict__ kidx = nullptr, int64_t K_pad = 0) {
   using S = Stage<PLANES, RB, BKT>;
-  const int64_t nks = (K + BKT - 1) / BKT, nrb = (rows + RB - 1) / RB;
+  // K_pad > K: zero planes up to K_pad (whole k-ranges of a split reduction)
+  const int64_t nks = ((K_pad > K ? K_pad : K) + BKT - 1) / BKT, nrb = (rows + RB - 1) / RB;
   const int64_t total = nrb * nks * RB * S::CHP;
   for (int64_t t = blockIdx.x * 256LL + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
     // consecutive threads walk the contiguous direction of X: chunks of one row (k-major) or rows of one chunk
@@ -304,7 +311,8 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restric
       const int64_t k = k0 + j;
       float x = 0.f;
       if (row < rows && k < K) {
-        x = sc * (k_major ? X[rs * ld + k] : X[k * ld + rs]);
+        const int64_t ks = kidx ? kidx[k] : k;
+        x = sc * (k_major ? X[rs * ld + ks] : X[ks * ld + rs]);
         if (klse) x *= expf(kshift - klse[k]);
       }
       v[j] = x;
@@ -320,11 +328,11 @@ __global__ __launch_bounds__(256) void pack_planes_kernel(const float* __restric
 
 template <int RB, int BKT>
 static inline void pack_planes(const float* X, int64_t ld, int k_major, int64_t rows, int64_t K, const float* scale, const int64_t* ridx,
-                               const float* klse, float kshift, char* out, hipStream_t st) {
+                               const float* klse, float kshift, char* out, hipStream_t st, const int64_t* kidx = nullptr) {
   const int64_t total = ((rows + RB - 1) / RB) * ((K + BKT - 1) / BKT) * RB * (BKT / 8);
   const int64_t blocks = (total + 255) / 256;
   hipLaunchKernelGGL((pack_planes_kernel<RB, BKT>), dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, X, ld, k_major, rows, K,
-                     scale, ridx, klse, kshift, out);
+                     scale, ridx, klse, kshift, out, kidx);
 }
 
 }  // namespace egnn_gemm3

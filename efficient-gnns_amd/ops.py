@@ -658,6 +658,76 @@ def grad_tap(x: Tensor) -> Tensor:
     return y
 
 
+_CONST_PLANES = _cache.TensorKeyedCache(capacity=4)
+
+
+def _dw_const_rows(gy: Tensor, x: Tensor, idx: Tensor):
+    """dW = gy^T x[idx] for a CONSTANT x (the teacher's features under the teacher projection head, gnn.py:155,303-306): x[idx] is cut
+    once per (x, idx) identity + version into bf16 planes with the row position as the reduction index (egnn_gemm_tn_planes_pack_f32,
+    6 bytes per element: 419 MB for [90 941, 750], kept as long as the cache entry lives); the per-step product then takes the
+    transposed-operand x planes form of the DMA pipeline (egnn_gemm_tn_planes_f32).  None = shape not taken (the caller's generic
+    gather-fused GEMM)."""
+    K, M = gy.shape
+    N = x.shape[1]
+    if not (M % 256 == 0 and K >= 16384 and gy.stride(0) % 4 == 0 and gy.data_ptr() % 16 == 0 and x.stride(1) == 1 and idx.numel() == K):
+        return None
+    lib = _lib.load()
+
+    def build():
+        nbytes = lib.egnn_gemm_tn_planes_bytes(N, K)
+        planes = _aligned_bytes(nbytes, x.device)
+        _lib.check(lib.egnn_gemm_tn_planes_pack_f32(_lib.ptr(x), x.stride(0), _lib.ptr(idx), N, K, _lib.ptr(planes), nbytes, _lib.stream()),
+                   "egnn_gemm_tn_planes_pack_f32")
+        return planes
+    planes = _CONST_PLANES.get((x, idx), (), build)
+    gw = torch.empty(M, N, dtype=torch.float32, device=gy.device)
+    nws = lib.egnn_gemm_tn_planes_ws_floats(M, N, K)
+    ws = torch.empty(nws, dtype=torch.float32, device=gy.device)
+    rc = lib.egnn_gemm_tn_planes_f32(M, N, K, 1.0, _lib.ptr(gy), gy.stride(0), _lib.ptr(planes), _lib.ptr(gw), gw.stride(0), _lib.ptr(ws), nws,
+                                     _lib.stream())
+    if rc == _lib.EGNN_EALIGN:
+        return None
+    _lib.check(rc, "egnn_gemm_tn_planes_f32")
+    return gw
+
+
+_CONST_ROW_PLANES = _cache.TensorKeyedCache(capacity=4)
+
+
+def _aligned_bytes(nbytes: int, device) -> Tensor:
+    """uint8 [nbytes] starting on a 1 KB boundary (the DMA pipeline copies plane tiles in 1 KB pieces)."""
+    buf = torch.empty(nbytes + 1024, dtype=torch.uint8, device=device)
+    off = (-buf.data_ptr()) % 1024
+    return buf[off:off + nbytes]
+
+
+def _fwd_const_rows(x: Tensor, idx: Tensor, w: Tensor, bias: Tensor | None):
+    """y = x[idx] @ w^T + bias for a CONSTANT x (see ``_dw_const_rows``): the gathered rows live as tile-packed bf16 planes, cut once
+    per (x, idx); w is cut per call (egnn_gemm_rows_planes_f32: planes x planes on the DMA pipeline).  None = shape not taken."""
+    M, K = idx.numel(), x.shape[1]
+    N = w.shape[0]
+    if not (N % 128 == 0 and M >= 16384 and x.stride(1) == 1 and w.stride(1) == 1 and w.shape[1] == K):
+        return None
+    lib = _lib.load()
+
+    def build():
+        nbytes = lib.egnn_gemm_rows_planes_bytes(M, K)
+        planes = _aligned_bytes(nbytes, x.device)
+        _lib.check(lib.egnn_gemm_rows_planes_pack_f32(_lib.ptr(x), x.stride(0), _lib.ptr(idx), M, K, _lib.ptr(planes), nbytes, _lib.stream()),
+                   "egnn_gemm_rows_planes_pack_f32")
+        return planes
+    planes = _CONST_ROW_PLANES.get((x, idx), (), build)
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    nws = lib.egnn_gemm_rows_planes_ws_bytes(N, K)
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+    rc = lib.egnn_gemm_rows_planes_f32(M, N, K, 1.0, _lib.ptr(planes), _lib.ptr(w), w.stride(0), _lib.ptr(bias), _lib.ptr(y), y.stride(0),
+                                       _lib.ptr(ws), nws, _lib.stream())
+    if rc == _lib.EGNN_EALIGN:
+        return None
+    _lib.check(rc, "egnn_gemm_rows_planes_f32")
+    return y
+
+
 class _LinearRows(torch.autograd.Function):
     """y = x[idx] @ weight^T + bias for UNIQUE row ids, without materialising x[idx] (egnn_gemm_rows_f32): the forward
     gathers in the A-operand load, dW = dY^T x[idx] in the B-operand load, dx scatters the rows of dY W (or leaves
@@ -668,7 +738,8 @@ class _LinearRows(torch.autograd.Function):
         w = pad_pitch(weight) if not _pitch_ok(weight) else weight   # 0.8 MB at 256 x 750: rows 16-byte aligned
         ctx.save_for_backward(x, idx, w)
         ctx.has_bias, ctx.box = bias is not None, box
-        return gemm_raw(x, w, False, True, bias, a_rows=idx)
+        y = _fwd_const_rows(x, idx, w, bias) if not x.requires_grad else None      # a constant input: its gathered rows as planes, cut once
+        return y if y is not None else gemm_raw(x, w, False, True, bias, a_rows=idx)
 
     @staticmethod
     def backward(ctx, gy):
@@ -683,7 +754,9 @@ class _LinearRows(torch.autograd.Function):
                 gx = torch.zeros(x.shape, dtype=gy.dtype, device=gy.device)
                 gx.index_copy_(0, idx, rows)
         if ctx.needs_input_grad[2]:
-            gw = gemm_raw(gy, x, True, False, b_rows=idx)
+            gw = _dw_const_rows(gy, x, idx) if not x.requires_grad else None
+            if gw is None:
+                gw = gemm_raw(gy, x, True, False, b_rows=idx)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gb = colsum(gy)
         return gx, None, gw, gb, None

@@ -247,6 +247,31 @@ int egnn_gemm_rows_f32(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K
                        const float* bias, float* C, int64_t ldc,
                        int split_k, float* ws, size_t ws_bytes, void* stream);
 
+/* C [M, N] = alpha A^T B[b_rows] for a CONSTANT B (dW = dY^T x[idx] of a Linear over a constant input: the teacher projection head
+ * of /root/reference/arxiv_pyg/gnn.py:296-306, whose input -- the teacher's [N, 750] features -- never changes): B's gathered rows
+ * are cut ONCE into tile-packed bf16 planes with the gathered row index as the reduction dimension (egnn_gemm_tn_planes_pack_f32;
+ * egnn_gemm_tn_planes_bytes of 1 KB-aligned device memory, 6 bytes per element); every later product reads A [K, M] (lda >= M,
+ * 16-byte aligned rows, M % 256 == 0) down LDS columns against those planes -- no gather and no operand cut in the loop.  Same
+ * six-product fp32 arithmetic as egnn_gemm_f32 on the bf16 pipe; fixed-order split over k (workspace egnn_gemm_tn_planes_ws_floats).
+ * EGNN_EALIGN: shape / alignment not taken, or EGNN_GEMM_PIPE=f32 (callers then use egnn_gemm_rows_f32). */
+size_t egnn_gemm_tn_planes_bytes(int64_t N, int64_t K);
+int egnn_gemm_tn_planes_pack_f32(const float* B, int64_t ldb, const int64_t* b_rows, int64_t N, int64_t K, void* planes,
+                                 size_t planes_bytes, void* stream);
+size_t egnn_gemm_tn_planes_ws_floats(int64_t M, int64_t N, int64_t K);
+int egnn_gemm_tn_planes_f32(int64_t M, int64_t N, int64_t K, float alpha, const float* A, int64_t lda, const void* planes, float* C,
+                            int64_t ldc, float* ws, size_t ws_floats, void* stream);
+
+/* The forward of the same Linear, C [M, N] = alpha A[a_rows] B^T + bias (B stored [N, K] as nn.Linear keeps its weight; N % 128 == 0):
+ * the CONSTANT A's gathered rows are cut once into planes (row blocks of 128 gathered rows x k-steps of 16: the gather is baked in),
+ * B is cut per call into the workspace (egnn_gemm_rows_planes_ws_bytes); both operand tiles then travel global -> LDS as lane-linear
+ * DMA copies with no VALU work in the loop.  Same arithmetic and return codes as above. */
+size_t egnn_gemm_rows_planes_bytes(int64_t M, int64_t K);
+int egnn_gemm_rows_planes_pack_f32(const float* A, int64_t lda, const int64_t* a_rows, int64_t M, int64_t K, void* planes,
+                                   size_t planes_bytes, void* stream);
+size_t egnn_gemm_rows_planes_ws_bytes(int64_t N, int64_t K);
+int egnn_gemm_rows_planes_f32(int64_t M, int64_t N, int64_t K, float alpha, const void* planes_a, const float* B, int64_t ldb,
+                              const float* bias, float* C, int64_t ldc, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused losses (K5-K7).  Every loss entry point comes as fwd (scalars out) + bwd (input grads out);
  * upstream gradients are passed as DEVICE scalars so that no host sync is needed.

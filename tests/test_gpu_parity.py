@@ -1429,6 +1429,45 @@ def test_sharded_epoch_captured_as_a_graph_replays_the_eager_steps(gnn, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,N,M,K", [(40000, 750, 256, 20011), (30000, 256, 512, 16384), (25000, 100, 256, 17000)])
+def test_weight_gradient_against_constant_rows_cut_once_into_planes(n, N, M, K):
+    """egnn_gemm_tn_planes_{pack,}_f32 (ops._dw_const_rows): dW = dY^T x[idx] for a constant x whose gathered rows were cut once
+    into bf16 planes -- against a float64 product (error unit sum_k |a_k b_k|, the bar of the split-pipeline accuracy test) and
+    against the generic gather-fused GEMM; ragged K (zero planes past the end, clamped dY rows), padded columns dropped, a second
+    call reuses the cached planes, an in-place change of x rebuilds them."""
+    g = torch.Generator().manual_seed(n + N)
+    x = ops.pad_pitch((torch.randn(n, N, generator=g) * torch.exp2(torch.randint(-4, 4, (n, N), generator=g).float())).to(DEV))
+    idx = torch.randperm(n, generator=g)[:K].to(DEV)
+    gy = (torch.randn(K, M, generator=g) * torch.exp2(torch.randint(-4, 4, (K, M), generator=g).float())).to(DEV)
+    got = ops._dw_const_rows(gy, x, idx)
+    assert got is not None and got.shape == (M, N)
+    A, B = gy.double().t().cpu(), x[idx].double().cpu()
+    ref = A @ B
+    unit = A.abs() @ B.abs()
+    err = ((got.double().cpu() - ref).abs() / unit)
+    assert float(err.mean()) < 1.2e-7 and float(err.max()) < 2e-6, (float(err.mean()), float(err.max()))
+    generic = ops.gemm_raw(gy, x, True, False, b_rows=idx)
+    close(got, generic, rtol=1e-5, atol_scale=1e-6)
+    n_cached = len(ops._CONST_PLANES)
+    again = ops._dw_const_rows(gy, x, idx)
+    assert torch.equal(again, got) and len(ops._CONST_PLANES) == n_cached, "planes reused, fixed summation order"
+    x.mul_(2.0)                                  # a new version of x: the planes are rebuilt
+    close(ops._dw_const_rows(gy, x, idx), got * 2.0, rtol=1e-6, atol_scale=1e-7)
+    # through autograd: the teacher head's Linear over constant features -- forward on the planes x planes form, backward as above
+    w = (torch.randn(M, N, generator=g) * 0.05).to(DEV).requires_grad_(True)
+    b = torch.randn(M, generator=g).to(DEV).requires_grad_(True)
+    y = ops.linear_rows(x, idx, w, b)
+    Y64 = x[idx].double().cpu() @ w.detach().double().cpu().t()
+    uy = x[idx].double().cpu().abs() @ w.detach().double().cpu().abs().t()
+    ey = (y.detach().double().cpu() - b.detach().double().cpu() - Y64).abs() / uy
+    assert float(ey.mean()) < 1.2e-7 and float(ey.max()) < 2e-6, (float(ey.mean()), float(ey.max()))
+    close(y, ops.gemm_raw(x, ops.pad_pitch(w.detach()), False, True, b.detach(), a_rows=idx), rtol=1e-5, atol_scale=1e-6)
+    y.backward(gy)
+    close(w.grad, ops.gemm_raw(gy, x, True, False, b_rows=idx), rtol=1e-5, atol_scale=1e-6)
+    close(b.grad, gy.sum(0), rtol=1e-5, atol_scale=1e-6)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,C,P,m,padded", [(1000, 750, 256, 400, True), (1000, 750, 256, 400, False), (513, 64, 40, 513, True),
                                            (3000, 256, 128, 1, True), (700, 130, 72, 300, False)])
 def test_linear_rows_fused_gather_gemm_vs_torch(n, C, P, m, padded):
