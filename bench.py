@@ -234,6 +234,8 @@ class GemmProbe:
                 e0.record()
                 rc = orig(*a)
                 e1.record()
+                if rc != 0:                                # a refused shape / pipeline (EGNN_EALIGN: the caller takes another entry point)
+                    return rc
                 if name == "egnn_gemm_tn_planes_f32":      # C = A^T B[rows], B cut once into planes: (M, N, K, ...)
                     self.records.append((1, 0, int(a[0]), int(a[1]), int(a[2]), "+rows(planes)", e0, e1))
                 elif name == "egnn_gemm_rows_planes_f32":  # C = A[rows] B^T, A cut once into planes
