@@ -46,6 +46,10 @@ def all_cases():
     for name, gnn, mode, sig in (("gcn-nce-static", "gcn", "nce", 6.0), ("gcn-kd", "gcn", "kd", None), ("sage-lpw", "sage", "lpw", None),
                                  ("gcn-gpw-static", "gcn", "gpw", 6.0)):
         cases[f"{name}-notrain-tail-ov1"] = dict(gnn=gnn, mode=mode, sigmas=sig, order="natural", overlap=1, train_below=0.4)
+    # 5 sampled rows over the ranks in the dynamic layout: ranks that own train rows but NO sampled row (an empty pick under SyncBN,
+    # an empty row block of the G-CRD problem) next to ranks that do
+    cases["gcn-nce-overflow-5samples-ov1"] = dict(gnn="gcn", mode="nce", sigmas=-50.0, order="natural", overlap=1, max_samples=5)
+    cases["gcn-gpw-overflow-5samples-ov1"] = dict(gnn="gcn", mode="gpw", sigmas=-50.0, order="natural", overlap=1, max_samples=5)
     return cases
 
 
