@@ -1324,8 +1324,18 @@ class ShardedGraphedEpoch:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.rep, self.correct = body()
             # structural guard on every capture (_audit.check_captured_graph): no memset / host node next to the kernels and RCCL's nodes
-            from ._audit import check_captured_graph
-            self.node_kinds = check_captured_graph(self.graph, "ShardedGraphedEpoch", kernels_only=False)
+            from ._audit import LongReductionInCapture, check_captured_graph, graph_node_kinds
+            try:
+                self.node_kinds = check_captured_graph(self.graph, "ShardedGraphedEpoch", kernels_only=False)
+            except LongReductionInCapture as e:
+                # One rank over RCCL has been observed (kernel + memcpy nodes only) and is held to that.  What RCCL itself puts into a
+                # captured collective with SEVERAL ranks has never been observed (no multi-GPU box in any round): there a violation is
+                # reported, not fatal -- the operator-name audit above still refuses long torch reductions on every rank count.
+                if prob.world == 1:
+                    raise
+                import warnings
+                warnings.warn(f"{e}  (world_size {prob.world}: reported only; RCCL's own graph nodes cannot be told apart here)")
+                self.node_kinds = graph_node_kinds(self.graph)
             self.graph.instantiate()
             torch.cuda.synchronize(dev)
         self._refresh()
