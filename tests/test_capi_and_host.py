@@ -481,3 +481,54 @@ def test_ctypes_table_matches_the_header_argument_by_argument():
         else:
             assert restype is C.c_char_p
     assert seen == set(_lib.SIGNATURES)
+
+
+def test_student_layer_form_table():
+    """models._Student._layer_form: WHICH kernels run a hidden layer (conv -> BatchNorm -> ReLU -> dropout, gnn.py:47-50) is a function of
+    mode, grad mode, device, adjacency kind and module types only.  The decision table, checked on the host with a stand-in for a GPU
+    tensor (the forms themselves are compared with their composed counterparts on the GPU: tests/test_gpu_parity.py)."""
+    import types
+    import efficient_gnns_amd.dist as DD
+    import efficient_gnns_amd.models as PM
+    gpu = types.SimpleNamespace(is_cuda=True, requires_grad=False)          # what _layer_form reads of the layer input
+    cpu = types.SimpleNamespace(is_cuda=False, requires_grad=False)
+    adj = E.SparseTensor(rowptr=torch.tensor([0, 1, 2]), col=torch.tensor([1, 0]), sparse_sizes=(2, 2))
+    sharded = types.SimpleNamespace(gcn_normalized=lambda: None, aggregate=None)
+
+    def forms(model, x, a):
+        return [model._layer_form(li, x, a) for li in range(len(model.bns))]
+
+    gcn = PM.GCN(128, 256, 40, 3, 0.5)
+    gcn.train()
+    assert forms(gcn, gpu, adj) == [("stats", "bn_act"), ("stats", "tail")]            # training on one GPU: statistics epilogue, fused tail
+    assert forms(gcn, cpu, adj) == [("plain", "torch"), ("plain", "torch")]            # (the gloo tests' stand-in route)
+    with torch.no_grad():
+        assert forms(gcn, gpu, adj) == [("stats", "bn_act"), ("stats", "bn_act")]      # no autograd: no fused tail
+    gcn.eval()
+    with torch.no_grad():
+        assert forms(gcn, gpu, adj) == [("fold", None), ("fold", None)]                # test(): BatchNorm folded into the conv
+    assert forms(gcn, gpu, adj) == [("plain", "bn_act"), ("plain", "bn_act")]          # eval with autograd on: no fold
+    prev = PM._FUSED_TAIL
+    try:
+        PM._FUSED_TAIL = False
+        gcn.train()
+        assert forms(gcn, gpu, adj) == [("stats", "bn_act"), ("stats", "bn_act")]
+    finally:
+        PM._FUSED_TAIL = prev
+    wide_out = PM.GCN(128, 256, 300, 3, 0.5)                                          # 300 classes > 64: the tail kernels do not apply
+    wide_out.train()
+    assert forms(wide_out, gpu, adj)[-1] == ("stats", "bn_act")
+    sage = PM.SAGE(128, 256, 40, 3, 0.5)
+    sage.train()
+    assert forms(sage, gpu, adj) == [("plain", "bn_act"), ("plain", "bn_act")]
+    # node-range shards: SyncBatchNorm1d, the fused tail with all-rank statistics for a GCN, the eval fold as well
+    sgcn = DD.swap_batchnorm(PM.GCN(128, 256, 40, 3, 0.5))
+    sgcn.train()
+    assert forms(sgcn, gpu, sharded) == [("plain", "sync"), ("plain", "tail_sync")]
+    assert forms(sgcn, cpu, sharded) == [("plain", "sync"), ("plain", "sync")]
+    sgcn.eval()
+    with torch.no_grad():
+        assert forms(sgcn, gpu, sharded) == [("fold", None), ("fold", None)]
+    ssage = DD.swap_batchnorm(PM.SAGE(128, 256, 40, 3, 0.5))
+    ssage.train()
+    assert forms(ssage, gpu, sharded) == [("plain", "sync"), ("plain", "sync")]
