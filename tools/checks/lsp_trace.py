@@ -18,6 +18,10 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import efficient_gnns_amd.data as D
 import efficient_gnns_amd.models as PM
+import efficient_gnns_amd._audit as _A
+# this tool captures the REFUSED kind of graph on purpose (the reproducer of the round-4 finding): the structural guard of round 5
+# (models.GraphedEpoch reads every captured graph back and refuses memset nodes) is reduced to its census here
+_A.check_captured_graph = lambda graph, what, kernels_only: _A.graph_node_kinds(graph)
 import efficient_gnns_amd.ops as ops
 import efficient_gnns_amd.ops_edge as OE
 from efficient_gnns_amd.utils import subgraph
