@@ -86,6 +86,10 @@ def parse():
                     help="all ranks of a multi-rank launch share cuda:0 and their collectives travel over gloo through host memory "
                          "(efficient-gnns_amd/hostcomm.py): a FUNCTIONAL run of the sharded step on the real kernels with a non-empty halo "
                          "on a one-GPU box (eager launches; its epochs/s is not a scaling measurement)")
+    ap.add_argument("--device", default="cuda", choices=["cuda", "cpu"],
+                    help="cpu: the sharded path's HOST LOGIC over gloo (launcher, partition plan, collectives, the JSON line) with the tests' "
+                         "stand-ins for the kernels (tests/bench_cpu_harness.py); without them every operator raises on a CPU tensor")
+    ap.add_argument("--hidden", type=int, default=0, help="sharded runs: hidden width (default: the model of record, 256)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the node-range sharded (multi-GPU) code path even with one rank: RCCL init, halo plan, "
                          "SyncBN, row-block G-CRD -- a 1-GPU check of the path the N>1 runs take")
@@ -742,18 +746,45 @@ def cap_cpu_threads(local_world: int = 1) -> int:
     return n
 
 
+def spawn_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher in front: re-run this very command line as N ranks of one node under
+    ``torch.distributed.run`` (rendezvous on 127.0.0.1, a free port), one process per GPU; rank 0's JSON line goes to this
+    process's stdout unchanged.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(os.environ.get("EGNN_BENCH_ENTRY", sys.argv[0])), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on these hosts (RCCL across processes)
+    print(f"bench.py: --gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: start the N ranks (one process per GPU) and hand their exit code on -- a plain
+        # `--gpus 8` must never run one GPU and print n_gpus 1
+        raise SystemExit(spawn_ranks(args.gpus))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch one rank per GPU, or leave WORLD_SIZE unset and "
+                         f"let `python bench.py --gpus N` start them)")
     cap_cpu_threads(int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     if args.one_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if args.device == "cpu":
+        if not (world > 1 or args.force_sharded):
+            raise SystemExit("bench.py: --device cpu exists for the host-logic harness of the sharded path only (tests/bench_cpu_harness.py)")
+        device = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     hp = dict(HP, max_samples=args.max_samples)
     if args.training in MODE_HP:
         hp.update(MODE_HP[args.training])
@@ -788,7 +819,8 @@ def main():
             from efficient_gnns_amd import hostcomm
             hostcomm.install()
             args.graph = "off"        # a host round trip cannot be captured into a hipGraph
-        dist_mod.bench_main(args, hp, MODEL, rank, world, device, backend="gloo" if args.one_device else "nccl")   # prints the line on rank 0; ends with barrier + destroy_process_group
+        model_cfg = dict(MODEL, hidden=args.hidden) if args.hidden else MODEL
+        dist_mod.bench_main(args, hp, model_cfg, rank, world, device, backend="gloo" if (args.one_device or args.device == "cpu") else "nccl")   # prints the line on rank 0; ends with barrier + destroy_process_group
         # leave without the interpreter / static-destructor teardown: communicator background threads have been seen racing it
         # (exit code -6 after all results were delivered) and the launcher reads every rank's exit code
         sys.stdout.flush()

@@ -1577,7 +1577,7 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
                   f"SAGE-{model_cfg['hidden']} (mean) student + logit KD from synthetic teacher logits, full-graph train step + eval per epoch")
         else:
             metric = "training epochs/sec, ogbn-arxiv 3-layer GCN student + G-CRD, 1/2/4/8 MI355X"
-            wl = (f"ogbn-arxiv-shaped synthetic graph (N={data.num_nodes}, nnz_sym={data.adj_t.nnz()}), 3-layer {args.gnn.upper()}-256 student + "
+            wl = (f"ogbn-arxiv-shaped synthetic graph (N={data.num_nodes}, nnz_sym={data.adj_t.nnz()}), 3-layer {args.gnn.upper()}-{model_cfg['hidden']} student + "
                   f"{args.training} loss (max_samples={hp['max_samples']}, proj_dim={hp['proj_dim']}), full-graph train step + eval per epoch")
         out = dict(
             metric=metric, value=round(args.steps / el, 3), unit="epochs/s", n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -3,6 +3,7 @@ is bit-exact vs the oracle; the product path fails loudly without a GPU (no CPU 
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -532,3 +533,25 @@ def test_student_layer_form_table():
     ssage = DD.swap_batchnorm(PM.SAGE(128, 256, 40, 3, 0.5))
     ssage.train()
     assert forms(ssage, gpu, sharded) == [("plain", "sync"), ("plain", "sync")]
+
+
+def test_plain_bench_command_starts_the_ranks_itself():
+    """``python bench.py --gpus 2`` with NO launcher in front and WORLD_SIZE unset must start two ranks by itself (it used
+    to run the single-GPU path and print n_gpus 1).  Host logic only: tests/bench_cpu_harness.py puts the gloo tests' stand-ins in
+    place of the kernels in every rank it is re-launched as; the line must say n_gpus 2 and carry a non-empty halo exchange."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "bench_cpu_harness.py"), "--gpus", "2", "--device", "cpu", "--scale", "0.004",
+           "--hidden", "32", "--max-samples", "128", "--steps", "2", "--warmup", "1", "--graph", "off"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "starting 2 ranks" in r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["steps"] == 2
+    per_rank = out["comm_per_epoch"]["per_rank"]
+    assert len(per_rank) == 2 and all(c["halo_all_to_all_bytes_sent"] > 0 for c in per_rank)
+    # a launcher's WORLD_SIZE that disagrees with --gpus is an error, never a silently different run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
