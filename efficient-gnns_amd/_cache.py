@@ -15,8 +15,17 @@ _RECORDERS: list = []
 
 
 class TensorKeyedCache:
-    def __init__(self, capacity: int = 16):
-        self.capacity, self.store = capacity, OrderedDict()
+    def __init__(self, capacity: int = 16, max_bytes: int | None = None):
+        """``max_bytes``: also bound the sum of the values' tensor bytes (the newest entry always stays, whatever its size)."""
+        self.capacity, self.max_bytes, self.store = capacity, max_bytes, OrderedDict()
+
+    @staticmethod
+    def _nbytes(value) -> int:
+        if hasattr(value, "element_size") and hasattr(value, "numel"):
+            return value.numel() * value.element_size()
+        if isinstance(value, (tuple, list)):
+            return sum(TensorKeyedCache._nbytes(v) for v in value)
+        return 0
 
     @staticmethod
     def _key(tensors, extra):
@@ -29,6 +38,9 @@ class TensorKeyedCache:
             hit = self.store[key] = (tuple(tensors), build())
             while len(self.store) > self.capacity:
                 self.store.popitem(last=False)
+            if self.max_bytes is not None:
+                while len(self.store) > 1 and sum(self._nbytes(v[1]) for v in self.store.values()) > self.max_bytes:
+                    self.store.popitem(last=False)
         else:
             self.store.move_to_end(key)
         for rec in _RECORDERS:

@@ -36,6 +36,18 @@ def _sample_rows(n: int, max_samples: int, device):
     return None
 
 
+def _rows_of(x, idx):
+    """(tensor, index) to hand to a kernel that gathers ``x[idx]`` itself.  A deferred activation (lazy.py: the reference's own model
+    code under dropin/accel.py) forms only the rows ``idx`` -- what ``models.distill_loss`` does through ``forward_rows(pick=)``."""
+    m = getattr(x, "_egnn_materialise", None)
+    return (x, idx) if m is None else (m(pick=idx), None)
+
+
+def _plain(x):
+    m = getattr(x, "_egnn_materialise", None)
+    return x if m is None else m()
+
+
 def _ce_term(logits, labels, rows=None):
     return ops.cross_entropy(logits, labels, rows)
 
@@ -80,7 +92,7 @@ def fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000):
 def rows_fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=None, *, _cls=None):
     """``fitnet_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
     loss_cls = (_cls or _ce_term)(logits, labels, rows)
-    loss_aux = ops.fitnet_loss(feat, teacher_feat)
+    loss_aux = ops.fitnet_loss(_plain(feat), _plain(teacher_feat))
     return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 
 
@@ -92,7 +104,7 @@ def at_criterion(logits, labels, feat, teacher_feat, beta=1000):
 def rows_at_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=None, *, _cls=None):
     """``at_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
     loss_cls = (_cls or _ce_term)(logits, labels, rows)
-    loss_aux = ops.at_loss(feat, teacher_feat)
+    loss_aux = ops.at_loss(_plain(feat), _plain(teacher_feat))
     return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 
 
@@ -109,6 +121,9 @@ def rows_gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta
         raise NotImplementedError
     loss_cls = (_cls or _ce_term)(logits, labels, rows)
     idx = None if presampled else _sample_rows(feat.shape[0], max_samples, feat.device)
+    if hasattr(feat, "_egnn_materialise") or hasattr(teacher_feat, "_egnn_materialise"):   # deferred activations: only the rows idx
+        from .lazy import materialise
+        feat, teacher_feat, idx = materialise(feat, idx), materialise(teacher_feat, idx), None
     loss_aux = gsp_loss(feat, teacher_feat, idx, kernel)
     return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 
@@ -124,7 +139,7 @@ def rows_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="c
     if kernel not in ("cosine", "poly", "l2", "rbf") or criterion not in ("kld", "mse"):
         raise NotImplementedError
     loss_cls = (_cls or _ce_term)(logits, labels, rows)
-    loss_aux = lsp_loss(feat, teacher_feat, edge_index, kernel, criterion)
+    loss_aux = lsp_loss(_plain(feat), _plain(teacher_feat), edge_index, kernel, criterion)
     return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 
 
@@ -138,8 +153,8 @@ def rows_nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075
     ``presampled``: as in ``rows_gpw_criterion``."""
     loss_cls = (_cls or _ce_term)(logits, labels, rows)
     idx = None if presampled else _sample_rows(feat.shape[0], max_samples, feat.device)
-    fhat = ops.gather_normalize(feat, idx)
-    that = ops.gather_normalize(teacher_feat, idx)
+    fhat = ops.gather_normalize(*_rows_of(feat, idx))
+    that = ops.gather_normalize(*_rows_of(teacher_feat, idx))
     loss_aux = ops.nce_unit(fhat, that, nce_T)
     return torch.add(loss_cls, loss_aux, alpha=beta), loss_cls, loss_aux
 

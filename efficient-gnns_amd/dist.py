@@ -1158,7 +1158,7 @@ def sharded_train_step_tensors(model, prob: ShardedProblem, optimizer, mode: str
         """(student rows, teacher rows) of the projection heads: all local train rows enter the Linear and the (all-rank) BatchNorm
         statistics; with ``pick`` only those output rows are normalised and stored (ops.sync_bn_act(..., pick=))."""
         if hasattr(student_proj, "forward_rows") and prob.x.is_cuda:
-            return (student_proj.forward_rows(model.out_feat, rows, pick=pick), teacher_proj.forward_rows(prob.teacher_out_feat, rows, pick=pick))
+            return (student_proj.forward_rows(model.out_feat, rows, pick=pick), teacher_proj.forward_rows(prob.teacher_out_feat, rows, pick=pick, const_input=True))
         f, t = student_proj(take(model.out_feat, rows)), teacher_proj(take(prob.teacher_out_feat, rows))
         return (f, t) if pick is None else (f[pick], t[pick])
     if mode == "supervised":

@@ -658,7 +658,7 @@ def grad_tap(x: Tensor) -> Tensor:
     return y
 
 
-_CONST_PLANES = _cache.TensorKeyedCache(capacity=4)
+_CONST_PLANES = _cache.TensorKeyedCache(capacity=4, max_bytes=2 << 30)    # plane images of constant operands: at most 2 GiB of the 288
 
 
 def _dw_const_rows(gy: Tensor, x: Tensor, idx: Tensor):
@@ -691,7 +691,7 @@ def _dw_const_rows(gy: Tensor, x: Tensor, idx: Tensor):
     return gw
 
 
-_CONST_ROW_PLANES = _cache.TensorKeyedCache(capacity=4)
+_CONST_ROW_PLANES = _cache.TensorKeyedCache(capacity=4, max_bytes=2 << 30)
 
 
 def _aligned_bytes(nbytes: int, device) -> Tensor:
@@ -734,11 +734,13 @@ class _LinearRows(torch.autograd.Function):
     them with the tap of a ``grad_tap`` tensor)."""
 
     @staticmethod
-    def forward(ctx, x, idx, weight, bias, box):
+    def forward(ctx, x, idx, weight, bias, box, const_input=False):
         w = pad_pitch(weight) if not _pitch_ok(weight) else weight   # 0.8 MB at 256 x 750: rows 16-byte aligned
         ctx.save_for_backward(x, idx, w)
         ctx.has_bias, ctx.box = bias is not None, box
-        y = _fwd_const_rows(x, idx, w, bias) if not x.requires_grad else None      # a constant input: its gathered rows as planes, cut once
+        # a CONSTANT input (the caller says so: the teacher's features, gnn.py:155): its gathered rows as planes, cut once per (x, idx)
+        ctx.const_input = bool(const_input) and not x.requires_grad
+        y = _fwd_const_rows(x, idx, w, bias) if ctx.const_input else None
         return y if y is not None else gemm_raw(x, w, False, True, bias, a_rows=idx)
 
     @staticmethod
@@ -754,19 +756,23 @@ class _LinearRows(torch.autograd.Function):
                 gx = torch.zeros(x.shape, dtype=gy.dtype, device=gy.device)
                 gx.index_copy_(0, idx, rows)
         if ctx.needs_input_grad[2]:
-            gw = _dw_const_rows(gy, x, idx) if not x.requires_grad else None
+            gw = _dw_const_rows(gy, x, idx) if ctx.const_input else None
             if gw is None:
                 gw = gemm_raw(gy, x, True, False, b_rows=idx)
         if ctx.has_bias and ctx.needs_input_grad[3]:
             gb = colsum(gy)
-        return gx, None, gw, gb, None
+        return gx, None, gw, gb, None, None
 
 
-def linear_rows(x: Tensor, idx: Tensor, weight: Tensor, bias: Tensor | None = None) -> Tensor:
-    """``F.linear(x[idx], weight, bias)`` with the row gather fused into the GEMM (unique ``idx``)."""
+def linear_rows(x: Tensor, idx: Tensor, weight: Tensor, bias: Tensor | None = None, const_input: bool = False) -> Tensor:
+    """``F.linear(x[idx], weight, bias)`` with the row gather fused into the GEMM (unique ``idx``).
+    ``const_input=True`` (opt-in; the teacher projection head): ``x`` does not change between calls -- its gathered rows are re-laid
+    ONCE per (x, idx) identity + version as tile-packed bf16 planes (6 bytes per element, held by a byte-bounded cache) and the forward /
+    weight-gradient products run on the planes x planes forms.  Without the flag no plane image is ever built: activations under
+    ``no_grad`` (requires_grad False as well) or RGCN's per-node-type calls take the gather-fused GEMM."""
     if not _lib.on_gpu(x):
         return torch.nn.functional.linear(take_rows(x, idx), weight, bias)
-    return _LinearRows.apply(x, idx, weight, bias, getattr(x, "_egnn_tap", None) if torch.is_grad_enabled() else None)
+    return _LinearRows.apply(x, idx, weight, bias, getattr(x, "_egnn_tap", None) if torch.is_grad_enabled() else None, const_input)
 
 
 def linear(x: Tensor, weight: Tensor, bias: Tensor | None = None) -> Tensor:
@@ -1338,8 +1344,7 @@ def _row_count(n: int, dev) -> Tensor:
     key = (int(n), str(dev))
     t = _ROW_COUNTS.get(key)
     if t is None:
-        if len(_ROW_COUNTS) > 64:
-            _ROW_COUNTS.clear()
+        # never evicted (4 bytes each): captured graphs read these constants through raw pointers for as long as they live
         t = _ROW_COUNTS[key] = torch.full((1,), float(n), dtype=torch.float32, device=dev)
     return t
 

@@ -555,3 +555,19 @@ def test_plain_bench_command_starts_the_ranks_itself():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_tensor_keyed_cache_is_bounded_by_bytes_as_well():
+    """the plane images of constant operands are hundreds of MB each -- their caches are bounded by bytes, not only by
+    entry count; the newest entry always stays."""
+    from efficient_gnns_amd._cache import TensorKeyedCache
+    c = TensorKeyedCache(capacity=8, max_bytes=1000)
+    keys = [torch.zeros(1) for _ in range(4)]
+    for k in keys[:3]:
+        c.get((k,), (), lambda: torch.zeros(100, dtype=torch.uint8))          # 3 x 100 B
+    assert len(c) == 3
+    c.get((keys[3],), (), lambda: torch.zeros(900, dtype=torch.uint8))        # 1200 B > bound: the oldest entries go
+    assert len(c) == 2 and c.get((keys[3],), (), lambda: None) is not None
+    big = torch.zeros(1)
+    c.get((big,), (), lambda: torch.zeros(5000, dtype=torch.uint8))           # alone above the bound: kept (never an empty cache)
+    assert len(c) == 1

@@ -14,13 +14,25 @@ import torch
 
 from conftest import ROOT
 
-_CANDIDATES = ("/root/reference/arxiv_pyg/gnn.py", os.path.join(ROOT, "oracle", "_ref", "arxiv_pyg", "gnn.py"))
-REF = next((p for p in _CANDIDATES if os.path.exists(p)), _CANDIDATES[0])
+def _ref_script(name):
+    cands = (f"/root/reference/arxiv_pyg/{name}", os.path.join(ROOT, "oracle", "_ref", "arxiv_pyg", name))
+    return next((p for p in cands if os.path.exists(p)), cands[0])
+
+
+REF = _ref_script("gnn.py")
+REF_KD_AUX = _ref_script("gnn_kd_and_aux.py")     # the second caller of the same operators: loss = KD + beta * aux
 DROPIN = os.path.join(ROOT, "efficient-gnns_amd", "dropin")
 _SHIMMED = ("criterion", "torch_geometric", "torch_geometric.nn", "torch_geometric.utils", "torch_geometric.transforms", "torch_sparse")
 
 
-def _load_reference_gnn():
+def _load_accel():
+    spec = importlib.util.spec_from_file_location("egnn_dropin_accel_ref", os.path.join(DROPIN, "accel.py"))
+    accel = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(accel)
+    return accel
+
+
+def _load_reference_gnn(path=None):
     sys.dont_write_bytecode = True   # never leave __pycache__ inside the read-only reference tree
     for name in ("ogb", "ogb.nodeproppred", "torch.utils.tensorboard", "logger"):
         sys.modules.setdefault(name, types.ModuleType(name))
@@ -31,7 +43,7 @@ def _load_reference_gnn():
     sys.path.insert(0, DROPIN)
     for stale in _SHIMMED:
         sys.modules.pop(stale, None)
-    spec = importlib.util.spec_from_file_location("ref_gnn_dropin", REF)
+    spec = importlib.util.spec_from_file_location("ref_gnn_dropin", path or REF)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
@@ -74,17 +86,30 @@ class _Evaluator:
 @pytest.mark.gpu
 @pytest.mark.parametrize("gnn", ["gcn", "sage"])
 @pytest.mark.parametrize("mode", ["nce", "kd", "lpw", "gpw"])
-def test_reference_train_loop_runs_unchanged_on_the_new_operators(gnn, mode):
+@pytest.mark.parametrize("script,accel_mode", [("gnn", "plain"), ("gnn", "lazy"), ("gnn", "eager"), ("kd_and_aux", "plain"), ("kd_and_aux", "lazy")])
+def test_reference_train_loop_runs_unchanged_on_the_new_operators(gnn, mode, script, accel_mode):
     """arxiv_pyg/gnn.py's own GCN / SAGE classes, train() and test() (gnn.py:20,23-85,102-218), imported unchanged
     through efficient-gnns_amd/dropin and executed on the GPU kernels: three optimisation steps and the eval logits equal
     the package's own train_step / evaluate from the same initial weights and the same NumPy draw (dropout 0: the
-    reference's F.dropout and the fused kernel's mask are equal only in distribution)."""
-    assert os.path.exists(REF), ("the reference's arxiv_pyg/gnn.py is neither under /root/reference nor staged under oracle/_ref/ "
-                                 "(run __graft_entry__.build() in the build container before shipping the tree)")
+    reference's F.dropout and the fused kernel's mask are equal only in distribution).
+    ``script`` = kd_and_aux: arxiv_pyg/gnn_kd_and_aux.py's train() (:100-181, loss = KD + beta * aux) against
+    ``train_step(kd_and_aux=True)``.  ``accel_mode``: plain = torch's own BatchNorm1d / Linear (launch.py --plain-torch-modules);
+    eager = dropin/accel.py with one launch per torch call; lazy = accel's default: BatchNorm1d.forward returns a deferred activation
+    that absorbs F.relu / F.dropout and is formed by its consumer (efficient_gnns_amd/lazy.py)."""
+    path = REF if script == "gnn" else REF_KD_AUX
+    assert os.path.exists(path), (f"the reference's {os.path.basename(path)} is neither under /root/reference nor staged under oracle/_ref/ "
+                                  "(run __graft_entry__.build() in the build container before shipping the tree)")
+    if script == "kd_and_aux" and mode == "kd":
+        pytest.skip("gnn_kd_and_aux.py's kd branch is gnn.py's")
     import efficient_gnns_amd.data as D
     import efficient_gnns_amd.models as PM
     from efficient_gnns_amd.utils import subgraph
-    ref = _load_reference_gnn()
+    ref = _load_reference_gnn(path)
+    accel = None
+    if accel_mode != "plain":
+        accel = _load_accel()
+        accel.LAZY = accel_mode == "lazy"
+        accel.enable()
     try:
         dev = torch.device("cuda")
         d = D.arxiv_like(scale=0.02, seed=2)
@@ -120,7 +145,12 @@ def test_reference_train_loop_runs_unchanged_on_the_new_operators(gnn, mode):
         np.random.seed(3)
         got = [ref.train(model, data, train_idx, opt, args, tf, tl, sp, tp, edge_index) for _ in range(3)]
         np.random.seed(3)
-        want = [PM.train_step(mine, data.x, data.adj_t, data.y, train_idx, mopt, mode, hp, tf, tl, msp, mtp, edge_index) for _ in range(3)]
+        if accel is not None:
+            accel.disable()          # the package's own loop below never goes through the re-pointed torch modules; make that certain
+        want = [PM.train_step(mine, data.x, data.adj_t, data.y, train_idx, mopt, mode, hp, tf, tl, msp, mtp, edge_index, kd_and_aux=script == "kd_and_aux")
+                for _ in range(3)]
+        if accel is not None:
+            accel.enable()
         # step 1: same weights, same draw -> the kernels' rounding only.  Steps 2-3 are a trajectory: Adam's g / sqrt(v) turns rounding
         # differences of small gradients into O(lr) weight differences, and GSP at beta = 100 multiplies what the loss sees of them
         # (the two sides differ in association order only: fused heads / SAGE's output layer aggregating lin_l(x))
@@ -129,7 +159,12 @@ def test_reference_train_loop_runs_unchanged_on_the_new_operators(gnn, mode):
         assert all(np.isfinite(v) for step in got for v in step)
         out, accs = ref.test(model, data, split_idx, _Evaluator())
         assert out.shape == (d.num_nodes, d.num_classes) and all(0 <= a <= 1 for a in accs)
+        if accel_mode == "lazy":     # the deferred form is what ran: out_feat of the script's model is the deferred object, formed by now
+            from efficient_gnns_amd.lazy import LazyBnAct
+            assert isinstance(model.out_feat, LazyBnAct) and model.out_feat._value is not None
     finally:
+        if accel is not None:
+            accel.disable()
         if DROPIN in sys.path:
             sys.path.remove(DROPIN)
         for stale in _SHIMMED + ("ref_gnn_dropin",):

@@ -1497,6 +1497,40 @@ def test_linear_rows_fused_gather_gemm_vs_torch(n, C, P, m, padded):
 
 
 @pytest.mark.gpu
+def test_constant_operand_planes_are_an_explicit_opt_in():
+    """``linear_rows`` builds the 6-bytes-per-element plane image of ``x[idx]`` only when the caller SAYS the input
+    is constant (``const_input=True``: the teacher head).  A large activation under ``no_grad`` (requires_grad False as well) or with
+    autograd off must leave both plane caches untouched; with the flag the two routes agree and the image is reused."""
+    g = torch.Generator().manual_seed(11)
+    n, C, P, m = 20000, 264, 128, 16640
+    x = torch.randn(n, C, generator=g).to(DEV)
+    w = (torch.randn(P, C, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    b = torch.randn(P, generator=g).to(DEV).requires_grad_(True)
+    idx = torch.randperm(n, generator=g)[:m].to(DEV)
+    before = (len(ops._CONST_PLANES), len(ops._CONST_ROW_PLANES))
+    with torch.no_grad():
+        y0 = ops.linear_rows(x, idx, w, b)
+    y1 = ops.linear_rows(x, idx, w, b)
+    y1.sum().backward()
+    gw1 = w.grad.clone()
+    assert (len(ops._CONST_PLANES), len(ops._CONST_ROW_PLANES)) == before, "no plane image without the flag"
+    w.grad = None
+    y2 = ops.linear_rows(x, idx, w, b, const_input=True)
+    y2.sum().backward()
+    assert len(ops._CONST_ROW_PLANES) == before[1] + 1
+    close(y2, y1, rtol=1e-5, atol_scale=1e-6)
+    close(w.grad, gw1, rtol=1e-5, atol_scale=1e-6)
+    assert torch.equal(y0, y1)
+    n_now = (len(ops._CONST_PLANES), len(ops._CONST_ROW_PLANES))
+    ops.linear_rows(x, idx, w, b, const_input=True)
+    assert (len(ops._CONST_PLANES), len(ops._CONST_ROW_PLANES)) == n_now, "image reused"
+    # a tensor that takes part in autograd is never treated as constant, whatever the flag says
+    xr = x.clone().requires_grad_(True)
+    ops.linear_rows(xr, idx, w, b, const_input=True).sum().backward()
+    assert (len(ops._CONST_PLANES), len(ops._CONST_ROW_PLANES)) == n_now and xr.grad is not None
+
+
+@pytest.mark.gpu
 def test_native_graph_construction_edge_cases_bit_exact():
     """egnn_csr_from_coo_i64 / egnn_csr_transpose_i64 against the oracle: duplicates kept (ToSparseTensor) or merged
     (to_symmetric), self loops, isolated nodes, a single edge, an empty edge list, a rectangular transpose with values."""
@@ -1911,6 +1945,43 @@ def test_graphed_epoch_draws_fresh_dropout_masks_and_samples():
         ge.step()
         picks.append(ge._pick_dev.clone())
     assert not torch.equal(picks[0], picks[1]) and not torch.equal(picks[1], picks[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_eval", [True, False])
+def test_graphed_epoch_step_async_hands_out_the_same_values_one_call_later(with_eval):
+    """``GraphedEpoch.step_async`` (replay k is launched before the values of epoch k - 1 are read: no idle GPU between epochs) is the
+    same program as ``step``: same replays, same host draws in the same order, dropout 0.5 -- every loss and accuracy BIT-equal, handed
+    out one call later; ``drain`` delivers the last epoch; ``step`` refuses to run while an epoch's values are in flight."""
+    d = D.arxiv_like(scale=0.02, seed=8)
+    dev = torch.device(DEV)
+    x, adj, y = d.x.to(dev), d.adj_t.to(dev), d.y.to(dev)
+    split = {k: v.to(dev) for k, v in d.split_idx.items()}
+    tf, tl = ops.pad_pitch(d.teacher_out_feat.to(dev)), d.teacher_logits.to(dev)
+    hp = dict(alpha=0.9, kd_T=4.0, beta=0.1, nce_T=0.075, max_samples=256, kernel="cosine", proj_dim=32)
+
+    def run(async_):
+        torch.manual_seed(0)
+        np.random.seed(3)
+        m = PM.GCN(d.num_features, 64, d.num_classes, 3, 0.5).to(dev)
+        sp, tp = PM.make_projection(64, 32).to(dev), PM.make_projection(750, 32).to(dev)
+        opt = torch.optim.Adam([{"params": list(m.parameters()) + list(sp.parameters()) + list(tp.parameters())}], lr=0.01, fused=True, capturable=True)
+        ge = PM.GraphedEpoch(m, x, adj, y, split["train"], opt, "nce", hp, tf, tl, sp, tp, split_idx=split if with_eval else None, warmup=2)
+        vals = []
+        if not async_:
+            return [ge.step() for _ in range(6)]
+        assert ge.step_async() is None
+        for _ in range(5):
+            vals.append(ge.step_async())
+        with pytest.raises(RuntimeError, match="drain"):
+            ge.step()
+        vals.append(ge.drain())
+        assert ge.drain() is None
+        vals.append(ge.step())          # and the synchronous form continues the same trajectory
+        return vals
+    ref, got = run(False), run(True)
+    assert got[:6] == ref, (got, ref)
+    assert np.isfinite(np.array([v[0] for v in got])).all() and len({v[0] for v in got}) == 7
 
 
 @pytest.mark.gpu

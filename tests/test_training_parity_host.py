@@ -165,3 +165,32 @@ def test_dropin_accel_keeps_torch_paths_for_cpu_inputs_and_restores():
         accel.disable()
     assert torch.nn.BatchNorm1d.forward is bn0 and torch.nn.Linear.forward is lin0 and not accel.enabled()
     assert torch.allclose(got, want, atol=1e-6)
+
+
+def test_deferred_activation_protocol_on_host():
+    """efficient_gnns_amd/lazy.py without a GPU: which torch calls a deferred BatchNorm activation ABSORBS (F.relu, then F.dropout in
+    training; the nn.ReLU module; F.dropout outside training is the identity) and that everything else would materialise (here: raise,
+    there is no kernel on the CPU -- which is the point: nothing is skipped silently)."""
+    import torch.nn.functional as F
+    from efficient_gnns_amd import _lib
+    from efficient_gnns_amd.lazy import LazyBnAct, LazyRows, materialise
+    bn = torch.nn.BatchNorm1d(8)
+    src = dict(x=torch.randn(16, 8), bn=bn, mean=torch.zeros(8), var=torch.ones(8), use_batch=True, training=True)
+    a = LazyBnAct(src)
+    assert tuple(a.shape) == (16, 8) and a.dim() == 2 and a.size(0) == 16 and len(a) == 16 and a.dtype == torch.float32
+    r = F.relu(a)
+    assert isinstance(r, LazyBnAct) and r._relu and r._p == 0.0 and r is not a and not a._relu
+    assert torch.nn.ReLU()(a)._relu
+    assert F.relu(r) is r
+    d = F.dropout(r, p=0.5, training=True)
+    assert isinstance(d, LazyBnAct) and d._relu and d._p == 0.5
+    assert F.dropout(r, p=0.5, training=False) is r and F.dropout(r, p=0.0, training=True) is r
+    for other in (lambda: torch.sigmoid(d), lambda: d + 1.0, lambda: d[torch.arange(4)], lambda: d.sum(), lambda: materialise(d)):
+        with pytest.raises(RuntimeError):       # forming the tensor needs the kernels: no GPU here
+            other()
+    assert d._value is None
+    plain = torch.randn(5, 3)
+    assert materialise(plain) is plain and torch.equal(materialise(plain, torch.tensor([2, 0])), plain[[2, 0]])
+    lr = LazyRows(plain, torch.tensor([4, 1, 3]))      # rows of a real tensor: a plain gather (torch indexing is plumbing, not a kernel)
+    assert tuple(lr.shape) == (3, 3) and lr._value is None
+    assert torch.equal(materialise(lr), plain[[4, 1, 3]]) and torch.equal(materialise(lr, torch.tensor([2])), plain[[3]])
