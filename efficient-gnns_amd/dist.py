@@ -652,7 +652,8 @@ class SyncBatchNorm1d(nn.Module):
         """dropout(relu(self(x)), p) -- on the GPU through the fused BN + ReLU + dropout kernels (ops.sync_bn_act /
         ops.bn_act), elsewhere (gloo tests) through the torch operators above.  ``pick`` (unique row ids): only those rows of the
         result are formed; the statistics still span every row of every rank."""
-        if not (_lib.on_gpu(x) and ops.bn_shape_ok(x)):
+        _lib.require_gpu(x)
+        if not ops.bn_shape_ok(x):       # a width the fused kernels do not take (C % 4 != 0, C > 1024): the torch operators above
             y = self(x)
             y = torch.relu(y) if relu else y
             y = torch.nn.functional.dropout(y, p, training) if p > 0 else y
@@ -667,7 +668,8 @@ class SyncBatchNorm1d(nn.Module):
     def fused_act_linear(self, x: Tensor, w: Tensor, relu: bool, p: float, training: bool):
         """(h, h @ w) for h = dropout(relu(self(x)), p) and a narrow ``w`` (the output conv's weight): the students' last hidden layer
         in one forward pass and a two-half backward around ONE all-reduce (ops.sync_bn_act_linear).  None when not taken."""
-        if not (training and _lib.on_gpu(x)):
+        _lib.require_gpu(x)
+        if not (training and ops.bn_shape_ok(x)):
             return None
         both = ops.sync_bn_act_linear(x, self, w, relu, p, training, self.group)
         if both is None:
@@ -1139,7 +1141,7 @@ def sharded_train_step_tensors(model, prob: ShardedProblem, optimizer, mode: str
         if p is not None:
             p.train()
     group = prob.group
-    take = ops.take_rows if _lib.on_gpu(prob.x) else (lambda t, i: t[i])   # train ids are unique: gather / scatter without a sort
+    take = ops.take_rows   # train ids are unique: gather / scatter without a sort
     logits = model(prob.x, prob.adj)
     rows, n_tr = prob.train_local, int(prob.train_local.numel())
     labels = prob.y.view(-1)
@@ -1157,7 +1159,7 @@ def sharded_train_step_tensors(model, prob: ShardedProblem, optimizer, mode: str
     def heads(pick):
         """(student rows, teacher rows) of the projection heads: all local train rows enter the Linear and the (all-rank) BatchNorm
         statistics; with ``pick`` only those output rows are normalised and stored (ops.sync_bn_act(..., pick=))."""
-        if hasattr(student_proj, "forward_rows") and prob.x.is_cuda:
+        if hasattr(student_proj, "forward_rows"):
             return (student_proj.forward_rows(model.out_feat, rows, pick=pick), teacher_proj.forward_rows(prob.teacher_out_feat, rows, pick=pick, const_input=True))
         f, t = student_proj(take(model.out_feat, rows)), teacher_proj(take(prob.teacher_out_feat, rows))
         return (f, t) if pick is None else (f[pick], t[pick])
@@ -1239,12 +1241,8 @@ def sharded_evaluate_tensors(model, prob: ShardedProblem):
     """``test()`` on shards without the host read: (local logits, device tensor of the three GLOBAL hit counts)."""
     model.eval()
     out = model(prob.x, prob.adj)
-    if _lib.on_gpu(out):
-        # argmax + the three hit counts in one pass of this package's kernel (no long torch reduction inside the captured epoch, _audit.py)
-        correct = ops.split_accuracy(out, prob.y, prob.split_local, counts=True)[:3].to(torch.float32)
-    else:
-        y_pred = out.argmax(dim=-1, keepdim=True)
-        correct = torch.stack([(prob.y[prob.split_local[k]] == y_pred[prob.split_local[k]]).sum() for k in ("train", "valid", "test")]).float()
+    # argmax + the three hit counts in one pass of this package's kernel (no long torch reduction inside the captured epoch, _audit.py)
+    correct = ops.split_accuracy(out, prob.y, prob.split_local, counts=True)[:3].to(torch.float32)
     dist.all_reduce(correct, group=prob.group)
     return out, correct
 

@@ -92,8 +92,8 @@ class _Student(nn.Module):
                 x = ops.bn_act(x, bn, relu=True, p=self.dropout, training=self.training)
             elif act == "sync":
                 x = bn.fused_act(x, True, self.dropout, self.training)
-            else:
-                _lib.on_gpu(x)         # raises for a CPU tensor outside the tests' stand-in switch
+            else:                      # another norm module: torch's own operators (on the GPU)
+                _lib.require_gpu(x)
                 x = F.dropout(F.relu(bn(x)), p=self.dropout, training=self.training)
             self.out_feat = x
         if self.training and x.is_cuda:
@@ -135,9 +135,10 @@ class ProjectionHead(nn.Sequential):
 
     def forward(self, x):
         lin, bn = self[0], self[1]
-        if x.is_cuda and hasattr(bn, "fused_act"):              # dist.SyncBatchNorm1d
+        if hasattr(bn, "fused_act"):                            # dist.SyncBatchNorm1d
             return bn.fused_act(ops.linear(x, lin.weight, lin.bias), True, 0.0, self.training)
-        if not _lib.on_gpu(x) or not isinstance(bn, nn.BatchNorm1d):
+        _lib.require_gpu(x)
+        if not isinstance(bn, nn.BatchNorm1d):
             return super().forward(x)
         return ops.bn_act(ops.linear(x, lin.weight, lin.bias), bn, relu=True, p=0.0, training=self.training)
 
@@ -146,9 +147,6 @@ class ProjectionHead(nn.Sequential):
         ``pick`` (unique ids into ``idx``): ``self(x[idx])[pick]`` -- what a sampled criterion keeps of the head's output
         (criterion.py:62-65,134-137); the BatchNorm statistics span all of ``idx``, only the picked rows are normalised and stored."""
         lin, bn = self[0], self[1]
-        if not _lib.on_gpu(x):
-            y = self(x[idx])
-            return y if pick is None else y[pick]
         y = ops.linear_rows(x, idx, lin.weight, lin.bias, const_input=const_input)   # const_input: see ops.linear_rows (the teacher head)
         if hasattr(bn, "fused_act"):                            # dist.SyncBatchNorm1d: all-rank statistics, only the picked rows formed
             return bn.fused_act(y, True, 0.0, self.training, pick=pick)
@@ -197,7 +195,7 @@ def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_
     if mode in ("fitnet", "gpw", "nce"):
         if hasattr(student_proj, "forward_rows") and hasattr(teacher_proj, "forward_rows") and not _CACHE_CONST_ROWS:
             pick = None
-            if mode in ("gpw", "nce") and _SAMPLED_HEADS and _lib.on_gpu(model.out_feat):
+            if mode in ("gpw", "nce") and _SAMPLED_HEADS:
                 # the criterion's one host draw (criterion.py:62-65,134-137), made here: the heads then form only the sampled rows
                 pick = C._sample_rows(train_idx.numel(), hp["max_samples"], model.out_feat.device)
                 picked = pick is not None
@@ -206,7 +204,7 @@ def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_
         else:
             f = student_proj(ops.take_rows(model.out_feat, train_idx))
             t = teacher_proj(_const_rows(teacher_out_feat, train_idx))
-    elif mode == "lpw" and _LSP_FULL_ROWS and edge_index is not None and _lib.on_gpu(model.out_feat):
+    elif mode == "lpw" and _LSP_FULL_ROWS and edge_index is not None:
         # LSP reads rows only through the edge list (criterion.py:100-104): the train-subgraph ids of gnn.py:274 are composed with
         # train_idx once, and the edge kernels then address the FULL feature tensors -- feat[train_idx] / teacher_feat[train_idx] (366 MB of
         # copies per step) and the zero-fill + scatter of their backward never exist; the loss is a mean over the same edges.
@@ -235,10 +233,24 @@ def distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_
     return loss + hp["beta"] * loss_aux, loss_cls, loss_aux
 
 
+_ONES: dict = {}
+
+
+def _one_like(t):
+    """A cached 0-dim 1.0 on ``t``'s device: ``loss.backward(gradient=...)`` without autograd's per-step ones_like fill launch.  Never
+    evicted (4 bytes per device; captured graphs read it through a raw pointer)."""
+    key = (str(t.device), t.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones((), dtype=t.dtype, device=t.device)
+    return one
+
+
 def train_step_tensors(model, x, adj_t, y, train_idx, optimizer, mode, hp, teacher_out_feat=None, teacher_logits=None,
-                       student_proj=None, teacher_proj=None, edge_index=None, kd_and_aux=False):
+                       student_proj=None, teacher_proj=None, edge_index=None, kd_and_aux=False, out=None):
     """One full-graph optimisation step (gnn.py:102-195) WITHOUT the host reads: returns the device tensor
-    [loss, loss_cls, loss_aux].  (``train_step`` adds the reads; ``GraphedEpoch`` captures this function.)"""
+    [loss, loss_cls, loss_aux] (written into ``out`` -- float32 [3] -- when given).  (``train_step`` adds the reads; ``GraphedEpoch``
+    captures this function.)"""
     model.train()
     for p in (student_proj, teacher_proj):
         if p is not None:
@@ -255,9 +267,9 @@ def train_step_tensors(model, x, adj_t, y, train_idx, optimizer, mode, hp, teach
         loss, loss_cls, loss_aux = distill_loss(mode, model, out, labels, train_idx, teacher_out_feat, teacher_logits, hp,
                                                 student_proj, teacher_proj, edge_index, adj_t, kd_and_aux)
     optimizer.zero_grad()
-    loss.backward()
+    loss.backward(gradient=_one_like(loss) if loss.is_cuda and loss.dim() == 0 else None)
     optimizer.step()
-    return torch.stack([loss.detach(), loss_cls.detach(), loss_aux.detach()])
+    return torch.stack([loss.detach(), loss_cls.detach(), loss_aux.detach()], out=out)
 
 
 def train_step(model, x, adj_t, y, train_idx, optimizer, mode, hp, teacher_out_feat=None, teacher_logits=None,
@@ -276,12 +288,13 @@ def accuracy(y_true, y_pred) -> float:
 
 
 @torch.no_grad()
-def evaluate_tensors(model, x, adj_t, y, split_idx):
-    """``test()`` (gnn.py:198-218) without the host read: (logits, device tensor of the three accuracies)."""
+def evaluate_tensors(model, x, adj_t, y, split_idx, accs_out=None):
+    """``test()`` (gnn.py:198-218) without the host read: (logits, device tensor of the three accuracies -- ``accs_out``, float64 [3],
+    when given)."""
     model.eval()
     out = model(x, adj_t)
-    if out.is_cuda and y.dtype == torch.int64 and y.numel() == out.shape[0]:
-        return out, ops.split_accuracy(out, y, split_idx)   # argmax + the three Evaluator accuracies in one pass
+    if y.dtype == torch.int64 and y.numel() == out.shape[0]:
+        return out, ops.split_accuracy(out, y, split_idx, out=accs_out)   # argmax + the three Evaluator accuracies in one pass
     y_pred = out.argmax(dim=-1, keepdim=True)
     hit = (y_pred == y).view(-1).to(torch.float32)
     return out, torch.stack([hit[split_idx[k]].mean() for k in ("train", "valid", "test")])
@@ -289,14 +302,9 @@ def evaluate_tensors(model, x, adj_t, y, split_idx):
 
 @torch.no_grad()
 def evaluate(model, x, adj_t, y, split_idx):
-    if _lib.on_gpu(x):   # the three Evaluator accuracies with ONE device->host read instead of three
-        out, accs = evaluate_tensors(model, x, adj_t, y, split_idx)
-        return out, tuple(accs.tolist())
-    model.eval()
-    out = model(x, adj_t)
-    y_pred = out.argmax(dim=-1, keepdim=True)
-    accs = tuple(accuracy(y[split_idx[k]], y_pred[split_idx[k]]) for k in ("train", "valid", "test"))
-    return out, accs
+    _lib.require_gpu(x)
+    out, accs = evaluate_tensors(model, x, adj_t, y, split_idx)   # the three Evaluator accuracies with ONE device->host read instead of three
+    return out, tuple(accs.tolist())
 
 
 class GraphedEpoch:
@@ -326,11 +334,16 @@ class GraphedEpoch:
         args = (model, x, adj_t, y, train_idx, optimizer, mode, hp, teacher_out_feat, teacher_logits, student_proj, teacher_proj,
                 edge_index, kd_and_aux)
 
+        # the epoch's six scalars side by side in ONE 40-byte device buffer (three float32 losses at byte 0, three float64 accuracies at
+        # byte 16), written by the kernels that produce them: one device->host copy per epoch, no gather launch
+        self._res_bytes = torch.zeros(40, dtype=torch.uint8, device=dev)
+        res_losses, res_accs = self._res_bytes[:12].view(torch.float32), self._res_bytes[16:].view(torch.float64)
+
         def body():
-            losses = train_step_tensors(*args)
+            losses = train_step_tensors(*args, out=res_losses)
             if split_idx is None:
                 return losses, None, None
-            out, accs = evaluate_tensors(model, x, adj_t, y, split_idx)
+            out, accs = evaluate_tensors(model, x, adj_t, y, split_idx, accs_out=res_accs)
             return losses, out, accs
         self._body = body
         # every cached structure the captured launches read through raw pointers (edge plans, composed edge lists, inverse row maps,
@@ -372,15 +385,6 @@ class GraphedEpoch:
             torch.cuda.synchronize(dev)
             with torch.cuda.graph(self.graph):
                 self.losses, self.out, self.accs = body()
-                # the epoch's scalars side by side: ONE device->host read per epoch (a kernel node of the graph, not a launch per step)
-                # (element-wise kernels, not torch.cat: a cat of contiguous pieces is captured as a memcpy node, which the structural
-                #  guard refuses; float64: the accuracies are doubles)
-                if self.accs is None:
-                    self.result = self.losses
-                else:
-                    self.result = torch.empty(3 + self.accs.numel(), dtype=torch.float64, device=dev)
-                    torch.add(self.losses, 0.0, out=self.result[:3])
-                    torch.add(self.accs, 0.0, out=self.result[3:])
         self.node_kinds = check_captured_graph(self.graph, "GraphedEpoch", kernels_only=True)
         self.graph.instantiate()
         torch.cuda.synchronize(dev)
@@ -446,17 +450,20 @@ class GraphedEpoch:
     # replays, same draws in the same order, every epoch's values still read by the host -- one call later.
     def _slots(self):
         if getattr(self, "_res_host", None) is None:
-            self._res_host = [torch.zeros(self.result.numel(), dtype=self.result.dtype).pin_memory() for _ in range(2)]
+            self._res_host = [torch.zeros(40, dtype=torch.uint8).pin_memory() for _ in range(2)]
             self._res_done = [None, None]
             self._pending = None          # slot of the epoch whose values have not been handed out yet
             self._k = 0
             self.replay_events = None     # set to a list to collect (start, end) HIP events around every replay (bench.py)
         return self._res_host
 
+    def _decode(self, host_bytes):
+        losses = tuple(host_bytes[:12].view(torch.float32).tolist())
+        return (losses, None) if self.accs is None else (losses, tuple(host_bytes[16:].view(torch.float64).tolist()))
+
     def _values(self, slot):
         self._res_done[slot].synchronize()
-        vals = self._res_host[slot].tolist()
-        return (tuple(vals[:3]), None) if self.accs is None else (tuple(vals[:3]), tuple(vals[3:]))
+        return self._decode(self._res_host[slot])
 
     def step_async(self):
         """Launch one epoch and return the values of the PREVIOUS ``step_async`` epoch (None on the first call): the randomness of this
@@ -472,7 +479,7 @@ class GraphedEpoch:
         if self.replay_events is not None:
             e1.record()
             self.replay_events.append((e0, e1))
-        self._res_host[slot].copy_(self.result, non_blocking=True)
+        self._res_host[slot].copy_(self._res_bytes, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
         self._res_done[slot] = done
@@ -493,9 +500,9 @@ class GraphedEpoch:
             raise RuntimeError("GraphedEpoch.step() after step_async(): call drain() first (an epoch's values are still in flight)")
         self.graph.replay()
         self._draw()                                            # overlapped with the replay; uploaded after the read below
-        vals = self.result.tolist()                             # one device->host read per epoch
+        vals = self._decode(self._res_bytes.cpu())              # one device->host read per epoch
         self._upload()
-        return (tuple(vals[:3]), None) if self.accs is None else (tuple(vals[:3]), tuple(vals[3:]))
+        return vals
 
 
 class GAT(nn.Module):

@@ -258,8 +258,8 @@ def colsum(g: Tensor) -> Tensor:
     tag = getattr(g, "_egnn_colsum", None)
     if tag is not None and tag[1] == g._version and tag[0].shape[0] == g.shape[1]:
         return tag[0]
-    if not g.is_cuda or g.dim() != 2 or g.dtype != torch.float32 or g.shape[0] == 0:
-        _lib.on_gpu(g)
+    _lib.require_gpu(g)
+    if g.dim() != 2 or g.dtype != torch.float32 or g.shape[0] == 0:
         return g.sum(0)
     # egnn_colsum_f32, not ``g.sum(0)``: torch's multi-block reduction zeroes its semaphores with a memset node, and inside replayed
     # hipGraphs on this stack such reductions were seen to leave their output unwritten (ops_edge._LspLoss)
@@ -288,9 +288,7 @@ class _AddBias(torch.autograd.Function):
 def add_bias(x: Tensor, bias: Tensor | None) -> Tensor:
     if bias is None:
         return x
-    if not x.is_cuda:
-        _lib.on_gpu(x)
-        return x + bias
+    _lib.require_gpu(x)
     return _AddBias.apply(x, bias)
 
 
@@ -555,8 +553,8 @@ class _LinearAdd(torch.autograd.Function):
 
 def linear_add(x: Tensor, weight: Tensor, bias: Tensor | None, addend: Tensor) -> Tensor:
     """F.linear(x, weight, bias) + addend, one store."""
-    if not x.is_cuda or x.shape[0] == 0:
-        _lib.on_gpu(x)
+    _lib.require_gpu(x)
+    if x.shape[0] == 0:
         return torch.nn.functional.linear(x, weight, bias) + addend
     return _LinearAdd.apply(x, weight, bias, addend)
 
@@ -624,7 +622,7 @@ def split_ids(split_idx: dict, n: int, device) -> Tensor:
     return _SPLIT_IDS.get(tuple(split_idx[k] for k in names), (n, str(device)), build)
 
 
-def split_accuracy(logits: Tensor, y: Tensor, split_idx: dict, counts: bool = False) -> Tensor:
+def split_accuracy(logits: Tensor, y: Tensor, split_idx: dict, counts: bool = False, out: Tensor | None = None) -> Tensor:
     """float64 [3]: the Evaluator accuracies of test() (gnn.py:198-218) for train / valid / test in one pass over the
     logits (egnn_split_accuracy_f32: first-max argmax, integer hit counts over split sizes).
     ``counts``: float64 [6] = (hits of the three splits, sizes of the three splits) instead of the ratios (a shard's contribution
@@ -642,7 +640,9 @@ def split_accuracy(logits: Tensor, y: Tensor, split_idx: dict, counts: bool = Fa
     lib = _lib.load()
     nws = lib.egnn_split_accuracy_ws_ints()
     ws = torch.empty(nws, dtype=torch.int32, device=logits.device)
-    acc = torch.empty(6 if counts else 3, dtype=torch.float64, device=logits.device)
+    acc = out if out is not None else torch.empty(6 if counts else 3, dtype=torch.float64, device=logits.device)
+    if acc.dtype != torch.float64 or acc.numel() != (6 if counts else 3) or not acc.is_contiguous() or acc.device != logits.device:
+        raise TypeError("split_accuracy: `out` must be a contiguous float64 tensor of 3 (6 with counts) elements on the logits' device")
     fn, name = (lib.egnn_split_counts_f32, "egnn_split_counts_f32") if counts else (lib.egnn_split_accuracy_f32, "egnn_split_accuracy_f32")
     _lib.check(fn(_lib.ptr(logits), logits.stride(0), n, C, _lib.ptr(yv), _lib.ptr(sid), _lib.ptr(acc), _lib.ptr(ws), nws, _lib.stream()), name)
     return acc
@@ -770,8 +770,7 @@ def linear_rows(x: Tensor, idx: Tensor, weight: Tensor, bias: Tensor | None = No
     ONCE per (x, idx) identity + version as tile-packed bf16 planes (6 bytes per element, held by a byte-bounded cache) and the forward /
     weight-gradient products run on the planes x planes forms.  Without the flag no plane image is ever built: activations under
     ``no_grad`` (requires_grad False as well) or RGCN's per-node-type calls take the gather-fused GEMM."""
-    if not _lib.on_gpu(x):
-        return torch.nn.functional.linear(take_rows(x, idx), weight, bias)
+    _lib.require_gpu(x)
     return _LinearRows.apply(x, idx, weight, bias, getattr(x, "_egnn_tap", None) if torch.is_grad_enabled() else None, const_input)
 
 
@@ -1036,6 +1035,19 @@ def _draw_dropout_seed() -> int:
     return int(torch.empty((), dtype=torch.int64).random_()) & 0x7FFFFFFFFFFFFFFF
 
 
+_DEPHASE = int(os.environ.get("EGNN_DEPHASE_BYTES", "0"))     # lab switch (tools/r06): output tensors of the streaming BatchNorm kernels start
+_DEPHASE_N = [0]                                               # this many bytes x (1..7) past their allocation's 2 MiB-aligned base
+
+
+def _empty_rows(n: int, C: int, device) -> Tensor:
+    """float32 [n, C] row-major; with the lab switch the tensor sits at a rotating offset inside a slightly larger allocation."""
+    if _DEPHASE <= 0:
+        return torch.empty(n, C, dtype=torch.float32, device=device)
+    _DEPHASE_N[0] = _DEPHASE_N[0] % 7 + 1
+    off = _DEPHASE_N[0] * _DEPHASE // 4
+    return torch.empty(n * C + 8 * _DEPHASE // 4, dtype=torch.float32, device=device)[off:off + n * C].view(n, C)
+
+
 def _bn_shape_ok(x: Tensor) -> bool:
     C = x.shape[1]
     return x.is_cuda and C % 4 == 0 and C <= 1024 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
@@ -1051,7 +1063,7 @@ class _BnAct(torch.autograd.Function):
         n, C = x.shape
         seed_dev = _DROPOUT_SEED_DEV if p > 0 else None
         if pick is None:
-            y = torch.empty(n, C, dtype=torch.float32, device=x.device)
+            y = _empty_rows(n, C, x.device)
             rc = _lib.load().egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
                                                  _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(seed_dev), _lib.ptr(y), y.stride(0),
                                                  _lib.stream())
@@ -1077,7 +1089,7 @@ class _BnAct(torch.autograd.Function):
         gy = _rowmajor(gy)
         n, C = x.shape
         lib, dev = _lib.load(), x.device
-        dx = torch.empty_like(x)
+        dx = _empty_rows(n, C, dev)
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         nws = lib.egnn_bn_ws_floats(C)
@@ -1180,7 +1192,7 @@ class _BnActLinear(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, mean, var, eps, relu, p, seed, batch_stats, w, box):
         x = _rowmajor(x)
         n, C = x.shape
-        h = torch.empty(n, C, dtype=torch.float32, device=x.device)
+        h = _empty_rows(n, C, x.device)
         seed_dev = _DROPOUT_SEED_DEV if p > 0 else None
         w = _rowmajor(w)
         lib = _lib.load()
@@ -1232,7 +1244,7 @@ def _tail_backward(ctx, g_h, g_xw, x, gamma, beta, mean, var, h, w, eps, relu, p
             gw = gemm_raw(h, g_xw, True, False) if n > 0 else torch.zeros_like(w)     # dW = h^T G
     if not ctx.needs_input_grad[0]:
         return None, None, None, gw
-    dx = torch.empty_like(x)
+    dx = _empty_rows(x.shape[0], x.shape[1], x.device)
     sums = torch.empty(2 * C, dtype=torch.float32, device=dev)       # [dbeta | dgamma]; written by the reduce half (zeroed on an empty shard)
     if n == 0:
         sums.zero_()
