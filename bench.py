@@ -85,6 +85,10 @@ def parse():
                     help="sharded runs: auto = cut the node ranges from the community order when that lowers the halo; range = node ids as given")
     ap.add_argument("--graph-kind", default="chunglu", choices=["chunglu", "local", "local-sorted"],
                     help="synthetic graph of the sharded runs: chunglu (headline: no locality) | local (community structure, ids shuffled)")
+    ap.add_argument("--agg", default="auto", choices=["auto", "halo", "sliced"],
+                    help="sharded runs: how an aggregation gets its remote operand rows -- halo (the referenced rows travel), sliced (the feature "
+                         "columns are re-sharded around the aggregation: bytes independent of the halo), auto (per adjacency and width, whichever "
+                         "moves fewer bytes; dist.ShardedAdj.sliced_pays)")
     ap.add_argument("--one-device", action="store_true",
                     help="all ranks of a multi-rank launch share cuda:0 and their collectives travel over gloo through host memory "
                          "(efficient-gnns_amd/hostcomm.py): a FUNCTIONAL run of the sharded step on the real kernels with a non-empty halo "
@@ -877,6 +881,7 @@ def main():
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
         import efficient_gnns_amd.dist as dist_mod
+        dist_mod._AGG_MODE = args.agg
         if args.one_device:
             from efficient_gnns_amd import hostcomm
             hostcomm.install()

@@ -64,7 +64,8 @@ class CommTrace:
                     for v in inp.shape[1:]:
                         width *= int(v)
                     rec.append((name, self._bytes(inp), self._bytes(out), width,
-                                None if isz is None else tuple(int(v) for v in isz), None if osz is None else tuple(int(v) for v in osz)))
+                                None if isz is None else tuple(int(v) for v in isz), None if osz is None else tuple(int(v) for v in osz),
+                                _A2A_KIND[0], inp.element_size()))
                 elif name == "all_gather_into_tensor":
                     rec.append((name, self._bytes(a[1]), self._bytes(a[0]), a[1].numel()))
                 elif name == "barrier":
@@ -87,12 +88,19 @@ class CommTrace:
     def summary(self) -> dict:
         """Bytes this rank put on / took off the wire, by kind (an all_reduce counted as 2 (w-1)/w of its payload each way is the
         RING volume; here the plain payload is reported and the ring factor left to the reader)."""
-        a2a_out = sum(r[1] for r in self.records if r[0] == "all_to_all_single")
-        a2a_in = sum(r[2] for r in self.records if r[0] == "all_to_all_single")
+        halo = [r for r in self.records if r[0] == "all_to_all_single" and r[6] != "sliced"]
+        a2a_out, a2a_in = sum(r[1] for r in halo), sum(r[2] for r in halo)
         red = sum(r[1] for r in self.records if r[0] == "all_reduce")
         gat = sum(r[2] for r in self.records if r[0].startswith("all_gather"))
         out = dict(collectives=len(self.records), halo_all_to_all_bytes_sent=a2a_out, halo_all_to_all_bytes_received=a2a_in,
                    all_reduce_payload_bytes=red, all_gather_bytes_received=gat)
+        sliced = [r for r in self.records if r[0] == "all_to_all_single" and r[6] == "sliced"]
+        if sliced:
+            # column-sliced aggregations (_SlicedAggregate): what leaves this rank = the payload minus the block it keeps for itself
+            me = dist.get_rank() if dist.is_initialized() else 0
+            wire = lambda r, sizes: (sum(sizes) - sizes[me]) * r[3] * r[7]   # noqa: E731
+            out.update(sliced_exchanges=len(sliced), sliced_all_to_all_bytes_sent=sum(wire(r, r[4]) for r in sliced),
+                       sliced_all_to_all_bytes_received=sum(wire(r, r[5]) for r in sliced))
         if self.overlap:
             win = sum(e0.elapsed_time(e1) for e0, e1, _ in self.overlap) * 1e3
             exp = sum(e1.elapsed_time(e2) for _, e1, e2 in self.overlap) * 1e3
@@ -140,6 +148,13 @@ def node_range(n: int, world: int, rank: int):
 
 
 _OVERLAP = os.environ.get("EGNN_DIST_OVERLAP", "1") != "0"
+# How a sharded aggregation gets its remote operand rows (ShardedAdj.aggregate):
+#   halo    the rows a shard's entries reference travel to it (one all_to_all of [halo rows, K] per aggregation): bytes grow with the halo
+#   sliced  the feature COLUMNS are re-sharded around the aggregation (all_to_all to [N, K / world] column slices, aggregation of all N
+#           rows on the full adjacency, all_to_all back): 2 N K 4 (world - 1) / world^2 bytes per rank, whatever the graph looks like
+#   auto    sliced where it moves fewer bytes than the halo (decided once per adjacency from the all-rank mean halo, same on every rank)
+_AGG_MODE = os.environ.get("EGNN_DIST_AGG", "auto")
+_A2A_KIND = ["halo"]      # what CommTrace files an all_to_all_single under (set around the sliced exchanges)
 
 
 def _agg(adj, x, addend=None, bias=None, relu=False):
@@ -388,6 +403,48 @@ class _OverlapAggregate(torch.autograd.Function):
         return g_x, None, None, None, None, g_b, None
 
 
+def _sliced_product(x_local, sadj, full, bias=None, relu=False):
+    """y_local = (full @ X)[own rows] for the row-sharded X whose local rows are ``x_local`` -- by re-sharding the COLUMNS around the
+    aggregation: every rank receives the column slice [N, K / world] of X that belongs to it (all_to_all), aggregates ALL N rows of that
+    slice on the full matrix ``full`` (the local kernels; ``bias`` / ``relu`` of its slice in the store), and the row blocks travel back
+    (all_to_all).  Payload per rank and direction: N K 4 (world - 1) / world^2 bytes, independent of the halo.  Plain function (no
+    autograd): the body of ``_SlicedAggregate`` forward and, on ``full.t()``, backward."""
+    plan, group = sadj.plan, sadj.group
+    G, n_local, K = plan.world, plan.n_local, x_local.shape[1]
+    Kg = K // G
+    rows = sadj.rows_per_rank
+    # [n_local, G, Kg] -> [G, n_local, Kg]: the block for peer p is contiguous
+    send = x_local.reshape(n_local, G, Kg).permute(1, 0, 2).contiguous().view(G * n_local, Kg)
+    xs = torch.empty(plan.n, Kg, dtype=x_local.dtype, device=x_local.device)
+    _A2A_KIND[0] = "sliced"
+    try:
+        dist.all_to_all_single(xs, send, rows, [n_local] * G, group=group)
+        b = None if bias is None else bias[plan.rank * Kg:(plan.rank + 1) * Kg].contiguous()
+        ys = _agg(full, xs, bias=b, relu=relu)                                 # all N rows of this rank's column slice
+        back = torch.empty(G * n_local, Kg, dtype=x_local.dtype, device=x_local.device)
+        dist.all_to_all_single(back, ys.contiguous(), [n_local] * G, rows, group=group)
+    finally:
+        _A2A_KIND[0] = "halo"
+    return back.view(G, n_local, Kg).permute(1, 0, 2).reshape(n_local, K)
+
+
+class _SlicedAggregate(torch.autograd.Function):
+    """``ShardedAdj.aggregate`` in column-sliced form (see ``_sliced_product``); the backward is the same exchange pattern on the
+    transposed full matrix."""
+
+    @staticmethod
+    def forward(ctx, x_local, sadj, full, bias=None, relu=False):
+        ctx.sadj, ctx.full, ctx.has_bias = sadj, full, bias is not None
+        return _sliced_product(x_local.contiguous(), sadj, full, bias, relu)
+
+    @staticmethod
+    def backward(ctx, g_y):
+        g_y = g_y.contiguous()
+        g_x = _sliced_product(g_y, ctx.sadj, ctx.full.t())
+        g_b = ops.colsum(g_y) if (ctx.has_bias and ctx.needs_input_grad[3]) else None
+        return g_x, None, None, g_b, None
+
+
 class _ShardedSageLayer(torch.autograd.Function):
     """``ops._SageLayer`` on a node-range shard: SAGEConv (``lin_l(aggr_j x_j) + lin_r(x_i)``, gnn.py:79-84) as ONE autograd node whose
     aggregation is the overlapped halo-exchange form above -- ``lin_r(x)`` is the addend of the GEMM / aggregation store, the input
@@ -474,6 +531,70 @@ class ShardedAdj:
         self.scatter = self.plan.scatter_adj(dev)
         self._pieces = {}
         self._static = None
+        self._full = {}
+        plan = self.plan
+        self.rows_per_rank = [node_range(plan.n, plan.world, r)[1] - node_range(plan.n, plan.world, r)[0] for r in range(plan.world)]
+        # the mode decision must be the same on every rank: the all-rank MEAN halo (one small all_reduce at construction)
+        self.mean_halo = float(plan.n_halo)
+        if plan.world > 1 and dist.is_available() and dist.is_initialized():
+            t = torch.tensor([float(plan.n_halo)], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, group=self.group)
+            self.mean_halo = float(t.item()) / plan.world
+        self.agg_mode = _AGG_MODE
+
+    def sliced_pays(self, K: int) -> bool:
+        """True when the column-sliced exchange moves fewer bytes than the halo exchange for a K-wide aggregation:
+        mean halo rows x K  >  2 N K (world - 1) / world^2 (there and back), and the slices are kernel-aligned (K % (4 world) == 0)."""
+        plan = self.plan
+        G = plan.world
+        if G < 2 or K % (4 * G):
+            return False
+        if self.agg_mode == "sliced":
+            return True
+        return self.agg_mode == "auto" and self.mean_halo * G * G > 2.0 * plan.n * (G - 1)
+
+    def full_adj(self, mean: bool, valueless: bool) -> SparseTensor:
+        """The FULL [N, N] aggregation matrix (every rank's rows, global column ids, the values the pieces of ``_split`` carry), built
+        once per kind by all-gathering the shards' CSR pieces -- what the column-sliced form aggregates on.  COLLECTIVE (padded
+        all_gather_into_tensor of row counts, columns and values); the first sliced aggregation of a kind triggers it on every rank
+        at the same program point because the mode decision is global."""
+        key = (mean, valueless)
+        if key in self._full:
+            return self._full[key]
+        plan, dev, G = self.plan, self.device, self.plan.world
+        rp = plan.rowptr_local.to(dev)
+        cnt = (rp[1:] - rp[:-1])
+        halo_ids = plan.halo_ids.to(dev)
+        ce = plan.col_ext.to(dev)
+        col_global = torch.where(plan.remote_mask.to(dev), halo_ids[(ce - plan.n_local).clamp(min=0)] if plan.n_halo else ce, ce + plan.lo)
+        val = None if valueless else (None if plan.value_local is None else plan.value_local.to(dev))
+        if mean:
+            inv = torch.repeat_interleave(1.0 / cnt.clamp(min=1).to(torch.float32), cnt)
+            val = inv if val is None else val * inv
+
+        def gather_padded(t, width):
+            pad = torch.zeros(width, dtype=t.dtype, device=dev)
+            pad[:t.numel()] = t
+            out = torch.empty(G * width, dtype=t.dtype, device=dev)
+            dist.all_gather_into_tensor(out, pad, group=self.group)
+            return out.view(G, width)
+        per = plan.per
+        counts_all = gather_padded(cnt, per)                                       # [G, per] row lengths (padding rows: 0)
+        nnz = torch.tensor([int(cnt.sum())], dtype=torch.int64, device=dev)
+        nnz_all = torch.empty(G, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(nnz_all, nnz, group=self.group)
+        nnz_list = [int(v) for v in nnz_all.tolist()]
+        width = max(max(nnz_list), 1)
+        cols = gather_padded(col_global, width)
+        vals = None if val is None else gather_padded(val.to(torch.float32), width)
+        counts = torch.cat([counts_all[r, :self.rows_per_rank[r]] for r in range(G)])
+        rowptr = torch.zeros(plan.n + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=rowptr[1:])
+        col = torch.cat([cols[r, :nnz_list[r]] for r in range(G)]).contiguous()
+        value = None if vals is None else torch.cat([vals[r, :nnz_list[r]] for r in range(G)]).contiguous()
+        full = SparseTensor(rowptr=rowptr, col=col, value=value, sparse_sizes=(plan.n, plan.n))
+        self._full[key] = full
+        return full
 
     @staticmethod
     def _gcn_plan(rowptr_local, col_global, n, world, rank, group, make):
@@ -544,6 +665,8 @@ class ShardedAdj:
             raise NotImplementedError(f"sharded aggregation supports sum / mean, not '{reduce}'")
         st = self._static
         static = st is not None and st[0] is x_local and not x_local.requires_grad and x_local._version == st[2]   # version AT registration
+        if not static and self.sliced_pays(x_local.shape[1]):      # (a registered static input travels once per run: nothing to save)
+            return _SlicedAggregate.apply(x_local, self, self.full_adj(reduce == "mean", valueless), bias, relu)
         if _OVERLAP:
             own, halo = self._split(reduce == "mean", valueless)
             return _OverlapAggregate.apply(x_local, self, own, halo, st[1][self.plan.n_local:] if static else None, bias, relu)
@@ -559,6 +682,9 @@ class ShardedAdj:
         exchange would be skipped by autograd on this rank only)."""
         if not (_OVERLAP and x_local.is_cuda and reduce in ("sum", "add", "mean") and lin_r.bias is None and self.plan.n_local > 0):
             return None
+        width = lin_l.weight.shape[0] if narrow else x_local.shape[1]
+        if self.sliced_pays(width) and not (self._static is not None and self._static[0] is x_local):
+            return None                       # column-sliced mode: SAGEConv composes ``aggregate`` (sliced) with its GEMMs
         st = self._static
         static = st is not None and st[0] is x_local and not x_local.requires_grad and x_local._version == st[2]
         if torch.is_grad_enabled() and not (static or x_local.requires_grad):
@@ -1586,7 +1712,10 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
                                      f" + SyncBN all-reduce + flat grad all-reduce over "
                                      + ("RCCL" if backend == "nccl" else f"{backend} (host-staged: all ranks share one GPU, hostcomm.py -- a functional run, "
                                                                           f"not a scaling measurement)" if on_gpu else backend),
-                        mean_halo_rows_per_rank=int(float(halo) / world), node_order=partition),
+                        mean_halo_rows_per_rank=int(float(halo) / world), node_order=partition,
+                        aggregation_exchange=dict(mode=_AGG_MODE, sliced_for_width=[K for K in (32, 64, 128, 256, 512) if prob.adj.sliced_pays(K)],
+                                                  rule="sliced (feature columns re-sharded around the aggregation, 2 N K 4 (G-1)/G^2 bytes per rank) where "
+                                                       "the all-rank mean halo x G^2 > 2 N (G-1) and K % (4 G) == 0; halo rows otherwise")),
             launch=graph_note,
             comm_per_epoch=dict(what="one epoch (train step + eval) traced after the timed region: payload bytes per rank and kind; "
                                      "overlap_window_us = own-column aggregation time the halo exchanges run under, exposed_comm_us = what the "

@@ -1035,19 +1035,6 @@ def _draw_dropout_seed() -> int:
     return int(torch.empty((), dtype=torch.int64).random_()) & 0x7FFFFFFFFFFFFFFF
 
 
-_DEPHASE = int(os.environ.get("EGNN_DEPHASE_BYTES", "0"))     # lab switch (tools/r06): output tensors of the streaming BatchNorm kernels start
-_DEPHASE_N = [0]                                               # this many bytes x (1..7) past their allocation's 2 MiB-aligned base
-
-
-def _empty_rows(n: int, C: int, device) -> Tensor:
-    """float32 [n, C] row-major; with the lab switch the tensor sits at a rotating offset inside a slightly larger allocation."""
-    if _DEPHASE <= 0:
-        return torch.empty(n, C, dtype=torch.float32, device=device)
-    _DEPHASE_N[0] = _DEPHASE_N[0] % 7 + 1
-    off = _DEPHASE_N[0] * _DEPHASE // 4
-    return torch.empty(n * C + 8 * _DEPHASE // 4, dtype=torch.float32, device=device)[off:off + n * C].view(n, C)
-
-
 def _bn_shape_ok(x: Tensor) -> bool:
     C = x.shape[1]
     return x.is_cuda and C % 4 == 0 and C <= 1024 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
@@ -1063,7 +1050,7 @@ class _BnAct(torch.autograd.Function):
         n, C = x.shape
         seed_dev = _DROPOUT_SEED_DEV if p > 0 else None
         if pick is None:
-            y = _empty_rows(n, C, x.device)
+            y = torch.empty(n, C, dtype=torch.float32, device=x.device)
             rc = _lib.load().egnn_bn_act_fwd_f32(_lib.ptr(x), x.stride(0), n, C, _lib.ptr(mean), _lib.ptr(var), float(eps), _lib.ptr(gamma),
                                                  _lib.ptr(beta), int(relu), float(p), int(seed), _lib.ptr(seed_dev), _lib.ptr(y), y.stride(0),
                                                  _lib.stream())
@@ -1089,7 +1076,7 @@ class _BnAct(torch.autograd.Function):
         gy = _rowmajor(gy)
         n, C = x.shape
         lib, dev = _lib.load(), x.device
-        dx = _empty_rows(n, C, dev)
+        dx = torch.empty_like(x)
         dgamma = torch.empty(C, dtype=torch.float32, device=dev)
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         nws = lib.egnn_bn_ws_floats(C)
@@ -1192,7 +1179,7 @@ class _BnActLinear(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, mean, var, eps, relu, p, seed, batch_stats, w, box):
         x = _rowmajor(x)
         n, C = x.shape
-        h = _empty_rows(n, C, x.device)
+        h = torch.empty(n, C, dtype=torch.float32, device=x.device)
         seed_dev = _DROPOUT_SEED_DEV if p > 0 else None
         w = _rowmajor(w)
         lib = _lib.load()
@@ -1244,7 +1231,7 @@ def _tail_backward(ctx, g_h, g_xw, x, gamma, beta, mean, var, h, w, eps, relu, p
             gw = gemm_raw(h, g_xw, True, False) if n > 0 else torch.zeros_like(w)     # dW = h^T G
     if not ctx.needs_input_grad[0]:
         return None, None, None, gw
-    dx = _empty_rows(x.shape[0], x.shape[1], x.device)
+    dx = torch.empty_like(x)
     sums = torch.empty(2 * C, dtype=torch.float32, device=dev)       # [dbeta | dgamma]; written by the reduce half (zeroed on an empty shard)
     if n == 0:
         sums.zero_()

@@ -111,6 +111,7 @@ def _reference_run(gnn, mode, steps=3, hp=None):
     HP = dict(globals()["HP"], **(hp or {}))
     HP.pop("static_sigmas", None)
     HP.pop("host_staged", None)
+    HP.pop("agg_mode", None)
     import oracle.models as OM
     d = _make_data(train_ids_below=HP.pop("train_ids_below", None))
     torch.manual_seed(0)
@@ -169,6 +170,8 @@ def _worker(rank, world, port, gnn, mode, q, hp=None):
             hostcomm._STAGE_HOST_TENSORS = True
             hostcomm.install()
         d = _make_data(train_ids_below=HP.pop("train_ids_below", None))
+        if "agg_mode" in HP:               # "sliced": every kernel-aligned aggregation re-shards the feature columns instead of fetching halo rows
+            DD._AGG_MODE = HP.pop("agg_mode")
         prob = DD.ShardedProblem(d, world, rank, "cpu", None, need_gcn=True)
         if "static_sigmas" in HP:    # the sampled criteria in draw-independent shapes (what ShardedGraphedEpoch captures on > 1 rank)
             prob.static_sample = DD.StaticSample(prob, HP["max_samples"], sigmas=HP.pop("static_sigmas"))
@@ -187,10 +190,14 @@ def _worker(rank, world, port, gnn, mode, q, hp=None):
         opt = torch.optim.Adam(groups)
         out, accs = DD.sharded_evaluate(model, prob)
         losses = [DD.sharded_train_step(model, prob, opt, mode, HP, sp, tp) for _ in range(3)]
-        gathered = [None] * world
+        with DD.CommTrace() as trace:          # one more step with the collectives recorded: which exchange forms ran
+            DD.sharded_train_step(model, prob, opt, mode, HP, sp, tp)
+        gathered, comm = [None] * world, [None] * world
         dist.all_gather_object(gathered, out.numpy())
+        dist.all_gather_object(comm, (trace.summary(), trace.records))
         if rank == 0:
-            q.put((losses, np.concatenate(gathered, 0), accs, prob.adj.plan.n_halo))
+            q.put((losses, np.concatenate(gathered, 0), accs, prob.adj.plan.n_halo,
+                   dict(per_rank=[c[0] for c in comm], consistent=DD.consistent_collectives([c[1] for c in comm]))))
     except BaseException:
         import traceback
         traceback.print_exc()
@@ -219,10 +226,12 @@ def test_sharded_training_matches_single_process_oracle(gnn, mode, world, max_sa
     procs = [ctx.Process(target=_worker, args=(r, world, port, gnn, mode, q, hp)) for r in range(world)]
     for p in procs:
         p.start()
-    losses, logits, accs, n_halo = q.get()  # read before join: the payload is larger than the pipe buffer
+    losses, logits, accs, n_halo, comm = q.get()  # read before join: the payload is larger than the pipe buffer
     for p in procs:
         p.join(300)
         assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    assert comm["consistent"] is None, comm["consistent"]
+    assert all("sliced_exchanges" not in c for c in comm["per_rank"])      # (halo mode unless asked / unless it pays: tiny graphs never do)
 
     ref_losses, ref_logits, ref_accs = _reference_run(gnn, mode, hp=hp)
     np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-4, atol=1e-6)
@@ -231,6 +240,40 @@ def test_sharded_training_matches_single_process_oracle(gnn, mode, world, max_sa
     np.testing.assert_allclose(logits, ref_logits.numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(accs, ref_accs, atol=1e-9)
     assert n_halo > 0
+
+
+@pytest.mark.parametrize("gnn,mode,world", [("gcn", "nce", 2), ("gcn", "kd", 4), ("sage", "nce", 4), ("sage", "lpw", 2), ("gcn", "nce", 3)])
+def test_column_sliced_aggregation_matches_single_process_oracle(gnn, mode, world):
+    """the sharded step with the aggregation in COLUMN-SLICED form (dist._SlicedAggregate: all_to_all of the feature
+    columns to [N, K / world] slices, aggregation of all rows on the all-gathered full adjacency, all_to_all back -- bytes independent of
+    the halo) against the single-process oracle: same losses over three steps, same initial eval.  World 3: the 32-wide layers are not
+    divisible into kernel-aligned slices (32 % 12), every aggregation stays in halo form -- the mode is a per-call decision."""
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    hp = dict(max_samples=96, agg_mode="sliced")
+    if mode == "lpw":
+        hp.update(kernel="cosine", beta=100.0)
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, gnn, mode, q, hp)) for r in range(world)]
+    for p in procs:
+        p.start()
+    losses, logits, accs, n_halo, comm = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+    assert comm["consistent"] is None, comm["consistent"]
+    if world == 3:
+        assert all("sliced_exchanges" not in c for c in comm["per_rank"])
+    else:
+        # GCN: the 32-wide hidden aggregation forward + backward (the static input and the class-wide output layer stay in halo form);
+        # every sliced aggregation is two exchanges; all ranks put the same number of bytes on the wire (equal node ranges or not: the
+        # formula is N K 4 (G - 1) / G^2 per direction up to the last range's remainder)
+        assert all(c["sliced_exchanges"] >= 4 and c["sliced_exchanges"] % 2 == 0 for c in comm["per_rank"]), comm["per_rank"]
+        assert all(c["sliced_all_to_all_bytes_sent"] > 0 for c in comm["per_rank"])
+    ref_losses, ref_logits, ref_accs = _reference_run(gnn, mode, hp=hp)
+    np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(logits, ref_logits.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(accs, ref_accs, atol=1e-9)
 
 
 def test_shard_plan_integer_logic():

@@ -50,6 +50,12 @@ def all_cases():
     # an empty row block of the G-CRD problem) next to ranks that do
     cases["gcn-nce-overflow-5samples-ov1"] = dict(gnn="gcn", mode="nce", sigmas=-50.0, order="natural", overlap=1, max_samples=5)
     cases["gcn-gpw-overflow-5samples-ov1"] = dict(gnn="gcn", mode="gpw", sigmas=-50.0, order="natural", overlap=1, max_samples=5)
+    # round 6: the aggregation in COLUMN-SLICED form (dist._SlicedAggregate: the feature columns re-sharded around the aggregation,
+    # bytes independent of the halo) forced on every kernel-aligned call -- the 64-wide hidden layers here
+    cases["gcn-nce-static-sliced-natural-ov1"] = dict(gnn="gcn", mode="nce", sigmas=6.0, order="natural", overlap=1, agg="sliced")
+    cases["sage-lpw-sliced-natural-ov1"] = dict(gnn="sage", mode="lpw", sigmas=None, order="natural", overlap=1, agg="sliced")
+    cases["mag-sage-kd-sliced-ov1"] = dict(gnn="sage", mode="kd", sigmas=None, order="natural", overlap=1, workload="mag", agg="sliced")
+    cases["gcn-kd-sliced-notrain-tail-ov1"] = dict(gnn="gcn", mode="kd", sigmas=None, order="natural", overlap=1, train_below=0.4, agg="sliced")
     return cases
 
 
@@ -59,7 +65,15 @@ def full_size_cases():
     return {"full-gcn-nce-static-natural-ov1": dict(gnn="gcn", mode="nce", sigmas=6.0, order="natural", overlap=1, scale=1.0, hidden=256, proj=256,
                                                     max_samples=16384, seed=0),
             "full-sage-lpw-natural-ov1": dict(gnn="sage", mode="lpw", sigmas=None, order="natural", overlap=1, scale=1.0, hidden=256, proj=256,
-                                              max_samples=16384, seed=0)}
+                                              max_samples=16384, seed=0),
+            # round 6: the headline problem with the hidden-layer aggregations column-sliced, and BASELINE.json configs[4] at FULL size
+            # (N = 1 939 743, 42.2 M entries, SAGE-256 mean + logit KD) in both exchange forms
+            "full-gcn-nce-static-sliced-natural-ov1": dict(gnn="gcn", mode="nce", sigmas=6.0, order="natural", overlap=1, scale=1.0, hidden=256,
+                                                           proj=256, max_samples=16384, seed=0, agg="sliced"),
+            "full-mag-sage-kd-ov1": dict(gnn="sage", mode="kd", sigmas=None, order="natural", overlap=1, workload="mag", mag_scale=1.0, hidden=256,
+                                         seed=0),
+            "full-mag-sage-kd-sliced-ov1": dict(gnn="sage", mode="kd", sigmas=None, order="natural", overlap=1, workload="mag", mag_scale=1.0,
+                                                hidden=256, seed=0, agg="sliced")}
 
 
 def _problem(case, world, dev):
@@ -67,7 +81,7 @@ def _problem(case, world, dev):
     import efficient_gnns_amd.dist as DD
     note = {}
     if case.get("workload") == "mag":
-        d = DD.mag_problem(0.05, 5)             # N = 96 987, 2.1 M stored entries
+        d = DD.mag_problem(case.get("mag_scale", 0.05), case.get("seed", 5))             # default: N = 96 987, 2.1 M stored entries
     else:
         d = D.arxiv_like(scale=case.get("scale", 0.02), seed=case.get("seed", 5), graph="local" if case["order"] == "community" else "chunglu")
         if case.get("train_below"):
@@ -130,6 +144,7 @@ def _sharded(case, d, world, rank, dev, steps):
     import efficient_gnns_amd.dist as DD
     hp = _hp(case)
     DD._OVERLAP = bool(case["overlap"])
+    DD._AGG_MODE = case.get("agg", "halo")       # (the tests pin the form; "auto" is what bench.py runs)
     model, sp, tp, groups = _build(case, d, dev)
     for m in (model, sp, tp):
         if m is not None:
@@ -162,7 +177,7 @@ def _worker(rank, world, port, names, out_path, steps):
     try:
         import efficient_gnns_amd.dist as DD
         from efficient_gnns_amd import _lib, hostcomm
-        assert not _lib.HOST_STANDINS
+        assert not hasattr(_lib, "HOST_STANDINS")      # (round 6: the product has no stand-in switch any more)
         hostcomm.install()
         cases = dict(all_cases(), **full_size_cases())
         report = {}
@@ -194,7 +209,8 @@ def _worker(rank, world, port, names, out_path, steps):
                          per_rank=infos, note=note, seconds=round(time.perf_counter() - t0, 2), host_staged=hostcomm.stats())
             entry["ok"] = bool(logit_err <= 1.0 and loss_err <= 1.0 and acc_err <= 1.5 / min_split and bad is None
                                and all(i["n_halo"] > 0 for i in infos)
-                               and all(i["comm"]["halo_all_to_all_bytes_sent"] > 0 for i in infos))
+                               and all(i["comm"]["halo_all_to_all_bytes_sent"] > 0 for i in infos)
+                               and (case.get("agg") != "sliced" or all(i["comm"].get("sliced_exchanges", 0) > 0 for i in infos)))
             report[name] = entry
             with open(out_path, "w") as f:      # after every case: a crash in a later one keeps what has been compared
                 json.dump(report, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))
