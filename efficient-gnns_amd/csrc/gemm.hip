@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dma_kernel(const GemmArgs g) {
   const int64_t m0 = (tile / tiles_n) * 128, n0 = (tile % tiles_n) * 128;
   f32x16 acc[2][2];
   zero_acc(acc);
+  // (no scheduling hint here: iglp_opt(0) measured 137 vs 148 us in the lab on this shape but 146-149 vs 145 us inside the epoch, A/B on one box)
   egnn_gemm3::mainloop<egnn_gemm3::F32K, egnn_gemm3::PLANES, 2, 2, DMA_BKT, 2, 1>(acc, g.A, g.lda, m0, g.planes, g.K / DMA_BKT, n0, 0, g.K,
                                                                                  reinterpret_cast<char*>(smem), g.M);
   const int wave = egnn_wave_id();
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_planes_kernel(const float* __r
   const int64_t kbeg = (int64_t)blockIdx.y * k_per_split, kend = kbeg + k_per_split;   // whole k-steps; past K: zero planes x the last dY row
   f32x16 acc[4][4];
   zero_acc(acc);
-  egnn_gemm3::mainloop<egnn_gemm3::F32M, egnn_gemm3::PLANES, 4, 4, TNP_BKT, 3, 1>(acc, A, lda, m0, planes, nks, n0, kbeg, kend,
+  egnn_gemm3::mainloop<egnn_gemm3::F32M, egnn_gemm3::PLANES, 4, 4, TNP_BKT, 3, 1, egnn_gemm3::SCHED_IGLP0>(acc, A, lda, m0, planes, nks, n0, kbeg, kend,
                                                                                     reinterpret_cast<char*>(smem), K);
   const int lane = egnn_lane(), wave = egnn_wave_id();
   const int wm = wave >> 1, wn = wave & 1;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void gemm_pp_kernel(const GemmArgs g, const
   const int64_t nks = (g.K + PP_BKT - 1) / PP_BKT;
   f32x16 acc[2][2];
   zero_acc(acc);
-  egnn_gemm3::mainloop<egnn_gemm3::PLANES, egnn_gemm3::PLANES, 2, 2, PP_BKT, 3, 1>(acc, planes_a, nks, m0, g.planes, nks, n0, 0, nks * PP_BKT,
+  egnn_gemm3::mainloop<egnn_gemm3::PLANES, egnn_gemm3::PLANES, 2, 2, PP_BKT, 3, 1, egnn_gemm3::SCHED_HAND>(acc, planes_a, nks, m0, g.planes, nks, n0, 0, nks * PP_BKT,
                                                                                      reinterpret_cast<char*>(smem));
   const int wave = egnn_wave_id();
   if (g.wide_store) store_tile_wide<128, 128, 2>(acc, g, m0, n0, 0, egnn_lane(), wave >> 1, wave & 1, smem);

@@ -33,6 +33,15 @@ using egnn_gemm::split8;
 using egnn_gemm::u32x4;
 
 constexpr int F32K = 0, PLANES = 1, F32M = 2;
+// scheduling hints of the steady-state k-block (the ABL template parameter of `mainloop`; results unchanged).  Measured per form in
+// tools/lab/gemm3_lab (-DLAB_SCHED_ONLY; profiles/r06_gemm3_sched_lab.txt): 2-8 % on the shipped forms; iglp_opt(1) does not finish
+// compiling on these basic blocks (> 5 min per kernel, tens of GB).
+#ifdef EGNN_GEMM3_NO_SCHED          // (A/B builds: tools/r06/ab.sh)
+constexpr int SCHED_IGLP0 = 0, SCHED_HAND = 0;
+#else
+constexpr int SCHED_IGLP0 = 32;    // __builtin_amdgcn_iglp_opt(0)
+constexpr int SCHED_HAND = 128;    // sched_group_barrier: one MFMA, then a share of the next k-block's LDS reads and cutting VALU
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -152,6 +161,9 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[TM][TN], const u32x4 (&
 //           stages deep on top of the register stage.
 // ABL (lab only, tools/lab/gemm3_lab.hip; results are then wrong on purpose): 1 = no DMA, 2 = no barriers, 4 = fragments read
 // once and reused, 8 = no vmcnt waits, 16 = s_setprio(1) around every MFMA block.
+// Scheduling hints (results stay right; round 6): 32 = __builtin_amdgcn_iglp_opt(0) per k-block, 64 = iglp_opt(1),
+// 128 = a hand-placed order of the k-block -- one MFMA, then a share of the next k-block's LDS reads and cutting VALU
+// (sched_group_barrier), instead of what the compiler's list scheduler picks.
 template <int AMODE, int BMODE, int TM, int TN, int BKT, int NB, int PIPE = 0, int ABL = 0>
 __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM][TN], const void* __restrict__ pa, int64_t la, int64_t m0, const void* __restrict__ pb,
                                          int64_t lb, int64_t n0, int64_t kbeg, int64_t kend, char* smem, int64_t a_rows = INT64_MAX) {
@@ -255,6 +267,23 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[TM][TN], const void* __re
       if constexpr (ABL & 16) __builtin_amdgcn_s_setprio(1);
       mfma_block<TM, TN>(acc, ac, bc);
       if constexpr (ABL & 16) __builtin_amdgcn_s_setprio(0);
+      if constexpr (ABL & 32) __builtin_amdgcn_iglp_opt(0);
+      if constexpr (ABL & 64) __builtin_amdgcn_iglp_opt(1);
+      if constexpr (ABL & 128) {
+        // per k-block: 6 TM TN MFMAs; fragments of the next k-block: (TM + TN) x {PLANES: 3 ds_read_b128; F32K: 2 ds_read_b128 + ~44
+        // VALU; F32M: 8 ds_read_b32 + ~44 VALU}
+        constexpr int NM = 6 * TM * TN;
+        constexpr int DSA = AMODE == PLANES ? 3 : (AMODE == F32K ? 2 : 8), DSB = BMODE == PLANES ? 3 : (BMODE == F32K ? 2 : 8);
+        constexpr int NDS = TM * DSA + TN * DSB;
+        constexpr int NVA = (AMODE == PLANES ? 0 : 44 * TM) + (BMODE == PLANES ? 0 : 44 * TN);
+        constexpr int DS_PER = (NDS + NM - 1) / NM, VA_PER = (NVA + NM - 1) / NM;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // one MFMA
+          if (i * DS_PER < NDS) __builtin_amdgcn_sched_group_barrier(0x100, DS_PER, 0);   // LDS reads of the next fragments, front-loaded
+          if (VA_PER > 0) __builtin_amdgcn_sched_group_barrier(0x002, VA_PER, 0);   // their cutting VALU, spread over the MFMAs
+        }
+      }
     };
     // k-blocks alternate between the two register sets; a group of GS stages is an even number of k-blocks, so that both
     // sets are compile-time names inside the (unrolled) group and every group starts on set 0

@@ -232,6 +232,8 @@ struct PipelineS {
         refill();
       }
     }
+    // (round 6: __builtin_amdgcn_iglp_opt(0) here was measured on one box, builds interleaved A B A B: 6.611 / 6.589 vs 6.642 / 6.583 ms
+    //  per replayed epoch -- no effect on this register-staged loop; not kept.  The DMA pipeline's loops do profit: gemm3.h SCHED_*.)
   }
 };
 

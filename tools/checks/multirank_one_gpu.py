@@ -209,8 +209,8 @@ def _worker(rank, world, port, names, out_path, steps):
                          per_rank=infos, note=note, seconds=round(time.perf_counter() - t0, 2), host_staged=hostcomm.stats())
             entry["ok"] = bool(logit_err <= 1.0 and loss_err <= 1.0 and acc_err <= 1.5 / min_split and bad is None
                                and all(i["n_halo"] > 0 for i in infos)
-                               and all(i["comm"]["halo_all_to_all_bytes_sent"] > 0 for i in infos)
-                               and (case.get("agg") != "sliced" or all(i["comm"].get("sliced_exchanges", 0) > 0 for i in infos)))
+                               and (all(i["comm"]["halo_all_to_all_bytes_sent"] > 0 for i in infos) if case.get("agg") != "sliced"
+                                    else all(i["comm"].get("sliced_exchanges", 0) > 0 for i in infos)))
             report[name] = entry
             with open(out_path, "w") as f:      # after every case: a crash in a later one keeps what has been compared
                 json.dump(report, f, indent=1, default=lambda o: o.tolist() if hasattr(o, "tolist") else str(o))

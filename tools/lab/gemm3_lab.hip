@@ -114,6 +114,9 @@ void launch_v(const LabArgs& g, dim3 grid, hipStream_t st) {
 
 #define VARIANT(name, AM, BMo, TM, TN, BKT, NB, OCC, PIPE) \
   Variant{name, AM, BMo, 64 * TM, 64 * TN, BKT, (size_t)Tile<AM, BMo, TM, TN, BKT, NB>::SMEM_BYTES, launch_v<AM, BMo, TM, TN, BKT, NB, OCC, PIPE, 0>, 0}
+// scheduling-hint variants: results are checked like any variant (the template's ABL bits 32 / 64 / 128 only move instructions)
+#define SCHED(name, AM, BMo, TM, TN, BKT, NB, OCC, PIPE, HINT) \
+  Variant{name, AM, BMo, 64 * TM, 64 * TN, BKT, (size_t)Tile<AM, BMo, TM, TN, BKT, NB>::SMEM_BYTES, launch_v<AM, BMo, TM, TN, BKT, NB, OCC, PIPE, HINT>, 0}
 #define ABLATION(name, AM, BMo, TM, TN, BKT, NB, OCC, PIPE, ABL) \
   Variant{name, AM, BMo, 64 * TM, 64 * TN, BKT, (size_t)Tile<AM, BMo, TM, TN, BKT, NB>::SMEM_BYTES, launch_v<AM, BMo, TM, TN, BKT, NB, OCC, PIPE, ABL>, ABL}
 
@@ -134,6 +137,37 @@ int main(int argc, char** argv) {
       {"sq4k", 4096, 4096, 4096, 1},
   };
   const Variant variants[] = {
+#ifdef LAB_SCHED_ONLY
+      // (round 6) a small build: the shipped forms and their scheduling-hint twins only (-DLAB_SCHED_ONLY; the full list takes > 15 min to compile)
+      VARIANT("f32k_pln_128x128_bk32_nb2_p", F32K, PLANES, 2, 2, 32, 2, 2, 1),
+      VARIANT("pln_pln_128x128_bk16_nb3_p", PLANES, PLANES, 2, 2, 16, 3, 2, 1),
+      VARIANT("f32m_pln_256x256_bk16_nb3_p", F32M, PLANES, 4, 4, 16, 3, 1, 1),
+      VARIANT("pln_pln_256x256_bk16_nb3_p", PLANES, PLANES, 4, 4, 16, 3, 1, 1),
+#if defined(LAB_SCHED32)
+      SCHED("sched32_f32k_pln_128x128_bk32_nb2_p", F32K, PLANES, 2, 2, 32, 2, 2, 1, 32),
+#endif
+#if defined(LAB_SCHED64)
+      SCHED("sched64_f32k_pln_128x128_bk32_nb2_p", F32K, PLANES, 2, 2, 32, 2, 2, 1, 64),
+#endif
+#if defined(LAB_SCHED128)
+      SCHED("sched128_f32k_pln_128x128_bk32_nb2_p", F32K, PLANES, 2, 2, 32, 2, 2, 1, 128),
+#endif
+#if defined(LAB_SCHED32)
+      SCHED("sched32_pln_pln_128x128_bk16_nb3_p", PLANES, PLANES, 2, 2, 16, 3, 2, 1, 32),
+#endif
+#if defined(LAB_SCHED64)
+      SCHED("sched64_pln_pln_128x128_bk16_nb3_p", PLANES, PLANES, 2, 2, 16, 3, 2, 1, 64),
+#endif
+#if defined(LAB_SCHED128)
+      SCHED("sched128_pln_pln_128x128_bk16_nb3_p", PLANES, PLANES, 2, 2, 16, 3, 2, 1, 128),
+#endif
+#if defined(LAB_SCHED32) && defined(LAB_BIG)
+      SCHED("sched32_f32m_pln_256x256_bk16_nb3_p", F32M, PLANES, 4, 4, 16, 3, 1, 1, 32),
+#endif
+#if defined(LAB_SCHED32) && defined(LAB_BIG)
+      SCHED("sched32_pln_pln_256x256_bk16_nb3_p", PLANES, PLANES, 4, 4, 16, 3, 1, 1, 32),
+#endif
+#else
       // name: <A form>_<B form>_<block tile>_bk<k per stage>_nb<LDS stages>[_p = fragments one k-block ahead in registers]
       VARIANT("f32k_f32k_128x128_bk32_nb2", F32K, F32K, 2, 2, 32, 2, 2, 0),
       VARIANT("f32k_f32k_128x128_bk16_nb3", F32K, F32K, 2, 2, 16, 3, 2, 0),
@@ -177,6 +211,7 @@ int main(int argc, char** argv) {
       ABLATION("abl_fp_nodma", F32K, PLANES, 2, 2, 16, 3, 2, 1, 1 | 8),
       ABLATION("abl_fp_setprio", F32K, PLANES, 2, 2, 32, 2, 2, 1, 16),
       ABLATION("abl_pp256_mfma_only", PLANES, PLANES, 4, 2, 16, 3, 1, 1, 1 | 8 | 4 | 2),
+#endif
   };
   hipStream_t st;
   CK(hipStreamCreate(&st));
