@@ -1120,7 +1120,9 @@ def main():
                             unit="TFLOP/s (fp32-input MFMA)", frac=round(tf / 157.3, 4), flops_per_call=gsum["flops"] / gsum["calls"],
                             us_per_call=round(gsum["secs"] / gsum["calls"] * 1e6, 1), calls_timed=gsum["calls"],
                             shape=dict(S=gsum["S"], P_student=gsum["Ps"], P_teacher=gsum["Pt"]),
-                            note="the backward (two GEMMs on the stored weight matrices) runs on the split-bf16 pipeline through egnn_gemm_f32")
+                            note="the backward (two GEMMs on the stored weight matrices) runs on the split-bf16 pipeline through egnn_gemm_f32; the "
+                                 "forward stays on the f32-input MFMA: with 8 k-steps per Gram product and two [S,S] weight matrices to write the kernel is "
+                                 "epilogue-bound -- on the split pipeline it took 203 us against 190 us (round 6, same box; profiles/r06_gsp_split_null.txt)")
     roofline_local = None
     if not args.no_local_roofline:
         try:
