@@ -465,6 +465,7 @@ class _ShardedSageLayer(torch.autograd.Function):
             out = ops.gemm_raw(agg, wl, False, True, bias=bl, addend=r)        # lin_l(agg) + lin_r(x) in one store
         ctx.save_for_backward(x, wl, wr, *([] if agg is None else [agg]))
         ctx.sadj, ctx.pieces, ctx.narrow, ctx.has_bias = sadj, (a_own, a_halo), narrow, bl is not None
+        ctx.static_input = static_halo is not None      # its forward made no exchange: neither does its backward, on any rank
         return out
 
     @staticmethod
@@ -489,8 +490,11 @@ class _ShardedSageLayer(torch.autograd.Function):
         else:
             if ctx.needs_input_grad[5]:
                 gwl = ops.gemm_raw(g, agg, True, False)                        # dW_l = g^T agg
-            if need_x:
+            # a non-static input exchanged its halo in the forward on EVERY rank, so every rank runs the reverse exchange here -- also one
+            # whose own input needs no gradient (sage_layer() only hands such inputs over when they are static; kept collective-safe anyway)
+            if need_x or not ctx.static_input:
                 gx = _overlap_backward(ops.gemm_raw(g, wl, False, False), ctx.sadj, a_own, a_halo, addend=ops.gemm_raw(g, wr, False, False))
+                gx = gx if need_x else None
         return ops._fresh(gx, ctx.tap_box), None, None, None, None, gwl, gbl, gwr, None
 
 
@@ -968,7 +972,9 @@ class _GatherPadded(torch.autograd.Function):
         gp.index_copy_(0, perm, g.contiguous())
         if reduce_grad and world > 1:
             from . import hostcomm
-            if dist.get_backend(group) == "nccl" or hostcomm.active():   # every rank only needs ITS block of the sum
+            # every rank only needs ITS block of the sum: reduce_scatter where the transport has one (RCCL; hostcomm for the tensors it
+            # stages -- gloo itself has none: host tensors take the all_reduce below)
+            if dist.get_backend(group) == "nccl" or (hostcomm.active() and hostcomm._staged(group, gp)):
                 mine = torch.empty(cap, g.shape[1], dtype=g.dtype, device=g.device)
                 dist.reduce_scatter_tensor(mine, gp, group=group)
                 return mine[:m], None, None, None, None, None, None

@@ -9,7 +9,8 @@ matches the script's flavour -- ``dropin/`` (class-index CE/KL losses: arxiv_pyg
 ``dropin/`` (multi-label BCE ``kd_criterion``: any script directory whose own criterion.py is BCE based) -- and only
 then the script's directory (its logger.py etc. still resolve).  Use ``--keep-criterion`` to shim the operators
 (GCNConv, SparseTensor, ...) but keep the script's own criterion.py, ``--plain-torch-modules`` to leave torch.nn.BatchNorm1d /
-torch.nn.Linear of the script's own model code on PyTorch's kernels (default: the package's, see accel.py).
+torch.nn.Linear of the script's own model code on PyTorch's kernels (default: the package's, scoped to the script's run, see accel.py),
+``--no-deferred-activations`` for accel with one launch per torch call (no lazy.py objects).
 """
 import os
 import runpy
@@ -40,18 +41,26 @@ def main(argv=None):
     plain = "--plain-torch-modules" in argv
     if plain:
         argv.remove("--plain-torch-modules")
+    eager = "--no-deferred-activations" in argv        # accel with one launch per torch call (round 5's form): accel.LAZY = False
+    if eager:
+        argv.remove("--no-deferred-activations")
     if not argv:
         raise SystemExit(__doc__)
     script = argv[0]
     sys.path[:0] = shim_path(script, keep)
-    if not plain:   # torch.nn.BatchNorm1d / torch.nn.Linear of the script's own model code on the package's kernels (dropin/accel.py)
-        import importlib.util
-        spec = importlib.util.spec_from_file_location("egnn_dropin_accel", os.path.join(HERE, "accel.py"))
-        accel = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(accel)
-        accel.enable()
     sys.argv = argv
-    runpy.run_path(script, run_name="__main__")
+    if plain:
+        runpy.run_path(script, run_name="__main__")
+        return
+    # torch.nn.BatchNorm1d / torch.nn.Linear of the script's own model code on the package's kernels (dropin/accel.py), SCOPED to the run of
+    # the script: torch's own methods are back when it returns or raises (an embedding process is left as it was found)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("egnn_dropin_accel", os.path.join(HERE, "accel.py"))
+    accel = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(accel)
+    accel.LAZY = not eager
+    with accel.scope():
+        runpy.run_path(script, run_name="__main__")
 
 
 if __name__ == "__main__":

@@ -3,7 +3,7 @@
 Why it exists.  RCCL refuses two ranks on one device, so on a one-GPU box the node-range sharded step (dist.py) could only
 ever run with world_size 1 -- an EMPTY halo.  With this transport W processes share ``cuda:0``: every rank runs the real HIP
 kernels on its shard, and each collective of the step (halo ``all_to_all_single``, SyncBN ``all_reduce`` / ``all_gather``,
-the G-CRD sample gather with its ``reduce_scatter``, the flat gradient ``all_reduce``) is carried by gloo through pinned
+the G-CRD sample gather with its ``reduce_scatter``, the flat gradient ``all_reduce``) is carried by gloo through (pageable)
 host memory: device -> host copy, the collective on the host tensor, host -> device copy, all ordered on the current
 stream.  Same collective program, same payloads, same order as the RCCL run -- only the wire differs (``CommTrace`` sees
 the calls above this layer).  It is a verification / bring-up transport (eager launches only: a host round trip cannot be

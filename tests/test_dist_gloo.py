@@ -170,8 +170,9 @@ def _worker(rank, world, port, gnn, mode, q, hp=None):
             hostcomm._STAGE_HOST_TENSORS = True
             hostcomm.install()
         d = _make_data(train_ids_below=HP.pop("train_ids_below", None))
-        if "agg_mode" in HP:               # "sliced": every kernel-aligned aggregation re-shards the feature columns instead of fetching halo rows
-            DD._AGG_MODE = HP.pop("agg_mode")
+        # "halo" (what these tests pin unless they say otherwise): the referenced rows travel; "sliced": every kernel-aligned aggregation
+        # re-shards the feature columns instead ("auto" -- the product default -- already picks sliced at 4 ranks on this 677-node graph)
+        DD._AGG_MODE = HP.pop("agg_mode", "halo")
         prob = DD.ShardedProblem(d, world, rank, "cpu", None, need_gcn=True)
         if "static_sigmas" in HP:    # the sampled criteria in draw-independent shapes (what ShardedGraphedEpoch captures on > 1 rank)
             prob.static_sample = DD.StaticSample(prob, HP["max_samples"], sigmas=HP.pop("static_sigmas"))
@@ -231,7 +232,7 @@ def test_sharded_training_matches_single_process_oracle(gnn, mode, world, max_sa
         p.join(300)
         assert p.exitcode == 0, f"rank exited with {p.exitcode}"
     assert comm["consistent"] is None, comm["consistent"]
-    assert all("sliced_exchanges" not in c for c in comm["per_rank"])      # (halo mode unless asked / unless it pays: tiny graphs never do)
+    assert all("sliced_exchanges" not in c for c in comm["per_rank"])      # (these cases pin the halo form)
 
     ref_losses, ref_logits, ref_accs = _reference_run(gnn, mode, hp=hp)
     np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-4, atol=1e-6)
@@ -542,7 +543,7 @@ def test_static_shape_sampled_criteria_match_the_oracle(gnn, mode, world, max_sa
         hp.update(max_samples=64, train_ids_below=-max_samples)
     if mode == "gpw":
         hp.update(kernel="cosine", beta=100.0)
-    losses, logits, accs, n_halo = _spawn(_worker, world, gnn, mode, hp)
+    losses, logits, accs, n_halo, _comm = _spawn(_worker, world, gnn, mode, hp)
     ref_losses, ref_logits, ref_accs = _reference_run(gnn, mode, hp=hp)
     np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-4, atol=1e-6)
 
@@ -610,7 +611,7 @@ def test_host_staged_collectives_carry_the_same_program(gnn, mode, world):
         hp.update(static_sigmas=6.0)        # _GatherPadded's backward takes the reduce_scatter branch under hostcomm
     if mode == "lpw":
         hp.update(kernel="cosine", beta=100.0)
-    losses, logits, accs, n_halo = _spawn(_worker, world, gnn, mode, hp)
+    losses, logits, accs, n_halo, _comm = _spawn(_worker, world, gnn, mode, hp)
     ref_losses, ref_logits, ref_accs = _reference_run(gnn, mode, hp=hp)
     np.testing.assert_allclose(np.array(losses), np.array(ref_losses), rtol=2e-4, atol=1e-6)
     np.testing.assert_allclose(logits, ref_logits.numpy(), rtol=1e-4, atol=1e-5)
