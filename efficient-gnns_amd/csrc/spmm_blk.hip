@@ -82,7 +82,14 @@ template <int J>
 __device__ __forceinline__ void gather_one(rsrc_t rsrc, uint32_t off_l, float v_l, int n, uint32_t lane_off, float4& x, float& v) {
   const uint32_t o = bcast8<J>(off_l);
   v = bcast8f<J>(v_l);
+#ifdef EGNN_SPMM_PRED
+  // (lab switch, round 6) padded slots issue NO request: the load is predicated on the slot being a real entry (29 % of the slots of the
+  // headline graph's short rows are padding at 8 entries per chunk)
+  x = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (J < n) x = buf_load4(rsrc, o + lane_off);
+#else
   x = buf_load4(rsrc, J < n ? o + lane_off : kOob);   // lane_off is kOob itself for lanes past K
+#endif
 }
 
 __device__ __forceinline__ void fma4(float v, const float4& x, float (&acc)[4]) {

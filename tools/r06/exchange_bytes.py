@@ -1,7 +1,7 @@
 """Bytes a rank sends per epoch for the aggregations of the sharded step, in both exchange forms, at 2 / 4 / 8 ranks -- integer
 arithmetic on the partition plan (dist.halo_rows_per_rank), no GPU.  GCN-256 on the arxiv-shaped graph: hidden aggregations K = 256
 (forward, backward, eval), class-wide K = 40 (forward, backward, eval), the input layer's halo is static.  SAGE-256 (mean) on the
-MAG-shaped graph: K = 256 hidden (fwd, bwd, eval) x 1 layer + the narrow-first output layer K = 349 -> padded ... reported per K.
+MAG-shaped graph: 6 aggregations of K = 256 per epoch (layers 2-3 forward, backward, eval; SAGEConv aggregates its input).
 usage: python tools/r06/exchange_bytes.py [--mag-scale 1.0]"""
 import argparse, os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -39,5 +39,7 @@ perm = None
 table("community graph (ids shuffled, ranges as given)", d2.adj_t, d2.num_nodes, [(256, 3), (40, 3)])
 if not args.skip_mag:
     m = DD.mag_problem(args.mag_scale, 0)
-    table("MAG-shaped (N=%d): SAGE-256 mean, 3 layers (input static; hidden K=256 fwd+bwd+eval; output narrow-first K=349 -> halo)" % m.num_nodes,
-          m.adj_t, m.num_nodes, [(256, 3), (349, 3)])
+    # SAGEConv aggregates its INPUT (out = 349 > in = 256: no narrow-first form): layers 2 and 3 gather 256-wide hidden rows forward, backward
+    # and in eval = 6 calls per epoch; layer 1's 128-wide input is static (halo fetched once, no input gradient)
+    table("MAG-shaped (N=%d): SAGE-256 mean, 3 layers; per epoch 6 aggregations of K=256 (layers 2-3: forward, backward, eval)" % m.num_nodes,
+          m.adj_t, m.num_nodes, [(256, 6)])
