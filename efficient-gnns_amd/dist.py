@@ -1540,18 +1540,55 @@ class ShardedGraphedEpoch:
             self.prob.sample_hook, self.prob.static_sample, ops._DROPOUT_SEED_DEV = prev
         return rep, correct
 
+    def _launch(self):
+        """Enqueue one epoch (the replay, or -- a draw that does not fit the static capacity -- the same program with eager launches);
+        returns the device tensors holding its (losses, hit counts)."""
+        if self._overflow is not None:
+            return self._eager_step(self._overflow)
+        self.graph.replay()
+        return self.rep, self.correct
+
+    def _decode(self, vals):
+        accs = tuple(vals[3 + i] / max(1, self.prob.split_sizes[k]) for i, k in enumerate(("train", "valid", "test")))
+        return finish_losses(vals[:3], self.mode, self.hp), accs
+
     def step(self):
         """Replay one epoch; returns ((loss, loss_cls, loss_aux), (train, valid, test accuracies))."""
-        if self._overflow is not None:
-            rep, correct = self._eager_step(self._overflow)
-        else:
-            self.graph.replay()
-            rep, correct = self.rep, self.correct
+        if getattr(self, "_pending", None) is not None:
+            raise RuntimeError("ShardedGraphedEpoch.step() after step_async(): call drain() first (an epoch's values are still in flight)")
+        rep, correct = self._launch()
         self._draw()                                              # the next step's host draw overlaps the replay
         vals = torch.cat([rep, correct]).tolist()                 # one device->host read per epoch
         self._upload()
-        accs = tuple(vals[3 + i] / max(1, self.prob.split_sizes[k]) for i, k in enumerate(("train", "valid", "test")))
-        return finish_losses(vals[:3], self.mode, self.hp), accs
+        return self._decode(vals)
+
+    # the loop without an idle GPU between epochs (models.GraphedEpoch.step_async on shards): epoch k is launched -- collectives included --
+    # before the host reads the values of epoch k - 1; same replays, same draws in the same order on every rank
+    def step_async(self):
+        """Launch one epoch and return the values of the PREVIOUS ``step_async`` epoch (None on the first call); ``drain()`` hands out
+        the last one."""
+        if getattr(self, "_res_host", None) is None:
+            self._res_host = [torch.zeros(6, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._res_done, self._pending, self._k = [None, None], None, 0
+        slot = self._k & 1
+        self._k += 1
+        rep, correct = self._launch()
+        self._res_host[slot].copy_(torch.cat([rep, correct]).to(torch.float32), non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        self._res_done[slot] = done
+        self._draw()
+        self._upload()
+        prev, self._pending = self._pending, slot
+        return None if prev is None else self._values(prev)
+
+    def _values(self, slot):
+        self._res_done[slot].synchronize()
+        return self._decode(self._res_host[slot].tolist())
+
+    def drain(self):
+        prev, self._pending = getattr(self, "_pending", None), None
+        return None if prev is None else self._values(prev)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1650,8 +1687,27 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
     elif want_graph:
         graph_note = f"eager launches: the sharded '{args.training}' step is not capturable"
     epoch = graphed.step if graphed is not None else eager_epoch
-    for _ in range(args.warmup):      # the W untimed warm-up steps: of the program that is timed (replays, or eager epochs)
-        epoch()
+
+    def run(n):
+        """n epochs of the timed program; replays launch ahead (step_async: epoch k before the values of epoch k - 1 are read)."""
+        if graphed is None:
+            for _ in range(n):
+                vals = eager_epoch()
+            return vals
+        for _ in range(n):
+            graphed.step_async()
+        return graphed.drain()
+    # untimed settle phase (as in bench.py's single-GPU path; declared in the line): the devices leave set-up in a low clock state
+    settle_s = float(getattr(args, "settle_seconds", 0.0)) if graphed is not None else 0.0
+    if settle_s > 0:
+        ts = time.perf_counter()
+        go = torch.ones(1, device=device)
+        while float(go.item()) > 0:          # every rank runs the same number of blocks: rank 0's clock decides
+            run(max(args.steps, 10))
+            go.fill_(1.0 if (time.perf_counter() - ts) < settle_s else 0.0)
+            dist.broadcast(go, src=0)
+    if args.warmup > 0:               # the W untimed warm-up steps: of the program that is timed (replays, or eager epochs)
+        run(args.warmup)
     # The interpreter holds ~170k long-lived objects after the torch / RCCL imports; a full (generation-2) collection
     # walks all of them (~40 ms) and the per-step autograd / collective bookkeeping triggers one every few steps.
     # Freezing the survivors of set-up keeps later collections proportional to the per-step garbage.
@@ -1672,8 +1728,7 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
         ops.spmm_raw = probed
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses, accs = epoch()
+    losses, accs = run(args.steps)
     sync()
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -1722,7 +1777,8 @@ def bench_main(args, hp, model_cfg, rank, world, device, backend: str = "nccl", 
                         aggregation_exchange=dict(mode=_AGG_MODE, sliced_for_width=[K for K in (32, 64, 128, 256, 512) if prob.adj.sliced_pays(K)],
                                                   rule="sliced (feature columns re-sharded around the aggregation, 2 N K 4 (G-1)/G^2 bytes per rank) where "
                                                        "the all-rank mean halo x G^2 > 2 N (G-1) and K % (4 G) == 0; halo rows otherwise")),
-            launch=graph_note,
+            launch=graph_note + ("; step_async loop (epoch k launched before the values of epoch k-1 are read), "
+                                 f"{settle_s:g} s of untimed settle replays in front of the warm-up" if graphed is not None else ""),
             comm_per_epoch=dict(what="one epoch (train step + eval) traced after the timed region: payload bytes per rank and kind; "
                                      "overlap_window_us = own-column aggregation time the halo exchanges run under, exposed_comm_us = what the "
                                      "compute stream still waits for them afterwards (forward exchanges; HIP events)",

@@ -78,6 +78,35 @@ for (le, ae), (lg, ag) in zip(eager, got):
     np.testing.assert_allclose(np.array(lg), np.array(le), rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(np.array(ag), np.array(ae), atol=2e-3)
 print("eager", eager[-1], "replayed", got[-1])
+# round 6: the launch-ahead loop (step_async) on an identically prepared twin: same replays, same draws -> the SAME values as `got`, one call later
+m3, sp3, tp3, o3 = build()
+state3 = [copy.deepcopy(x.state_dict()) if x is not None else None for x in (m3, sp3, tp3)]
+ge2 = DD.ShardedGraphedEpoch(m3, prob, o3, mode, hp, sp3, tp3, warmup=2, static_sample=True if a.static else None)
+for x, st in zip((m3, sp3, tp3), state3):
+    if x is not None:
+        x.load_state_dict(st)
+for grp in o3.param_groups:
+    for p_ in grp["params"]:
+        stt = o3.state[p_]
+        if stt:
+            stt["exp_avg"].zero_()
+            stt["exp_avg_sq"].zero_()
+            stt["step"].zero_()
+np.random.seed(3)
+ge2._refresh()
+assert ge2.step_async() is None
+later = [ge2.step_async(), ge2.step_async()]
+try:
+    ge2.step()
+    raise SystemExit("step() must refuse while an epoch's values are in flight")
+except RuntimeError:
+    pass
+later.append(ge2.drain())
+assert ge2.drain() is None
+for (lg, ag), (la, aa) in zip(got, later):
+    np.testing.assert_allclose(np.array(la), np.array(lg), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(np.array(aa), np.array(ag), atol=1e-9)
+print("async", later[-1])
 print("SHARDED-GRAPH-OK", flush=True)
 dist.barrier()
 dist.destroy_process_group()
