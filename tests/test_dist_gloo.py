@@ -487,8 +487,18 @@ def _plan_worker(rank, world, port, q):
         # the scatter matrix adds every received row into its owner row exactly once
         sc = sadj.scatter
         ok_scatter = sc.nnz() == loc.send_idx.numel() and torch.equal(torch.sort(sc.csr()[1]).values, torch.arange(sc.nnz()))
+        # round 6: the FULL matrix the column-sliced form aggregates on, all-gathered from the shards' pieces (uneven ranges at 3 ranks):
+        # A^ entry for entry, and the mean form of the raw adjacency (1 / rowcount per entry), both equal to the global structure
+        full = sadj.gcn_normalized().full_adj(False, False)
+        frp, fcol, fval = full.csr()
+        same_full = (torch.equal(frp, grp) and torch.equal(fcol, gcol) and torch.allclose(fval, gval, rtol=1e-6, atol=0))
+        mean_full = sadj.full_adj(True, True)
+        mrp, mcol, mval = mean_full.csr()
+        cnt = (rowptr[1:] - rowptr[:-1]).clamp(min=1).to(torch.float32)
+        same_mean = (torch.equal(mrp, rowptr) and torch.equal(mcol, col)
+                     and torch.allclose(mval, torch.repeat_interleave(1.0 / cnt, rowptr[1:] - rowptr[:-1]), rtol=1e-6, atol=0))
         got = [None] * world
-        dist.all_gather_object(got, (same, same_gcn, ok_scatter))
+        dist.all_gather_object(got, (same, same_gcn, ok_scatter, same_full, same_mean))
         if rank == 0:
             q.put(got)
     except BaseException:
