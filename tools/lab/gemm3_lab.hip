@@ -133,6 +133,7 @@ int main(int argc, char** argv) {
   const Shape shapes[] = {
       {"nce_fwd_16k_16k_256", 16384, 16384, 256, 1},
       {"layer_169k_256_256", 169216, 256, 256, 1},
+      {"layer128_169k_256_128", 169216, 256, 128, 1},
       {"nce_bwd_16k_256_16k_sk8", 16384, 256, 16384, 8},
       {"sq4k", 4096, 4096, 4096, 1},
   };
@@ -143,6 +144,14 @@ int main(int argc, char** argv) {
       VARIANT("pln_pln_128x128_bk16_nb3_p", PLANES, PLANES, 2, 2, 16, 3, 2, 1),
       VARIANT("f32m_pln_256x256_bk16_nb3_p", F32M, PLANES, 4, 4, 16, 3, 1, 1),
       VARIANT("pln_pln_256x256_bk16_nb3_p", PLANES, PLANES, 4, 4, 16, 3, 1, 1),
+#ifdef LAB_LAYER
+      // short-K layer shapes (K = 128 / 256): stage size, ring depth and row-tile height around the shipped form (first line)
+      VARIANT("f32k_pln_128x128_bk16_nb3_p", F32K, PLANES, 2, 2, 16, 3, 2, 1),
+      VARIANT("f32k_pln_128x128_bk16_nb4_p", F32K, PLANES, 2, 2, 16, 4, 2, 1),
+      VARIANT("f32k_pln_128x128_bk32_nb2", F32K, PLANES, 2, 2, 32, 2, 2, 0),
+      VARIANT("f32k_pln_256x128_bk16_nb3_p", F32K, PLANES, 4, 2, 16, 3, 1, 1),
+      VARIANT("f32k_pln_128x256_bk16_nb3_p", F32K, PLANES, 2, 4, 16, 3, 1, 1),
+#endif
 #if defined(LAB_SCHED32)
       SCHED("sched32_f32k_pln_128x128_bk32_nb2_p", F32K, PLANES, 2, 2, 32, 2, 2, 1, 32),
 #endif
