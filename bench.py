@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--repeat-blocks", type=int, default=-1,
                     help="further blocks of --steps replays timed after the contract's block (spread of the measurement; 0 = none; "
                          "default: as many as fill ~2 s, at least 4, at most 50)")
-    ap.add_argument("--settle-seconds", type=float, default=3.0,
+    ap.add_argument("--settle-seconds", type=float, default=5.0,
                     help="untimed device-settle phase in front of the --warmup steps: replays of the timed program for this many seconds "
                          "(reported in `timing.settle_before_warmup` with its block times; 0 = none)")
     ap.add_argument("--graph", default=None, choices=["on", "off", "auto"],
