@@ -22,9 +22,14 @@ package's autograd Functions implement first derivatives only); an ``Adam(differ
 """
 from __future__ import annotations
 
+import os
+import weakref
+
 import torch
 
 _orig: dict = {}
+_NEXT_BN: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()    # GCNConv -> weakref(BatchNorm1d it was seen to feed); kept outside the modules (pickling)
+DEFER_CONV = os.environ.get("EGNN_ACCEL_DEFER_CONV", "1") != "0"   # inference: a GCNConv seen to feed a BatchNorm1d is deferred, so that conv + BN + ReLU run as one folded pass (lazy.LazyFold)
 LAZY = True     # BatchNorm1d.forward returns a deferred activation (efficient_gnns_amd/lazy.py); False: one launch per torch call, as in round 5
 
 
@@ -44,7 +49,13 @@ def enable() -> None:
     from efficient_gnns_amd.sparse import SparseTensor
 
     def fast_bn(self, x):
+        if LAZY and isinstance(x, L.LazyConv) and x._value is None and not self.training and not torch.is_grad_enabled() \
+                and type(self) is torch.nn.BatchNorm1d and self.track_running_stats and self.weight is not None and self.bias is not None:
+            return L.LazyFold(x, self)       # inference: the BatchNorm folds into the deferred conv (+ the ReLU that follows)
         x = L.materialise(x)
+        prod = getattr(x, "_egnn_producer", None)
+        if prod is not None and type(self) is torch.nn.BatchNorm1d:
+            _NEXT_BN[prod] = weakref.ref(self)         # learned: this conv feeds this BatchNorm (decides deferral / statistics only)
         if (not _double_backward_wanted(x) and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and self.weight is not None and self.bias is not None
                 and self.track_running_stats and self.running_mean is not None and x.shape[0] > 1 and ops._bn_shape_ok(ops._rowmajor(x))):
             if LAZY:
@@ -75,8 +86,23 @@ def enable() -> None:
                 and self.in_channels >= self.out_channels and self._cached_ax is None:
             both = x.materialise_with_linear(self.weight)
             if both is not None:
-                return gcn_forward(self, both[0], edge_index, xw=both[1])
-        return gcn_forward(self, L.materialise(x), edge_index, *a, **kw)
+                out = gcn_forward(self, both[0], edge_index, xw=both[1])
+                out._egnn_producer = self
+                return out
+        x = L.materialise(x)
+        nb = _NEXT_BN.get(self)
+        bn = nb() if nb is not None else None
+        plain = LAZY and not a and not kw and isinstance(edge_index, SparseTensor) and bn is not None and x.is_cuda and x.dim() == 2
+        if plain and DEFER_CONV and not torch.is_grad_enabled() and not self.training and not bn.training and not self._uses_memoised_input(x):
+            return L.LazyConv(self, x, edge_index, gcn_forward)       # inference: deferred until its consumer is known (lazy.py)
+        if plain and self.training and bn.training and self.in_channels >= self.out_channels and bn.running_mean is not None:
+            # training: the BatchNorm this conv is known to feed gets its statistics from the aggregation's epilogue (a tagged by-product
+            # of the same output; ignored by any other consumer)
+            out = gcn_forward(self, x, edge_index, bn_stats_shift=bn.running_mean, want_bn_stats=True)
+        else:
+            out = gcn_forward(self, x, edge_index, *a, **kw)
+        out._egnn_producer = self
+        return out
 
     def sage_consume(self, x, edge_index, *a, **kw):
         return sage_forward(self, L.materialise(x), edge_index, *a, **kw)

@@ -16,6 +16,11 @@ module's running-statistics update) and returns a ``LazyBnAct``: a tensor-like o
   * answers ``lazy[idx]`` for a 1-D int64 index with a ``LazyRows`` that a following ``Linear`` turns into the gather-fused GEMM
     (``ops.linear_rows``: no ``[N_tr, 256]`` copy forward, no zero-fill + scatter backward).
 
+Inference (``model.eval()`` under ``no_grad``): a ``GCNConv`` that has been SEEN feeding a ``BatchNorm1d`` (``accel`` learns the association
+from the first forward; it only decides what is deferred) hands out a ``LazyConv``; the eval-mode BatchNorm turns it into a ``LazyFold``
+that absorbs the ReLU and is formed as ONE pass -- the BatchNorm folded into the conv's weights, the ReLU in the last kernel's store.
+In training the same association gives the BatchNorm its statistics out of the aggregation's epilogue.
+
 Same arithmetic as ``models.train_step`` (the kernels are the same); dropout masks come from the same counter hash (one host seed per
 materialised dropout).  Consumers inside the package ask through ``materialise(x)`` / the ``_egnn_materialise`` attribute.
 """
@@ -154,6 +159,68 @@ class LazyBnAct(_TensorLike):
         h._egnn_tap = box
         self._value = h
         return h, xw
+
+    def __getitem__(self, idx):
+        if isinstance(idx, torch.Tensor) and idx.dtype == torch.int64 and idx.dim() == 1 and idx.is_cuda:
+            return LazyRows(self, idx)
+        return self._egnn_materialise()[idx]
+
+
+class LazyConv(_TensorLike):
+    """``conv(x, adj_t)`` of an inference forward (``model.eval()``, ``no_grad``), not run yet.  Only handed out by a ``GCNConv`` that has
+    been SEEN to feed a ``BatchNorm1d`` (the association is learned from the first forward, and only decides what is deferred -- any
+    consumer forms the same values): the BatchNorm turns it into a ``LazyFold``; everything else runs the conv now."""
+
+    def __init__(self, conv, x, adj_t, run):
+        self._conv, self._x, self._adj, self._run, self._value = conv, x, adj_t, run, None
+
+    shape = property(lambda self: torch.Size((self._x.shape[0], self._conv.out_channels)))
+    device = property(lambda self: self._x.device)
+
+    def _egnn_materialise(self, pick=None):
+        if self._value is None:
+            self._value = self._run(self._conv, self._x, self._adj)
+            self._value._egnn_producer = self._conv
+        return self._value if pick is None else self._value[pick]
+
+    def __getitem__(self, idx):
+        return self._egnn_materialise()[idx]
+
+
+class LazyFold(_TensorLike):
+    """``bn(conv(x, adj_t))`` in eval mode, deferred: with a following ``F.relu`` absorbed it is formed by ONE pass -- the BatchNorm folded
+    into the conv's weights and bias, the ReLU in the last kernel's store (``GCNConv.forward(eval_bn=)``: what ``models.evaluate`` runs;
+    gnn.py:47-49 under ``model.eval()``) -- instead of conv + a normalisation pass + a ReLU pass."""
+
+    def __init__(self, lazy_conv, bn, relu=False):
+        self._lc, self._bn, self._relu, self._value = lazy_conv, bn, relu, None
+
+    shape = property(lambda self: self._lc.shape)
+    device = property(lambda self: self._lc.device)
+
+    @classmethod
+    def _absorb(cls, func, args, kwargs):
+        x = args[0] if args else None
+        if not isinstance(x, LazyFold) or x._value is not None:
+            return NotImplemented
+        if func in (F.relu, torch.relu) and not kwargs.get("inplace", False) and len(args) == 1:
+            return x if x._relu else LazyFold(x._lc, x._bn, True)
+        if func is F.dropout and not kwargs.get("inplace", False) and len(args) <= 3:
+            training = args[2] if len(args) > 2 else kwargs.get("training", True)
+            p = args[1] if len(args) > 1 else kwargs.get("p", 0.5)
+            if not training or p == 0.0:
+                return x
+        return NotImplemented
+
+    def _egnn_materialise(self, pick=None):
+        if self._value is None:
+            lc, bn = self._lc, self._bn
+            if self._relu and lc._value is None and not torch.is_grad_enabled() and not bn.training:
+                self._value = lc._run(lc._conv, lc._x, lc._adj, eval_bn=bn)   # fold + ReLU in the last kernel's store
+            else:
+                y = ops.bn_act(lc._egnn_materialise(), bn, relu=self._relu, p=0.0, training=False)
+                self._value = y
+        return self._value if pick is None else self._value[pick]
 
     def __getitem__(self, idx):
         if isinstance(idx, torch.Tensor) and idx.dtype == torch.int64 and idx.dim() == 1 and idx.is_cuda:

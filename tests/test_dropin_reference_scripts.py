@@ -160,8 +160,17 @@ def test_reference_train_loop_runs_unchanged_on_the_new_operators(gnn, mode, scr
         out, accs = ref.test(model, data, split_idx, _Evaluator())
         assert out.shape == (d.num_nodes, d.num_classes) and all(0 <= a <= 1 for a in accs)
         if accel_mode == "lazy":     # the deferred form is what ran: out_feat of the script's model is the deferred object, formed by now
-            from efficient_gnns_amd.lazy import LazyBnAct
-            assert isinstance(model.out_feat, LazyBnAct) and model.out_feat._value is not None
+            from efficient_gnns_amd.lazy import LazyBnAct, LazyFold
+            assert isinstance(model.out_feat, (LazyBnAct, LazyFold)) and model.out_feat._value is not None
+            if gnn == "gcn":
+                # inference: the convs have been seen feeding their BatchNorms, so test() ran conv + BN + ReLU as ONE pass (the BatchNorm
+                # folded into the conv's weights, lazy.LazyFold); same logits as one launch per torch call
+                assert isinstance(model.out_feat, LazyFold) and model.out_feat._relu
+                accel.LAZY = False
+                out_eager, accs_eager = ref.test(model, data, split_idx, _Evaluator())
+                accel.LAZY = True
+                np.testing.assert_allclose(out.cpu().numpy(), out_eager.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(out_eager.abs().max()))
+                np.testing.assert_allclose(list(accs), list(accs_eager), atol=2.0 / min(int(v.numel()) for v in split_idx.values()))
     finally:
         if accel is not None:
             accel.disable()

@@ -191,6 +191,17 @@ def test_deferred_activation_protocol_on_host():
     assert d._value is None
     plain = torch.randn(5, 3)
     assert materialise(plain) is plain and torch.equal(materialise(plain, torch.tensor([2, 0])), plain[[2, 0]])
+    # inference: a deferred conv becomes a deferred fold under an eval-mode BatchNorm, which absorbs the ReLU (and F.dropout outside training)
+    import types
+    from efficient_gnns_amd.lazy import LazyConv, LazyFold
+    conv = types.SimpleNamespace(out_channels=8)
+    ran = []
+    lc = LazyConv(conv, torch.randn(16, 4), "adj", lambda c, x, a, **kw: ran.append(kw) or torch.ones(16, 8))
+    assert tuple(lc.shape) == (16, 8) and lc._value is None
+    fold = LazyFold(lc, bn.eval())
+    fr = F.dropout(F.relu(fold), p=0.5, training=False)
+    assert isinstance(fr, LazyFold) and fr._relu and not fold._relu and fr._value is None and not ran
+    assert torch.equal(materialise(lc), torch.ones(16, 8)) and ran == [{}]                  # any other consumer runs the conv as it is
     lr = LazyRows(plain, torch.tensor([4, 1, 3]))      # rows of a real tensor: a plain gather (torch indexing is plumbing, not a kernel)
     assert tuple(lr.shape) == (3, 3) and lr._value is None
     assert torch.equal(materialise(lr), plain[[4, 1, 3]]) and torch.equal(materialise(lr, torch.tensor([2])), plain[[3]])

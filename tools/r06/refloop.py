@@ -18,5 +18,8 @@ d = B.to_device(data, device)
 def show(tag):
     r = B.reference_loop(args, d, device, hp, epochs=30)
     print(tag, {k: v for k, v in r.items() if k not in ("what",)}, flush=True)
+import importlib.util
 show("fresh")
 show("again")
+# A/B of the deferred inference conv (accel.DEFER_CONV) inside the lazy leg, same process: bench.reference_loop loads its own accel module
+# from the file, so the switch is flipped in the source of truth -- an environment variable read at import
