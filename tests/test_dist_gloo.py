@@ -720,3 +720,77 @@ def test_community_order_lowers_the_halo_and_keeps_the_problem():
     flat = D.arxiv_like(scale=0.05, seed=1)
     perm_f, bf, af = DD.locality_order(flat, 8)
     assert perm_f is None or sum(af) < sum(bf)
+
+
+def _agg_forms_worker(rank, world, port, q):
+    """Operator level: ``ShardedAdj.aggregate`` in halo and in column-sliced form (forward and backward, sum with A^ values / valueless sum /
+    mean, with a bias) against the dense product, on a random graph with empty rows, a hub row and uneven node ranges."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _patch_ops_with_oracle()
+        import efficient_gnns_amd.dist as DD
+        g = torch.Generator().manual_seed(11)
+        n, K = 203, 16 * world                                   # 203 rows: the last range is shorter
+        dense = (torch.rand(n, n, generator=g) < 0.03).float()
+        dense[5] = 0.0                                           # an empty row
+        dense[:, 7] = 0.0                                        # a node nobody references
+        dense[11, :150] = 1.0                                    # a hub row
+        dense.fill_diagonal_(0.0)
+        rows, cols = dense.nonzero(as_tuple=True)
+        rowptr = torch.zeros(n + 1, dtype=torch.int64)
+        torch.cumsum(torch.bincount(rows, minlength=n), 0, out=rowptr[1:])
+        lo, hi, _ = DD.node_range(n, world, rank)
+        e0, e1 = int(rowptr[lo]), int(rowptr[hi])
+        sadj = DD.ShardedAdj(rowptr[lo:hi + 1] - e0, cols[e0:e1], n, world, rank, "cpu", None, with_gcn=True)
+        # dense references: raw A (sum / mean) and A^ = D^-1/2 (A + I) D^-1/2
+        ahat = dense + torch.eye(n)
+        dinv = ahat.sum(1).pow(-0.5)
+        ahat = dinv[:, None] * ahat * dinv[None, :]
+        cnt = dense.sum(1).clamp(min=1)
+        X = torch.randn(n, K, generator=g)
+        G = torch.randn(n, K, generator=g)
+        bias = torch.randn(K, generator=g)
+        worst = 0.0
+        for form in ("halo", "sliced"):
+            for kind, A, adj, kw in (("gcn", ahat, sadj.gcn_normalized(), dict(reduce="sum")),
+                                     ("sum", dense, sadj, dict(reduce="sum", valueless=True)),
+                                     ("mean", dense / cnt[:, None], sadj, dict(reduce="mean", valueless=True))):
+                adj.agg_mode = form
+                x = X[lo:hi].clone().requires_grad_(True)
+                b = bias.clone().requires_grad_(True)
+                y = adj.aggregate(x, bias=b, **kw)
+                y.backward(G[lo:hi])
+                xr = X.clone().requires_grad_(True)
+                br = bias.clone().requires_grad_(True)
+                (A @ xr + br)[lo:hi].backward(G[lo:hi])
+                gx_all = xr.grad.clone()                         # this rank's rows contribute to every source row: sum over ranks
+                dist.all_reduce(gx_all)
+                gb_ref = br.grad
+                for got, ref in ((y.detach(), (A @ X + bias)[lo:hi]), (x.grad, gx_all[lo:hi]), (b.grad, gb_ref)):
+                    worst = max(worst, float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-6)))
+                assert adj.sliced_pays(K) == (form == "sliced"), (form, kind)
+        out = [None] * world
+        dist.all_gather_object(out, worst)
+        if rank == 0:
+            q.put(out)
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        os._exit(1)
+    _quiet_exit()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_aggregate_forms_equal_the_dense_product_forward_and_backward(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agg_forms_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    worst = q.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert max(worst) < 2e-5, worst
