@@ -30,6 +30,7 @@ import torch
 _orig: dict = {}
 _NEXT_BN: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()    # GCNConv -> weakref(BatchNorm1d it was seen to feed); kept outside the modules (pickling)
 DEFER_CONV = os.environ.get("EGNN_ACCEL_DEFER_CONV", "1") != "0"   # inference: a GCNConv seen to feed a BatchNorm1d is deferred, so that conv + BN + ReLU run as one folded pass (lazy.LazyFold)
+MERGE_ADAM_GROUPS = os.environ.get("EGNN_ACCEL_MERGE_ADAM", "1") != "0"   # equal-option Adam groups stepped with one fused launch
 LAZY = True     # BatchNorm1d.forward returns a deferred activation (efficient_gnns_amd/lazy.py); False: one launch per torch call, as in round 5
 
 
@@ -122,6 +123,31 @@ def enable() -> None:
         adam_init(self, params, *args, **kwargs)
     torch.optim.Adam.__init__ = fused_adam_init
 
+    # gnn.py:308-312 hands Adam three parameter groups with the SAME options; the fused implementation launches once per group (latency-bound
+    # on 0.5 M parameters).  For the duration of step() the groups are presented as one -- the per-parameter state, ``param_groups`` and
+    # ``state_dict()`` of the optimizer stay exactly what the script built (the view is restored before step() returns).
+    adam_step = torch.optim.Adam.step
+    _orig["adam_step"] = adam_step
+
+    def _same(a, b):
+        return a is b if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor) else a == b
+
+    def merged_step(self, closure=None):
+        groups = self.param_groups
+        if MERGE_ADAM_GROUPS and len(groups) > 1 and all(g.get("fused") for g in groups) and not any(g.get("differentiable") for g in groups):
+            first = groups[0]
+            keys = [k for k in first if k != "params"]
+            if all(set(g) == set(first) and all(_same(g[k], first[k]) for k in keys) for g in groups[1:]):
+                merged = dict(first)
+                merged["params"] = [p for g in groups for p in g["params"]]
+                self.param_groups = [merged]
+                try:
+                    return adam_step(self, closure)
+                finally:
+                    self.param_groups = groups
+        return adam_step(self, closure)
+    torch.optim.Adam.step = merged_step
+
 
 _DOUBLE_BACKWARD = False
 
@@ -165,3 +191,4 @@ def disable() -> None:
     PN.GCNConv.forward = _orig.pop("gcn")
     PN.SAGEConv.forward = _orig.pop("sage")
     torch.optim.Adam.__init__ = _orig.pop("adam")
+    torch.optim.Adam.step = _orig.pop("adam_step")

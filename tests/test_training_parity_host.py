@@ -165,6 +165,40 @@ def test_dropin_accel_keeps_torch_paths_for_cpu_inputs_and_restores():
         accel.disable()
     assert torch.nn.BatchNorm1d.forward is bn0 and torch.nn.Linear.forward is lin0 and not accel.enabled()
     assert torch.allclose(got, want, atol=1e-6)
+    # round 6: under accel, Adam groups with equal options are stepped with ONE fused launch; parameters bit-equal to three launches, the
+    # optimizer's param_groups / state_dict keep the script's three groups, Adam.step is restored by disable()
+    torch.optim.Adam([torch.nn.Parameter(torch.zeros(1))])       # (the first Optimizer ever built wraps the class's step with torch's profiling hook)
+    step0 = torch.optim.Adam.step
+
+    def run(on):
+        torch.manual_seed(1)
+        mods = [torch.nn.Linear(4, 3), torch.nn.Linear(3, 2), torch.nn.Linear(2, 2)]
+        if on:
+            accel.enable()
+        try:
+            opt = torch.optim.Adam([{"params": m.parameters(), "lr": 0.01} for m in mods], fused=True)
+            for _ in range(3):
+                opt.zero_grad()
+                mods[2](mods[1](mods[0](torch.ones(5, 4)))).sum().backward()
+                opt.step()
+            assert len(opt.param_groups) == 3 and len(opt.state_dict()["param_groups"]) == 3
+            assert (torch.optim.Adam.step is not step0) == on
+        finally:
+            if on:
+                accel.disable()
+        return [p.detach().clone() for m in mods for p in m.parameters()]
+    assert all(torch.equal(a, b) for a, b in zip(run(False), run(True))) and torch.optim.Adam.step is step0
+    # groups with DIFFERENT options are never merged
+    accel.enable()
+    try:
+        a, b = torch.nn.Linear(2, 2), torch.nn.Linear(2, 2)
+        opt = torch.optim.Adam([{"params": a.parameters(), "lr": 0.1}, {"params": b.parameters(), "lr": 0.0}], fused=True)
+        b0 = b.weight.detach().clone()
+        (a(torch.ones(1, 2)) + b(torch.ones(1, 2))).sum().backward()
+        opt.step()
+        assert torch.equal(b.weight, b0) and not torch.equal(a.weight, torch.zeros_like(a.weight))
+    finally:
+        accel.disable()
 
 
 def test_deferred_activation_protocol_on_host():
