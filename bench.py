@@ -629,7 +629,8 @@ def reference_loop(args, d, device, hp, epochs=20, warmup=5):
                          "efficient-gnns_amd/dropin as dropin/launch.py runs it: eager launches; torch.nn.BatchNorm1d / torch.nn.Linear run on the "
                          "package's kernels, BatchNorm1d.forward returns a deferred activation (efficient_gnns_amd/lazy.py) that absorbs the script's "
                          "F.relu / F.dropout and is formed by its consumer in one launch (the next conv -- with its narrow h @ W --, a sampled "
-                         "criterion as only the sampled rows, Linear(out_feat[train_idx]) as the gather-fused GEMM); the script's "
+                         "criterion as only the sampled rows, Linear(out_feat[train_idx]) as the gather-fused GEMM, the constant teacher_out_feat[train_idx] "
+                         "gather deferred into the teacher head's planes GEMMs, inference convs folded with their BatchNorm); the script's "
                          "torch.optim.Adam(groups) resolves to the fused implementation (dropin/accel.py); faster of two blocks of `epochs`",
                     last_losses=[round(float(v), 5) for v in losses], last_accs=[round(float(a), 4) for a in accs])
     except Exception as e:  # noqa: BLE001  (a secondary leg must not take the headline line down)

@@ -180,6 +180,13 @@ def require_gpu(*tensors: torch.Tensor) -> None:
 #  itself has one code path: every operator goes through `ops.*`, and `require_gpu` refuses a CPU tensor.)
 
 
+def real(x):
+    """``x`` as a real tensor: deferred objects of ``lazy.py`` (the reference's own model code under dropin/accel.py) are formed now; tensors
+    and everything else pass through.  The public entry points that hand tensors to autograd Functions call it on their arguments."""
+    m = getattr(x, "_egnn_materialise", None)
+    return x if m is None else m()
+
+
 def build_info() -> str:
     buf = C.create_string_buffer(256)
     check(load().egnn_build_info(buf, 256), "egnn_build_info")

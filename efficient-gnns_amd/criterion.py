@@ -48,6 +48,17 @@ def _plain(x):
     return x if m is None else m()
 
 
+def _plain_args(fn):
+    """The classification / KD arguments (logits, labels, teacher_logits) of a criterion as real tensors (a deferred constant gather,
+    dropin/accel.py, may reach them); the feature arguments are consumed lazily where that pays (``_rows_of``)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(logits, labels, *args, **kw):
+        return fn(_plain(logits), _plain(labels), *args, **kw)
+    return wrapped
+
+
 def _ce_term(logits, labels, rows=None):
     return ops.cross_entropy(logits, labels, rows)
 
@@ -74,7 +85,7 @@ def kd_criterion(logits, labels, teacher_logits, alpha=0.9, T=4):
 
 def rows_kd_criterion(logits, labels, teacher_logits, alpha=0.9, T=4, rows=None):
     """``kd_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
-    loss_cls, loss_kd = ops.ce_and_kd(logits, labels, teacher_logits, T, rows)
+    loss_cls, loss_kd = ops.ce_and_kd(_plain(logits), _plain(labels), _plain(teacher_logits), T, rows)
     loss = loss_kd * (alpha * T * T) + loss_cls * (1 - alpha)
     return loss, loss_cls, loss_kd
 
@@ -89,6 +100,7 @@ def fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000):
     return rows_fitnet_criterion(logits, labels, feat, teacher_feat, beta, rows=None)
 
 
+@_plain_args
 def rows_fitnet_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=None, *, _cls=None):
     """``fitnet_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
     loss_cls = (_cls or _ce_term)(logits, labels, rows)
@@ -101,6 +113,7 @@ def at_criterion(logits, labels, feat, teacher_feat, beta=1000):
     return rows_at_criterion(logits, labels, feat, teacher_feat, beta, rows=None)
 
 
+@_plain_args
 def rows_at_criterion(logits, labels, feat, teacher_feat, beta=1000, rows=None, *, _cls=None):
     """``at_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
     loss_cls = (_cls or _ce_term)(logits, labels, rows)
@@ -113,6 +126,7 @@ def gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, m
     return rows_gpw_criterion(logits, labels, feat, teacher_feat, kernel, beta, max_samples, rows=None)
 
 
+@_plain_args
 def rows_gpw_criterion(logits, labels, feat, teacher_feat, kernel="cosine", beta=1, max_samples=8192, rows=None, presampled=False, *, _cls=None):
     """``gpw_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call).
     ``presampled``: ``feat`` / ``teacher_feat`` already are the sampled rows (the caller made the draw with ``_sample_rows``)."""
@@ -133,6 +147,7 @@ def lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="cosine
     return rows_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel, beta, criterion, rows=None)
 
 
+@_plain_args
 def rows_lpw_criterion(logits, labels, feat, teacher_feat, edge_index, kernel="cosine", beta=100, criterion="kld", rows=None, *, _cls=None):
     """``lpw_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call)."""
     from .ops_edge import lsp_loss
@@ -148,6 +163,7 @@ def nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max
     return rows_nce_criterion(logits, labels, feat, teacher_feat, beta, nce_T, max_samples, rows=None)
 
 
+@_plain_args
 def rows_nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075, max_samples=8192, rows=None, presampled=False, *, _cls=None):
     """``nce_criterion`` on the rows ``rows`` of full-size logits / labels (None: all rows, the reference's call).
     ``presampled``: as in ``rows_gpw_criterion``."""
@@ -189,5 +205,5 @@ def ppi_nce_criterion(logits, labels, feat, teacher_feat, beta=0.5, nce_T=0.075,
 def ppi_kd_criterion(logits, labels, teacher_logits, alpha=0.5, T=1):
     """Multi-label KD of /root/reference/ppi_pyg/criterion.py:8-18 (BCE-with-logits twice)."""
     from .ops_pairwise import bce_with_logits_pair
-    loss_cls, loss_kd = bce_with_logits_pair(logits, labels, teacher_logits)
+    loss_cls, loss_kd = bce_with_logits_pair(_plain(logits), _plain(labels), _plain(teacher_logits))
     return loss_kd * (alpha * T * T) + loss_cls * (1 - alpha), loss_cls, loss_kd

@@ -15,6 +15,13 @@ everything else takes the original path -- at this package's kernels:
     update (gnn.py:308-312 passes parameter groups and ``lr`` only) in one launch per group instead of PyTorch's default
     multi-tensor chain (~0.3 ms per step on the headline problem).
 
+Round 6 (all scoped to ``enable()`` .. ``disable()``, each with its switch): ``BatchNorm1d.forward`` returns a deferred activation that
+absorbs the script's ``F.relu`` / ``F.dropout`` (``LAZY``, efficient_gnns_amd/lazy.py); inference convs seen feeding a BatchNorm are folded
+with it (``DEFER_CONV``); equal-option Adam groups are stepped with one fused launch (``MERGE_ADAM_GROUPS``); and ``torch.Tensor.__getitem__``
+is guarded so that ONE kind of indexing -- a row gather of a large float32 GPU leaf outside autograd by a 1-D int64 GPU index inside a
+grad-enabled region, i.e. ``teacher_out_feat[train_idx]`` of gnn.py:155 -- is deferred into the consuming ``Linear``'s planes GEMMs
+(``DEFER_CONST_GATHER``); every other indexing expression takes torch's path unchanged.
+
 Same values within the fp32 tolerance of the package's parity tests; ``disable()`` restores torch's methods.  ``launch.py`` enables
 it unless ``--plain-torch-modules`` is given.  Scoped forms for code that must not change torch process-wide: ``with accel.scope():``
 (enabled inside the block only) and ``with accel.double_backward():`` (torch's own kernels for a ``create_graph=True`` region: the
@@ -30,6 +37,9 @@ import torch
 _orig: dict = {}
 _NEXT_BN: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()    # GCNConv -> weakref(BatchNorm1d it was seen to feed); kept outside the modules (pickling)
 DEFER_CONV = os.environ.get("EGNN_ACCEL_DEFER_CONV", "1") != "0"   # inference: a GCNConv seen to feed a BatchNorm1d is deferred, so that conv + BN + ReLU run as one folded pass (lazy.LazyFold)
+DEFER_CONST_GATHER = os.environ.get("EGNN_ACCEL_DEFER_GATHER", "1") != "0"   # big constant row gathers deferred into the consuming Linear
+_BIG_GATHER = 1 << 24          # elements of the gathered-from tensor from which a row gather is worth deferring (64 MB of float32) ...
+_MIN_GATHER_ROWS = 16384       # ... and rows gathered (the planes forms of ops.linear_rows start there); tests lower both
 MERGE_ADAM_GROUPS = os.environ.get("EGNN_ACCEL_MERGE_ADAM", "1") != "0"   # equal-option Adam groups stepped with one fused launch
 LAZY = True     # BatchNorm1d.forward returns a deferred activation (efficient_gnns_amd/lazy.py); False: one launch per torch call, as in round 5
 
@@ -148,6 +158,22 @@ def enable() -> None:
         return adam_step(self, closure)
     torch.optim.Adam.step = merged_step
 
+    # gnn.py:155 ``teacher_proj(teacher_out_feat[train_idx])``: a 273 MB gather of a tensor that never changes, followed by GEMMs on the fresh
+    # copy.  A row gather of a LARGE float32 GPU leaf that takes no part in autograd, by a 1-D int64 GPU index, inside a grad-enabled region
+    # (the train step) is deferred (lazy.LazyRows): a following Linear runs the gather-fused GEMM on the tensor's once-cut bf16 planes
+    # (ops.linear_rows(..., const_input=True): keyed on identity + version, so an in-place change of the tensor re-cuts them); any other
+    # consumer gets the gathered rows.  Everything else indexes as before.
+    getitem = torch.Tensor.__getitem__
+    _orig["getitem"] = getitem
+
+    def deferring_getitem(self, idx):
+        if (DEFER_CONST_GATHER and LAZY and type(idx) is torch.Tensor and type(self) is torch.Tensor and idx.dtype == torch.int64 and idx.dim() == 1
+                and self.dim() == 2 and self.dtype == torch.float32 and self.is_cuda and idx.is_cuda and not self.requires_grad and self.grad_fn is None
+                and self.shape[0] * self.shape[1] >= _BIG_GATHER and idx.numel() >= _MIN_GATHER_ROWS and torch.is_grad_enabled()):
+            return L.LazyRows(self, idx, const_base=True)
+        return getitem(self, idx)
+    torch.Tensor.__getitem__ = deferring_getitem
+
 
 _DOUBLE_BACKWARD = False
 
@@ -192,3 +218,4 @@ def disable() -> None:
     PN.SAGEConv.forward = _orig.pop("sage")
     torch.optim.Adam.__init__ = _orig.pop("adam")
     torch.optim.Adam.step = _orig.pop("adam_step")
+    torch.Tensor.__getitem__ = _orig.pop("getitem")

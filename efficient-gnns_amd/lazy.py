@@ -231,8 +231,8 @@ class LazyFold(_TensorLike):
 class LazyRows(_TensorLike):
     """``base[idx]`` (unique 1-D int64 ids) not gathered yet: a ``Linear`` consumes it as ``ops.linear_rows(base, idx, W, b)``."""
 
-    def __init__(self, base, idx):
-        self._base, self._idx, self._value = base, idx, None
+    def __init__(self, base, idx, const_base=False):
+        self._base, self._idx, self._value, self._const = base, idx, None, const_base
 
     shape = property(lambda self: torch.Size((self._idx.numel(),) + tuple(self._base.shape[1:])))
     device = property(lambda self: self._idx.device)
@@ -246,9 +246,12 @@ class LazyRows(_TensorLike):
         return self._value if pick is None else self._value[pick]
 
     def linear(self, weight, bias):
-        return ops.linear_rows(materialise(self._base), self._idx, weight, bias)
+        base = materialise(self._base)
+        # ``const_base``: the gathered-from tensor is a leaf outside autograd (accel's deferred constant gather): its rows as once-cut planes
+        const = bool(self._const and not base.requires_grad and base.grad_fn is None)
+        return ops.linear_rows(base, self._idx, weight, bias, const_input=const)
 
     def __getitem__(self, idx):
         if isinstance(idx, torch.Tensor) and idx.dtype == torch.int64 and idx.dim() == 1 and idx.is_cuda and self._value is None:
-            return LazyRows(self._base, self._idx[idx])
+            return LazyRows(self._base, self._idx[idx], self._const)
         return self._egnn_materialise()[idx]

@@ -248,6 +248,7 @@ class GATConv(nn.Module):
         return SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(n, n))
 
     def forward(self, x: Tensor, edge_index) -> Tensor:
+        x = _lib.real(x)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError("GATConv runs the frozen teacher (torch.no_grad() / requires_grad_(False)); "
                                       "teacher training is out of scope")
@@ -336,6 +337,7 @@ class DGLGATConv(nn.Module):
         return st["dgl_norm"]
 
     def forward(self, adj: SparseTensor, feat: Tensor) -> Tensor:
+        feat = _lib.real(feat)
         if torch.is_grad_enabled() and (feat.requires_grad or any(p.requires_grad for p in self.parameters())):
             raise NotImplementedError("DGLGATConv runs the teacher's inference forward (torch.no_grad()); teacher training is out of scope")
         if self.training and (self.edge_drop > 0 or self.attn_drop_p > 0 or self.feat_drop_p > 0):
@@ -422,6 +424,7 @@ class RGCNConv(nn.Module):
         return _RGCN_REL_CACHE.get((edge_index, edge_type, node_type), (n, self.num_edge_types, self.num_node_types), build)
 
     def forward(self, x: Tensor, edge_index: Tensor, edge_type: Tensor, node_type: Tensor) -> Tensor:
+        x = _lib.real(x)
         _lib.require_gpu(x, edge_index)
         n = x.shape[0]
         adjs, rows = self._relations(edge_index, edge_type, node_type, n)

@@ -362,8 +362,9 @@ class SparseTensor:
 
     # ---- matmul --------------------------------------------------------------------------------
     def matmul(self, x: Tensor, reduce: str = "sum") -> Tensor:
+        from . import _lib
         from .ops import spmm
-        return spmm(self, x, reduce)
+        return spmm(self, _lib.real(x), reduce)
 
     def __matmul__(self, x: Tensor) -> Tensor:
         return self.matmul(x, "sum")

@@ -31,8 +31,9 @@ def subgraph(subset: Tensor, edge_index: Tensor, edge_attr=None, relabel_nodes: 
 
 def softmax(src: Tensor, index: Tensor, ptr=None, num_nodes: int | None = None) -> Tensor:
     """Segment softmax over entries grouped by ``index``: exp(src - max) / (sum + 1e-16)."""
+    from . import _lib
     from .ops_edge import segment_softmax
-    return segment_softmax(src, index, num_nodes)
+    return segment_softmax(_lib.real(src), index, num_nodes)
 
 
 def dgl_bidirected_with_self_loops(adj_t):

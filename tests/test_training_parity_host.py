@@ -148,7 +148,7 @@ def test_dropin_accel_keeps_torch_paths_for_cpu_inputs_and_restores():
     spec = importlib.util.spec_from_file_location("egnn_dropin_accel_cpu", os.path.join(ROOT, "efficient-gnns_amd", "dropin", "accel.py"))
     accel = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(accel)
-    bn0, lin0 = torch.nn.BatchNorm1d.forward, torch.nn.Linear.forward
+    bn0, lin0, getitem0 = torch.nn.BatchNorm1d.forward, torch.nn.Linear.forward, torch.Tensor.__getitem__
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU())
     x = torch.randn(32, 8)
@@ -157,6 +157,11 @@ def test_dropin_accel_keeps_torch_paths_for_cpu_inputs_and_restores():
     accel.enable()
     try:
         assert accel.enabled() and torch.nn.BatchNorm1d.forward is not bn0
+        # tensor indexing goes through accel's guard while it is enabled: CPU tensors (and every index kind but a big constant row gather
+        # on the GPU) index exactly as before
+        t = torch.arange(12.0).view(3, 4)
+        assert torch.Tensor.__getitem__ is not getitem0 and torch.equal(t[torch.tensor([2, 0])], t.index_select(0, torch.tensor([2, 0])))
+        assert float(t[1, 2]) == 6.0 and torch.equal(t[:, 1], torch.tensor([1.0, 5.0, 9.0])) and torch.equal(t[t > 10], torch.tensor([11.0]))
         net2 = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU())
         net2.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
         net2[1].running_mean.zero_(); net2[1].running_var.fill_(1.0); net2[1].num_batches_tracked.zero_()
@@ -164,6 +169,7 @@ def test_dropin_accel_keeps_torch_paths_for_cpu_inputs_and_restores():
     finally:
         accel.disable()
     assert torch.nn.BatchNorm1d.forward is bn0 and torch.nn.Linear.forward is lin0 and not accel.enabled()
+    assert torch.Tensor.__getitem__ is getitem0
     assert torch.allclose(got, want, atol=1e-6)
     # round 6: under accel, Adam groups with equal options are stepped with ONE fused launch; parameters bit-equal to three launches, the
     # optimizer's param_groups / state_dict keep the script's three groups, Adam.step is restored by disable()
